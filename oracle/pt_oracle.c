@@ -1,0 +1,748 @@
+/*
+ * pt_oracle.c — CPU restatement of the reference's path-tracing integrator.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, load or call this file.
+ * The product (opentk-pathtracer_amd/csrc, libmi355pt.so) never includes, links or falls back to it.
+ *
+ * What it restates, function by function (all paths relative to /root/reference/OpenTK-PathTracer/):
+ *   res/shaders/PathTracing/compute.glsl:101-369          the integrator (cited per function below)
+ *   res/shaders/AtmosphericScattering/compute.glsl:30-171 the atmosphere env-map precompute
+ *   src/Render/PathTracer.cs:114-129                      frame counter / dispatch semantics
+ *
+ * PINNING: the reference has no tests or golden vectors of its own.  This oracle is
+ * pinned against outputs of the reference ITSELF run in the build container: the unmodified GLSL executed
+ * by Mesa llvmpipe through oracle/glsl_ref/glsl_runner.c; the resulting fixtures are committed under
+ * tests/golden/ (generator: tests/golden/make_golden.py) and checked by tests/test_oracle_vs_reference.py.
+ *
+ * ARITHMETIC CONTRACT ("pt-f32", shared with the HIP kernel so that HIP == oracle BIT-FOR-BIT):
+ *   - every value is IEEE-754 binary32; +,-,*,/ and sqrt are correctly rounded; denormals are kept;
+ *   - a*b+c is fused ONLY where this file writes fmaf() — compile with -ffp-contract=off;
+ *   - dot(a,b)      = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
+ *   - normalize(v)  = v * (1.0f / sqrtf(dot(v,v)))
+ *   - mix(x,y,a)    = fma(y, a, x*(1-a))                       (GLSL 4.50 section 8.3 definition)
+ *   - min/max       = IEEE minNum/maxNum (fminf/fmaxf); GLSL leaves NaN handling undefined
+ *   - sin/cos/exp   = the fixed polynomial algorithms below (<= ~1.5 ulp), pow(x,5) = x*(x^2)^2,
+ *                     pow(x,1.5) = x*sqrt(x)
+ *   - cuboid slabs  : (Min-O)/D is evaluated as (Min-O) * (1.0f/D)  (GLSL 4.50 section 4.7.1 allows 2.5 ulp
+ *                     for a/b; one correctly-rounded reciprocal per ray component instead of six divisions per
+ *                     cuboid).  Define PT_SLAB_TRUE_DIVISION to get the literal a/b form (kept for the
+ *                     fidelity study in DESIGN.md; the HIP kernel implements the reciprocal form).
+ *   GLSL itself leaves precision of all of these implementation-defined; llvmpipe is one realisation, this
+ *   contract is another.  The stated tolerance against llvmpipe lives in tests/test_oracle_vs_reference.py.
+ *
+ * Build: gcc -O2 -ffp-contract=off -mfma -shared -fPIC pt_oracle.c -o _build/libpt_oracle.so -lm -lpthread
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PTO_API __attribute__((visibility("default")))
+
+#define FLOAT_MAX 3.4028235e+38f /* compute.glsl:2 */
+#define FLOAT_MIN -3.4028235e+38f /* compute.glsl:3 */
+#define EPSILON 0.001f            /* compute.glsl:4 */
+#define PI 3.14159265f            /* compute.glsl:5 */
+
+typedef struct { float x, y, z; } v3;
+
+/* ------------------------------------------------------------------ pt-f32 primitives */
+static inline float f_min(float a, float b) { return fminf(a, b); }
+static inline float f_max(float a, float b) { return fmaxf(a, b); }
+static inline float f_rcp(float a) { return 1.0f / a; }
+static inline float f_mix(float x, float y, float a) { return fmaf(y, a, x * (1.0f - a)); }
+
+static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 v_add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v_sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v_mul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 v_scale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 v_neg(v3 a) { return V(-a.x, -a.y, -a.z); }
+/* a + b*s, fused */
+static inline v3 v_fma(v3 b, float s, v3 a) { return V(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z)); }
+static inline float v_dot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline v3 v_normalize(v3 a) { return v_scale(a, f_rcp(sqrtf(v_dot(a, a)))); }
+static inline v3 v_mix(v3 x, v3 y, float a)
+{
+    float ia = 1.0f - a;
+    return V(fmaf(y.x, a, x.x * ia), fmaf(y.y, a, x.y * ia), fmaf(y.z, a, x.z * ia));
+}
+
+static inline float f_from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* sin and cos of a (radians), |a| small (the integrator only passes [0, 2*pi]).  Cody-Waite reduction by pi/2
+ * with two fused steps, then the classic single-precision minimax polynomials on [-pi/4, pi/4]. */
+static void f_sincos(float a, float *sn, float *cs)
+{
+    float k = rintf(a * 0.636619772f);
+    float r = fmaf(k, -1.57079637050628662109375f, a);
+    r = fmaf(k, 4.37113900018624283e-8f, r);
+    float z = r * r;
+    float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float s = fmaf(ps * z, r, r);
+    float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    float c = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    int q = (int)k & 3;
+    float s_out = (q & 1) ? c : s;
+    float c_out = (q & 1) ? s : c;
+    if (q == 1 || q == 2) c_out = -c_out;
+    if (q >= 2) s_out = -s_out;
+    *sn = s_out;
+    *cs = c_out;
+}
+
+/* e^x.  n = rint(x*log2 e), r = x - n*ln2 (two fused steps), degree-6 polynomial, 2^n applied as two exact
+ * power-of-two factors so that denormal results are rounded once. */
+static float f_exp(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return INFINITY;
+    if (x < -104.0f) return 0.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.428606765330187045e-06f, r);
+    float p = fmaf(1.9875691500e-4f, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float y = fmaf(p, r * r, r) + 1.0f;
+    int ni = (int)n;
+    int n1 = ni >> 1, n2 = ni - n1;
+    y = y * f_from_bits((uint32_t)(n1 + 127) << 23);
+    return y * f_from_bits((uint32_t)(n2 + 127) << 23);
+}
+
+static inline float f_pow5(float x) { float x2 = x * x; return x * (x2 * x2); }
+
+/* ------------------------------------------------------------------ scene blob accessors (std140, compute.glsl:13-42,66-70) */
+#define SPHERE_STRIDE 20  /* floats: 80 B  */
+#define CUBOID_STRIDE 24  /* floats: 96 B  */
+#define CUBOIDS_OFFSET 5120 /* floats: 20480 B = 256 * 80 */
+
+typedef struct {
+    v3 albedo;   float specularChance;
+    v3 emissiv;  float specularRoughness;
+    v3 absorbance; float refractionChance;
+    float refractionRoughness, ior;
+} Material;
+
+static Material load_material(const float *m)
+{
+    Material r;
+    r.albedo = V(m[0], m[1], m[2]);      r.specularChance = m[3];
+    r.emissiv = V(m[4], m[5], m[6]);     r.specularRoughness = m[7];
+    r.absorbance = V(m[8], m[9], m[10]); r.refractionChance = m[11];
+    r.refractionRoughness = m[12];       r.ior = m[13];
+    return r;
+}
+
+typedef struct {
+    /* BasicDataUBO, compute.glsl:59-64: float[4c+r] = element (row r, col c) of the GLSL matrix */
+    float invProj[16], invView[16];
+    v3 viewPos;
+    const float *objects; /* 6656 floats */
+    int numSpheres, numCuboids; /* loops are `int i < float n` (compute.glsl:231,244): i < n  <=>  i < ceil(n) */
+    int rayDepth, spp;
+    float focalLength, apertureDiameter;
+    int width, height;
+    int envSize, envFormat; /* 0 = RGBA32F (float[6][S][S][4]), 1 = SRGB8_A8 (uint8[6][S][S][4]) */
+    const void *env;
+    float srgbLut[256];
+} Ctx;
+
+typedef struct { uint64_t samples, bounces, sphereTests, cuboidTests, envLookups, rngDraws; } Stats;
+
+/* ------------------------------------------------------------------ RNG (compute.glsl:334-344) */
+static inline uint32_t pcg_hash(uint32_t *seed)
+{
+    *seed = *seed * 747796405u + 2891336453u;
+    uint32_t word = ((*seed >> ((*seed >> 28u) + 4u)) ^ *seed) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+static inline float rand01(uint32_t *seed) { return (float)pcg_hash(seed) * 2.3283064365386962890625e-10f; /* / 2^32, exact */ }
+
+/* ------------------------------------------------------------------ environment lookup (compute.glsl:177)
+ * texture(samplerCube, dir) from a compute stage: no derivatives -> LOD 0 -> MAG filter = LINEAR
+ * (MainWindow.cs:178, AtmosphericScatterer.cs:68), GL_TEXTURE_CUBE_MAP_SEAMLESS on (MainWindow.cs:168).
+ * Face selection / (s,t) mapping: OpenGL 4.5 core spec, table 8.19; ties go Z, then X, then Y (llvmpipe).
+ * Seamless filtering: taps that fall off a face edge are fetched from the adjacent face; at a cube corner the
+ * tap that falls off two edges has no texel and is replaced by the average of the other three.
+ * SRGB8_A8 texels are linearised before filtering (GL 4.5 section 8.24). */
+typedef struct { float r, g, b; } rgb;
+
+static rgb env_texel(const Ctx *c, int face, int x, int y)
+{
+    size_t idx = (((size_t)face * c->envSize + (size_t)y) * c->envSize + (size_t)x) * 4;
+    rgb o;
+    if (c->envFormat == 0) {
+        const float *p = (const float *)c->env + idx;
+        o.r = p[0]; o.g = p[1]; o.b = p[2];
+    } else {
+        const uint8_t *p = (const uint8_t *)c->env + idx;
+        o.r = c->srgbLut[p[0]]; o.g = c->srgbLut[p[1]]; o.b = c->srgbLut[p[2]];
+    }
+    return o;
+}
+
+/* direction of the point (s,t) in [-1,1]^2 on `face` (inverse of table 8.19), not normalised */
+static void face_to_dir(int face, float sc, float tc, float *x, float *y, float *z)
+{
+    switch (face) {
+    case 0: *x = 1.0f;  *y = -tc;  *z = -sc;  break;
+    case 1: *x = -1.0f; *y = -tc;  *z = sc;   break;
+    case 2: *x = sc;    *y = 1.0f; *z = tc;   break;
+    case 3: *x = sc;    *y = -1.0f; *z = -tc; break;
+    case 4: *x = sc;    *y = -tc;  *z = 1.0f; break;
+    default: *x = -sc;  *y = -tc;  *z = -1.0f; break;
+    }
+}
+
+static void dir_to_face(float x, float y, float z, int *face, float *sc, float *tc, float *ma)
+{
+    float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+    if (az >= f_max(ax, ay)) { *face = z < 0.0f ? 5 : 4; *ma = az; *sc = z < 0.0f ? -x : x; *tc = -y; }
+    else if (ax >= ay)       { *face = x < 0.0f ? 1 : 0; *ma = ax; *sc = x < 0.0f ? z : -z; *tc = -y; }
+    else                     { *face = y < 0.0f ? 3 : 2; *ma = ay; *sc = x; *tc = y < 0.0f ? -z : z; }
+}
+
+/* integer texel (ix,iy) possibly one step outside `face` in ONE direction -> texel on the neighbouring face */
+static rgb env_texel_wrapped(const Ctx *c, int face, int ix, int iy)
+{
+    int S = c->envSize;
+    if (ix >= 0 && ix < S && iy >= 0 && iy < S) return env_texel(c, face, ix, iy);
+    /* texel centre in face coordinates, then re-project through 3D onto the neighbour face */
+    float fs = (float)S;
+    float sc = ((float)ix + 0.5f) / fs * 2.0f - 1.0f;
+    float tc = ((float)iy + 0.5f) / fs * 2.0f - 1.0f;
+    float x, y, z, ma, nsc, ntc;
+    int nface;
+    face_to_dir(face, sc, tc, &x, &y, &z);
+    /* push the major axis below the overflowing one so the neighbour wins the selection */
+    dir_to_face(x, y, z, &nface, &nsc, &ntc, &ma);
+    float u = (nsc / ma * 0.5f + 0.5f) * fs;
+    float v = (ntc / ma * 0.5f + 0.5f) * fs;
+    int nx = (int)floorf(u), ny = (int)floorf(v);
+    if (nx < 0) nx = 0; if (nx > S - 1) nx = S - 1;
+    if (ny < 0) ny = 0; if (ny > S - 1) ny = S - 1;
+    return env_texel(c, nface, nx, ny);
+}
+
+static rgb sample_env(const Ctx *c, v3 d)
+{
+    int S = c->envSize, face;
+    float sc, tc, ma;
+    dir_to_face(d.x, d.y, d.z, &face, &sc, &tc, &ma);
+    float ima = 0.5f / ma;
+    float fs = (float)S;
+    float u = fmaf(sc, ima, 0.5f) * fs - 0.5f;
+    float v = fmaf(tc, ima, 0.5f) * fs - 0.5f;
+    /* NaN / inf coordinates (NaN ray directions, compute.glsl:211 with total internal reflection):
+       clamp so that the integer conversion below is defined identically on CPU and GPU */
+    u = f_min(f_max(u, -1.0f), fs);
+    v = f_min(f_max(v, -1.0f), fs);
+    float fu = floorf(u), fv = floorf(v);
+    float wu = u - fu, wv = v - fv;
+    int x0 = (int)fu, y0 = (int)fv, x1 = x0 + 1, y1 = y0 + 1;
+    int offx0 = x0 < 0, offx1 = x1 >= S, offy0 = y0 < 0, offy1 = y1 >= S;
+    float w00 = (1.0f - wu) * (1.0f - wv), w10 = wu * (1.0f - wv), w01 = (1.0f - wu) * wv, w11 = wu * wv;
+    int miss00 = offx0 && offy0, miss10 = offx1 && offy0, miss01 = offx0 && offy1, miss11 = offx1 && offy1;
+    rgb t00 = { 0, 0, 0 }, t10 = t00, t01 = t00, t11 = t00;
+    if (!miss00) t00 = env_texel_wrapped(c, face, x0, y0);
+    if (!miss10) t10 = env_texel_wrapped(c, face, x1, y0);
+    if (!miss01) t01 = env_texel_wrapped(c, face, x0, y1);
+    if (!miss11) t11 = env_texel_wrapped(c, face, x1, y1);
+    if (miss00 || miss10 || miss01 || miss11) {
+        /* cube corner: the tap that fell off two edges has no texel; it is replaced by the average of the other
+           three, i.e. its bilinear weight is shared equally among them (llvmpipe behaviour — pinned by the
+           tiny-cube fixtures in tests/golden; GL 4.5 section 8.14.2 recommends exactly this average) */
+        float a = (miss00 ? w00 : miss10 ? w10 : miss01 ? w01 : w11) * 0.333333343f;
+        w00 = miss00 ? 0.0f : w00 + a; w10 = miss10 ? 0.0f : w10 + a;
+        w01 = miss01 ? 0.0f : w01 + a; w11 = miss11 ? 0.0f : w11 + a;
+    }
+    rgb o;
+    o.r = fmaf(t11.r, w11, fmaf(t01.r, w01, fmaf(t10.r, w10, t00.r * w00)));
+    o.g = fmaf(t11.g, w11, fmaf(t01.g, w01, fmaf(t10.g, w10, t00.g * w00)));
+    o.b = fmaf(t11.b, w11, fmaf(t01.b, w01, fmaf(t10.b, w10, t00.b * w00)));
+    return o;
+}
+
+/* ------------------------------------------------------------------ intersections */
+/* compute.glsl:261-277 RaySphereIntersect */
+static int ray_sphere(v3 o, v3 d, v3 pos, float radius, float *t1, float *t2)
+{
+    *t1 = *t2 = FLOAT_MAX;
+    v3 oc = v_sub(o, pos);
+    float b = v_dot(d, oc);
+    float c = fmaf(-radius, radius, v_dot(oc, oc));
+    float disc = fmaf(b, b, -c);
+    if (disc < 0.0f) return 0;
+    float s = sqrtf(disc);
+    *t1 = -b - s;
+    *t2 = -b + s;
+    return *t1 <= *t2;
+}
+
+/* compute.glsl:280-294 RayCuboidIntersect */
+static int ray_cuboid(v3 o, v3 d, v3 invd, v3 mn, v3 mx, float *t1, float *t2)
+{
+#ifdef PT_SLAB_TRUE_DIVISION
+    (void)invd;
+    v3 t0s = V((mn.x - o.x) / d.x, (mn.y - o.y) / d.y, (mn.z - o.z) / d.z);
+    v3 t1s = V((mx.x - o.x) / d.x, (mx.y - o.y) / d.y, (mx.z - o.z) / d.z);
+#else
+    (void)d;
+    v3 t0s = v_mul(v_sub(mn, o), invd);
+    v3 t1s = v_mul(v_sub(mx, o), invd);
+#endif
+    v3 sm = V(f_min(t0s.x, t1s.x), f_min(t0s.y, t1s.y), f_min(t0s.z, t1s.z));
+    v3 bg = V(f_max(t0s.x, t1s.x), f_max(t0s.y, t1s.y), f_max(t0s.z, t1s.z));
+    *t1 = f_max(FLOAT_MIN, f_max(sm.x, f_max(sm.y, sm.z)));
+    *t2 = f_min(FLOAT_MAX, f_min(bg.x, f_min(bg.y, bg.z)));
+    return *t1 <= *t2;
+}
+
+static inline float f_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+static inline float f_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+
+/* compute.glsl:322-332 GetNormal(Cuboid) */
+static v3 cuboid_normal(v3 mn, v3 mx, v3 p)
+{
+    v3 half = v_scale(v_sub(mx, mn), 0.5f);
+    v3 cs = v_sub(p, v_scale(v_add(mx, mn), 0.5f));
+    v3 n;
+    n.x = f_sign(cs.x) * f_step(fabsf(fabsf(cs.x) - half.x), EPSILON);
+    n.y = f_sign(cs.y) * f_step(fabsf(fabsf(cs.y) - half.y), EPSILON);
+    n.z = f_sign(cs.z) * f_step(fabsf(fabsf(cs.z) - half.z), EPSILON);
+    return v_normalize(n);
+}
+
+typedef struct {
+    float T; int fromInside; v3 nearHitPos, normal; Material m;
+} HitInfo;
+
+/* compute.glsl:226-258 RayTrace.  The acceptance test uses the ENTRY distance t1 against the stored
+ * GetSmallestPositive(t1,t2) (compute.glsl:234,247,347-350): an object that contains the origin (t1<0) always
+ * replaces the current hit.  Objects are visited in reference order.  Material/normal are evaluated once for
+ * the surviving candidate (the reference evaluates them per accepted candidate and overwrites). */
+static int ray_trace(const Ctx *c, v3 o, v3 d, HitInfo *h, Stats *st)
+{
+    float T = FLOAT_MAX, t1, t2, wt2 = 0.0f;
+    int winner = -1;
+    const float *ob = c->objects;
+    for (int i = 0; i < c->numSpheres; i++) {
+        const float *s = ob + (size_t)i * SPHERE_STRIDE;
+        if (ray_sphere(o, d, V(s[0], s[1], s[2]), s[3], &t1, &t2) && t2 > 0.0f && t1 < T) {
+            T = t1 < 0.0f ? t2 : t1;
+            wt2 = t2;
+            winner = i;
+        }
+    }
+    v3 invd = V(f_rcp(d.x), f_rcp(d.y), f_rcp(d.z));
+    for (int i = 0; i < c->numCuboids; i++) {
+        const float *q = ob + CUBOIDS_OFFSET + (size_t)i * CUBOID_STRIDE;
+        if (ray_cuboid(o, d, invd, V(q[0], q[1], q[2]), V(q[4], q[5], q[6]), &t1, &t2) && t2 > 0.0f && t1 < T) {
+            T = t1 < 0.0f ? t2 : t1;
+            wt2 = t2;
+            winner = 256 + i;
+        }
+    }
+    if (st) { st->sphereTests += (uint64_t)c->numSpheres; st->cuboidTests += (uint64_t)c->numCuboids; }
+    if (winner < 0 || !(T != FLOAT_MAX)) return 0; /* compute.glsl:257 */
+    h->T = T;
+    h->fromInside = (T == wt2);
+    h->nearHitPos = v_fma(d, T, o);
+    if (winner < 256) {
+        const float *s = ob + (size_t)winner * SPHERE_STRIDE;
+        h->m = load_material(s + 4);
+        v3 pc = v_sub(h->nearHitPos, V(s[0], s[1], s[2])); /* compute.glsl:316-319 GetNormal(Sphere) */
+        h->normal = V(pc.x / s[3], pc.y / s[3], pc.z / s[3]);
+    } else {
+        const float *q = ob + CUBOIDS_OFFSET + (size_t)(winner - 256) * CUBOID_STRIDE;
+        h->m = load_material(q + 8);
+        h->normal = cuboid_normal(V(q[0], q[1], q[2]), V(q[4], q[5], q[6]), h->nearHitPos);
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------ sampling */
+/* compute.glsl:297-307 */
+static v3 cosine_sample_hemisphere(v3 n, uint32_t *seed)
+{
+    float z = fmaf(rand01(seed), 2.0f, -1.0f);
+    float a = rand01(seed) * 2.0f * PI;
+    float r = sqrtf(fmaf(-z, z, 1.0f));
+    float sn, cs;
+    f_sincos(a, &sn, &cs);
+    return v_normalize(v_add(n, V(r * cs, r * sn, z)));
+}
+
+/* compute.glsl:359-364 */
+static float fresnel_schlick(float cosTheta, float n1, float n2)
+{
+    float r0 = (n1 - n2) / (n1 + n2);
+    r0 *= r0;
+    return fmaf(1.0f - r0, f_pow5(1.0f - cosTheta), r0);
+}
+
+static v3 f_reflect(v3 i, v3 n) { return v_fma(n, -(2.0f * v_dot(n, i)), i); }
+
+static v3 f_refract(v3 i, v3 n, float eta)
+{
+    float ni = v_dot(n, i);
+    float k = fmaf(-(eta * eta), fmaf(-ni, ni, 1.0f), 1.0f);
+    if (k < 0.0f) return V(0.0f, 0.0f, 0.0f);
+    float f = fmaf(eta, ni, sqrtf(k));
+    return V(fmaf(eta, i.x, -(f * n.x)), fmaf(eta, i.y, -(f * n.y)), fmaf(eta, i.z, -(f * n.z)));
+}
+
+/* compute.glsl:184-224 BSDF */
+static float bsdf(v3 *ro, v3 *rd, const HitInfo *h, int *isRefractive, uint32_t *seed)
+{
+    *isRefractive = 0;
+    float spec = h->m.specularChance, refr = h->m.refractionChance;
+    if (spec > 0.0f) {
+        float n1 = h->fromInside ? h->m.ior : 1.0f, n2 = !h->fromInside ? h->m.ior : 1.0f;
+        spec = f_mix(spec, 1.0f, fresnel_schlick(v_dot(v_neg(*rd), h->normal), n1, n2));
+        float diffuse = 1.0f - spec - refr;
+        refr = 1.0f - spec - diffuse;
+    }
+    v3 diffuseRay = cosine_sample_hemisphere(h->normal, seed);
+    float prob;
+    float roll = rand01(seed);
+    if (spec > roll) {
+        v3 refl = f_reflect(*rd, h->normal);
+        *rd = v_normalize(v_mix(refl, diffuseRay, h->m.specularRoughness * h->m.specularRoughness));
+        prob = spec;
+    } else if (spec + refr > roll) {
+        v3 rf = f_refract(*rd, h->normal, h->fromInside ? (h->m.ior / 1.0f) : (1.0f / h->m.ior));
+        v3 rough = cosine_sample_hemisphere(v_neg(h->normal), seed);
+        *rd = v_normalize(v_mix(rf, rough, h->m.refractionRoughness * h->m.refractionRoughness));
+        prob = refr;
+        *isRefractive = 1;
+    } else {
+        *rd = diffuseRay;
+        prob = 1.0f - spec - refr;
+    }
+    *ro = v_fma(*rd, EPSILON, h->nearHitPos);
+    return f_max(prob, EPSILON);
+}
+
+/* compute.glsl:132-182 Radiance */
+static v3 radiance(const Ctx *c, v3 ro, v3 rd, uint32_t *seed, Stats *st)
+{
+    v3 throughput = V(1.0f, 1.0f, 1.0f), rad = V(0.0f, 0.0f, 0.0f);
+    HitInfo h;
+    for (int i = 0; i < c->rayDepth; i++) {
+        if (st) st->bounces++;
+        if (ray_trace(c, ro, rd, &h, st)) {
+            if (h.fromInside) {
+                h.normal = v_neg(h.normal);
+                throughput.x *= f_exp(-h.m.absorbance.x * h.T);
+                throughput.y *= f_exp(-h.m.absorbance.y * h.T);
+                throughput.z *= f_exp(-h.m.absorbance.z * h.T);
+            }
+            int isRefractive;
+            float prob = bsdf(&ro, &rd, &h, &isRefractive, seed);
+            rad = V(fmaf(h.m.emissiv.x, throughput.x, rad.x), fmaf(h.m.emissiv.y, throughput.y, rad.y),
+                    fmaf(h.m.emissiv.z, throughput.z, rad.z));
+            if (!isRefractive) throughput = v_mul(throughput, h.m.albedo);
+            throughput = V(throughput.x / prob, throughput.y / prob, throughput.z / prob);
+            float p = f_max(throughput.x, f_max(throughput.y, throughput.z));
+            if (rand01(seed) > p) break;
+            throughput = V(throughput.x / p, throughput.y / p, throughput.z / p);
+        } else {
+            rgb e = sample_env(c, rd);
+            if (st) st->envLookups++;
+            rad = V(fmaf(e.r, throughput.x, rad.x), fmaf(e.g, throughput.y, rad.y), fmaf(e.b, throughput.z, rad.z));
+            break;
+        }
+    }
+    return rad;
+}
+
+/* GLSL mat4 * vec4 with the column-major view of the UBO bytes */
+static void mat_vec(const float *m, float x, float y, float z, float w, float *out)
+{
+    for (int r = 0; r < 4; r++)
+        out[r] = fmaf(m[12 + r], w, fmaf(m[8 + r], z, fmaf(m[4 + r], y, m[r] * x)));
+}
+
+/* compute.glsl:101-130 main, for one pixel; `last` is the pixel's current accumulation value */
+static void shade_pixel(const Ctx *c, int px, int py, int frame, const float *last, float *out, Stats *st)
+{
+    uint32_t seed = ((uint32_t)px * 1973u + (uint32_t)py * 9277u + (uint32_t)frame * 2699u) | 1u; /* :106 */
+    v3 irr = V(0.0f, 0.0f, 0.0f);
+    for (int s = 0; s < c->spp; s++) {
+        float u0 = rand01(&seed), u1 = rand01(&seed); /* :113, x first */
+        float ndcx = fmaf(((float)px + u0) / (float)c->width, 2.0f, -1.0f);
+        float ndcy = fmaf(((float)py + u1) / (float)c->height, 2.0f, -1.0f);
+        /* GetWorldSpaceRay :352-357 */
+        float eye[4], wd[4];
+        mat_vec(c->invProj, ndcx, ndcy, -1.0f, 0.0f, eye);
+        mat_vec(c->invView, eye[0], eye[1], -1.0f, 0.0f, wd);
+        v3 dir = v_normalize(V(wd[0], wd[1], wd[2]));
+        v3 focal = v_fma(dir, c->focalLength, c->viewPos); /* :117 */
+        /* UniformSampleUnitCircle :309-314 */
+        float angle = rand01(&seed) * 2.0f * PI;
+        float rr = sqrtf(rand01(&seed));
+        float sn, cs;
+        f_sincos(angle, &sn, &cs);
+        float half_ap = c->apertureDiameter * 0.5f;
+        float ox = half_ap * (cs * rr), oy = half_ap * (sn * rr);
+        float org[4];
+        mat_vec(c->invView, ox, oy, 0.0f, 1.0f, org); /* :120 */
+        v3 ro = V(org[0], org[1], org[2]);
+        v3 rd = v_normalize(v_sub(focal, ro));
+        if (st) st->samples++;
+        irr = v_add(irr, radiance(c, ro, rd, &seed, st));
+    }
+    float fspp = (float)c->spp;
+    irr = V(irr.x / fspp, irr.y / fspp, irr.z / fspp); /* :125 */
+    float w = 1.0f / (float)(frame + 1);                  /* :128 */
+    out[0] = f_mix(last[0], irr.x, w);
+    out[1] = f_mix(last[1], irr.y, w);
+    out[2] = f_mix(last[2], irr.z, w);
+    out[3] = 1.0f; /* :129 */
+}
+
+/* ------------------------------------------------------------------ public C API (ctypes) */
+typedef struct {
+    int width, height;         /* FULL image size (NDC and seeds use global coordinates) */
+    int numSpheres, numCuboids;
+    int rayDepth, spp;
+    float focalLength, apertureDiameter;
+    int envSize, envFormat;
+} PtoParams;
+
+static float srgb_to_linear(int v)
+{
+    /* GL 4.5 section 8.24, evaluated in double and rounded once: a fixed 256-entry table */
+    double cs = v / 255.0;
+    double cl = cs <= 0.04045 ? cs / 12.92 : pow((cs + 0.055) / 1.055, 2.4);
+    return (float)cl;
+}
+
+/* Test-only knob: replace the exact GL sRGB decode table, e.g. with llvmpipe's cubic approximation, so that the
+ * llvmpipe pinning test can isolate everything else (tests/test_oracle_vs_reference.py). NULL restores exact. */
+static float g_lut_override[256];
+static int g_lut_overridden = 0;
+PTO_API void pto_set_srgb_lut(const float *lut256)
+{
+    g_lut_overridden = lut256 != NULL;
+    if (lut256) memcpy(g_lut_override, lut256, sizeof g_lut_override);
+}
+static void fill_lut(float *lut)
+{
+    for (int i = 0; i < 256; i++) lut[i] = g_lut_overridden ? g_lut_override[i] : srgb_to_linear(i);
+}
+
+static void make_ctx(Ctx *c, const PtoParams *p, const float *basic, const float *objects, const void *env)
+{
+    memcpy(c->invProj, basic, 64);
+    memcpy(c->invView, basic + 16, 64);
+    c->viewPos = V(basic[32], basic[33], basic[34]);
+    c->objects = objects;
+    c->numSpheres = p->numSpheres; c->numCuboids = p->numCuboids;
+    c->rayDepth = p->rayDepth; c->spp = p->spp;
+    c->focalLength = p->focalLength; c->apertureDiameter = p->apertureDiameter;
+    c->width = p->width; c->height = p->height;
+    c->envSize = p->envSize; c->envFormat = p->envFormat; c->env = env;
+    fill_lut(c->srgbLut);
+}
+
+typedef struct {
+    const Ctx *c; float *image; int y0, rows, frame, tid, nthreads; Stats st; int wantStats;
+} Job;
+
+static void *row_worker(void *arg)
+{
+    Job *j = (Job *)arg;
+    const Ctx *c = j->c;
+    for (int r = j->tid; r < j->rows; r += j->nthreads) {
+        int y = j->y0 + r;
+        float *row = j->image + (size_t)r * c->width * 4;
+        for (int x = 0; x < c->width; x++) {
+            float out[4];
+            shade_pixel(c, x, y, j->frame, row + 4 * x, out, j->wantStats ? &j->st : NULL);
+            memcpy(row + 4 * x, out, 16);
+        }
+    }
+    return NULL;
+}
+
+/* Render one frame into `image` (rows [y0, y0+rows) of the full image, tightly packed RGBA32F, row 0 = y0),
+ * accumulating onto its current contents exactly like one PathTracer.Render() call (PathTracer.cs:114-123).
+ * stats (optional, 6 x uint64): samples, bounces, sphereTests, cuboidTests, envLookups, reserved. */
+PTO_API int pto_render_frame(const PtoParams *p, const float *basic144, const float *objects26624, const void *env,
+                             float *image, int y0, int rows, int frame, int nthreads, uint64_t *stats)
+{
+    Ctx c;
+    make_ctx(&c, p, basic144, objects26624, env);
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    Job jobs[256];
+    for (int t = 0; t < nthreads; t++) {
+        Job j = { &c, image, y0, rows, frame, t, nthreads, { 0, 0, 0, 0, 0, 0 }, stats != NULL };
+        jobs[t] = j;
+        if (nthreads > 1) pthread_create(&th[t], NULL, row_worker, &jobs[t]);
+    }
+    if (nthreads == 1) row_worker(&jobs[0]);
+    else for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    if (stats) {
+        memset(stats, 0, 6 * sizeof(uint64_t));
+        for (int t = 0; t < nthreads; t++) {
+            stats[0] += jobs[t].st.samples; stats[1] += jobs[t].st.bounces; stats[2] += jobs[t].st.sphereTests;
+            stats[3] += jobs[t].st.cuboidTests; stats[4] += jobs[t].st.envLookups;
+        }
+    }
+    return 0;
+}
+
+/* Evaluate `n` listed pixels of frame `frame` starting from `last` (n x 4 floats; pass zeros for frame 0). */
+PTO_API int pto_render_pixels(const PtoParams *p, const float *basic144, const float *objects26624, const void *env,
+                              const int *xy, int n, int frame, const float *last, float *out)
+{
+    Ctx c;
+    make_ctx(&c, p, basic144, objects26624, env);
+    for (int i = 0; i < n; i++) shade_pixel(&c, xy[2 * i], xy[2 * i + 1], frame, last + 4 * i, out + 4 * i, NULL);
+    return 0;
+}
+
+/* ---- micro entry points for unit tests ---- */
+PTO_API uint32_t pto_pcg_hash(uint32_t *seed) { return pcg_hash(seed); }
+PTO_API float pto_rand01(uint32_t *seed) { return rand01(seed); }
+PTO_API uint32_t pto_pixel_seed(int x, int y, int frame)
+{ return ((uint32_t)x * 1973u + (uint32_t)y * 9277u + (uint32_t)frame * 2699u) | 1u; }
+PTO_API void pto_sincos(float a, float *s, float *c) { f_sincos(a, s, c); }
+PTO_API float pto_exp(float x) { return f_exp(x); }
+PTO_API int pto_ray_sphere(const float *o, const float *d, const float *pos_r, float *t12)
+{ return ray_sphere(V(o[0], o[1], o[2]), V(d[0], d[1], d[2]), V(pos_r[0], pos_r[1], pos_r[2]), pos_r[3], t12, t12 + 1); }
+PTO_API int pto_ray_cuboid(const float *o, const float *d, const float *mn, const float *mx, float *t12)
+{
+    v3 dd = V(d[0], d[1], d[2]);
+    return ray_cuboid(V(o[0], o[1], o[2]), dd, V(f_rcp(dd.x), f_rcp(dd.y), f_rcp(dd.z)), V(mn[0], mn[1], mn[2]),
+                      V(mx[0], mx[1], mx[2]), t12, t12 + 1);
+}
+PTO_API void pto_cuboid_normal(const float *mn, const float *mx, const float *p, float *n)
+{ v3 r = cuboid_normal(V(mn[0], mn[1], mn[2]), V(mx[0], mx[1], mx[2]), V(p[0], p[1], p[2])); n[0] = r.x; n[1] = r.y; n[2] = r.z; }
+PTO_API void pto_sample_env(const void *env, int size, int format, const float *dir, float *rgb_out)
+{
+    Ctx c;
+    memset(&c, 0, sizeof c);
+    c.env = env; c.envSize = size; c.envFormat = format;
+    fill_lut(c.srgbLut);
+    rgb o = sample_env(&c, V(dir[0], dir[1], dir[2]));
+    rgb_out[0] = o.r; rgb_out[1] = o.g; rgb_out[2] = o.b;
+}
+PTO_API float pto_srgb_to_linear(int v) { return srgb_to_linear(v); }
+
+/* ------------------------------------------------------------------ atmosphere precompute
+ * res/shaders/AtmosphericScattering/compute.glsl:30-171 (algorithm credited there to
+ * github.com/wwwtyro/glsl-atmosphere).  Same pt-f32 contract. */
+static void atmo_rsi(v3 r0, v3 rd, float sr, float *x, float *y) /* :58-71 */
+{
+    float a = v_dot(rd, rd);
+    float b = 2.0f * v_dot(rd, r0);
+    float c = fmaf(-sr, sr, v_dot(r0, r0));
+    float d = fmaf(b, b, -(4.0f * a * c));
+    if (d < 0.0f) { *x = 1e5f; *y = -1e5f; return; }
+    float sq = sqrtf(d), den = 2.0f * a;
+    *x = (-b - sq) / den;
+    *y = (-b + sq) / den;
+}
+
+static v3 atmosphere(v3 r, v3 r0, v3 pSun, float iSun, float rPlanet, float rAtmos, v3 kRlh, float kMie,
+                     float shRlh, float shMie, float g, int iSteps, int jSteps) /* :73-159 */
+{
+    pSun = v_normalize(pSun);
+    r = v_normalize(r);
+    float px, py, qx, qy;
+    atmo_rsi(r0, r, rAtmos, &px, &py);
+    if (px > py) return V(0.0f, 0.0f, 0.0f);
+    atmo_rsi(r0, r, rPlanet, &qx, &qy);
+    py = f_min(py, qx);
+    float iStepSize = (py - px) / (float)iSteps;
+    float iTime = 0.0f;
+    v3 totalRlh = V(0, 0, 0), totalMie = V(0, 0, 0);
+    float iOdRlh = 0.0f, iOdMie = 0.0f;
+    float mu = v_dot(r, pSun), mumu = mu * mu, gg = g * g;
+    float pRlh = 3.0f / (16.0f * PI) * (1.0f + mumu);
+    float base = 1.0f + gg - 2.0f * mu * g;
+    float pMie = 3.0f / (8.0f * PI) * ((1.0f - gg) * (mumu + 1.0f)) / ((base * sqrtf(base)) * (2.0f + gg));
+    float invShRlh = -1.0f / shRlh, invShMie = -1.0f / shMie; /* exp(-h/sh) evaluated as exp(h * (-1/sh)) */
+    for (int i = 0; i < iSteps; i++) {
+        v3 iPos = v_fma(r, fmaf(iStepSize, 0.5f, iTime), r0);
+        float iHeight = sqrtf(v_dot(iPos, iPos)) - rPlanet;
+        float odStepRlh = f_exp(iHeight * invShRlh) * iStepSize;
+        float odStepMie = f_exp(iHeight * invShMie) * iStepSize;
+        iOdRlh += odStepRlh;
+        iOdMie += odStepMie;
+        float sx, sy;
+        atmo_rsi(iPos, pSun, rAtmos, &sx, &sy);
+        float jStepSize = sy / (float)jSteps;
+        float jTime = 0.0f, jOdRlh = 0.0f, jOdMie = 0.0f;
+        for (int j = 0; j < jSteps; j++) {
+            v3 jPos = v_fma(pSun, fmaf(jStepSize, 0.5f, jTime), iPos);
+            float jHeight = sqrtf(v_dot(jPos, jPos)) - rPlanet;
+            jOdRlh = fmaf(f_exp(jHeight * invShRlh), jStepSize, jOdRlh);
+            jOdMie = fmaf(f_exp(jHeight * invShMie), jStepSize, jOdMie);
+            jTime += jStepSize;
+        }
+        float mieTerm = kMie * (iOdMie + jOdMie), rl = iOdRlh + jOdRlh;
+        v3 attn = V(f_exp(-fmaf(kRlh.x, rl, mieTerm)), f_exp(-fmaf(kRlh.y, rl, mieTerm)), f_exp(-fmaf(kRlh.z, rl, mieTerm)));
+        totalRlh = v_fma(attn, odStepRlh, totalRlh);
+        totalMie = v_fma(attn, odStepMie, totalMie);
+        iTime += iStepSize;
+    }
+    float pm = pMie * kMie;
+    return V(iSun * fmaf(pRlh * kRlh.x, totalRlh.x, pm * totalMie.x),
+             iSun * fmaf(pRlh * kRlh.y, totalRlh.y, pm * totalMie.y),
+             iSun * fmaf(pRlh * kRlh.z, totalRlh.z, pm * totalMie.z));
+}
+
+typedef struct { const float *ubo; const float *lightPos; float intensity; int size, iSteps, jSteps; float *out; int tid, nthreads; } AtmoJob;
+
+static void *atmo_worker(void *arg)
+{
+    AtmoJob *j = (AtmoJob *)arg;
+    int S = j->size;
+    for (int idx = j->tid; idx < 6 * S; idx += j->nthreads) {
+        int face = idx / S, y = idx % S;
+        const float *invView = j->ubo + 16 + 16 * face;
+        for (int x = 0; x < S; x++) {
+            /* main :30-56 : ndc = vec2(imgCoord.xy) / size * 2 - 1 (texel corner, no +0.5) */
+            float ndcx = fmaf((float)x / (float)S, 2.0f, -1.0f), ndcy = fmaf((float)y / (float)S, 2.0f, -1.0f);
+            float eye[4], wd[4];
+            mat_vec(j->ubo, ndcx, ndcy, -1.0f, 0.0f, eye);
+            mat_vec(invView, eye[0], eye[1], -1.0f, 0.0f, wd);
+            v3 dir = v_normalize(V(wd[0], wd[1], wd[2]));
+            v3 col = atmosphere(dir, V(0.0f, 6376e3f, 0.0f), V(j->lightPos[0], j->lightPos[1], j->lightPos[2]), j->intensity,
+                                6371e3f, 6471e3f, V(5.5e-6f, 13.0e-6f, 22.4e-6f), 21e-6f, 8e3f, 1.2e3f, 0.758f,
+                                j->iSteps, j->jSteps);
+            float *o = j->out + (((size_t)face * S + y) * S + x) * 4;
+            o[0] = col.x; o[1] = col.y; o[2] = col.z; o[3] = 1.0f;
+        }
+    }
+    return NULL;
+}
+
+/* out: float[6][size][size][4]; ubo464: InvProjection + 6 InvView (AtmosphericScatterer.cs:72-89) */
+PTO_API int pto_atmosphere(const float *ubo464, const float *lightPos, float lightIntensity, int size, int iSteps,
+                           int jSteps, float *out, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    AtmoJob jobs[256];
+    for (int t = 0; t < nthreads; t++) {
+        AtmoJob j = { ubo464, lightPos, lightIntensity, size, iSteps, jSteps, out, t, nthreads };
+        jobs[t] = j;
+        if (nthreads > 1) pthread_create(&th[t], NULL, atmo_worker, &jobs[t]);
+    }
+    if (nthreads == 1) atmo_worker(&jobs[0]);
+    else for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    return 0;
+}

@@ -1,0 +1,177 @@
+"""ctypes binding for oracle/_build/libpt_oracle.so — the CPU restatement of the reference integrator.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "libpt_oracle.so")
+LIB_TRUEDIV_PATH = os.path.join(HERE, "_build", "libpt_oracle_truediv.so")
+
+
+def build(force: bool = False) -> None:
+    src = os.path.join(HERE, "pt_oracle.c")
+    stale = (not os.path.exists(LIB_PATH) or not os.path.exists(LIB_TRUEDIV_PATH)
+             or os.path.getmtime(LIB_PATH) < os.path.getmtime(src))
+    if force or stale:
+        subprocess.run(["make", "-C", HERE, "-B" if force else "-s", "all"], check=True, capture_output=True)
+
+
+class PtoParams(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("numSpheres", C.c_int), ("numCuboids", C.c_int),
+                ("rayDepth", C.c_int), ("spp", C.c_int), ("focalLength", C.c_float), ("apertureDiameter", C.c_float),
+                ("envSize", C.c_int), ("envFormat", C.c_int)]
+
+
+_fp = C.POINTER(C.c_float)
+
+
+def _ptr(a, t=_fp):
+    return a.ctypes.data_as(t)
+
+
+class Oracle:
+    def __init__(self, true_division: bool = False):
+        build()
+        self.lib = C.CDLL(LIB_TRUEDIV_PATH if true_division else LIB_PATH)
+        L = self.lib
+        L.pto_render_frame.restype = C.c_int
+        L.pto_render_frame.argtypes = [C.POINTER(PtoParams), _fp, _fp, C.c_void_p, _fp, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.POINTER(C.c_uint64)]
+        L.pto_render_pixels.restype = C.c_int
+        L.pto_render_pixels.argtypes = [C.POINTER(PtoParams), _fp, _fp, C.c_void_p, C.POINTER(C.c_int), C.c_int,
+                                        C.c_int, _fp, _fp]
+        L.pto_pcg_hash.restype = C.c_uint32
+        L.pto_pcg_hash.argtypes = [C.POINTER(C.c_uint32)]
+        L.pto_rand01.restype = C.c_float
+        L.pto_rand01.argtypes = [C.POINTER(C.c_uint32)]
+        L.pto_pixel_seed.restype = C.c_uint32
+        L.pto_pixel_seed.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.pto_sincos.argtypes = [C.c_float, _fp, _fp]
+        L.pto_exp.restype = C.c_float
+        L.pto_exp.argtypes = [C.c_float]
+        L.pto_ray_sphere.restype = C.c_int
+        L.pto_ray_sphere.argtypes = [_fp, _fp, _fp, _fp]
+        L.pto_ray_cuboid.restype = C.c_int
+        L.pto_ray_cuboid.argtypes = [_fp, _fp, _fp, _fp, _fp]
+        L.pto_cuboid_normal.argtypes = [_fp, _fp, _fp, _fp]
+        L.pto_sample_env.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _fp]
+        L.pto_srgb_to_linear.restype = C.c_float
+        L.pto_srgb_to_linear.argtypes = [C.c_int]
+        L.pto_atmosphere.restype = C.c_int
+        L.pto_atmosphere.argtypes = [_fp, _fp, C.c_float, C.c_int, C.c_int, C.c_int, _fp, C.c_int]
+
+    # ---------------------------------------------------------------- frames
+    @staticmethod
+    def _inputs(basic_ubo: bytes, objects_ubo: bytes, env_faces: np.ndarray):
+        basic = np.frombuffer(basic_ubo, dtype=np.float32).copy()
+        objs = np.frombuffer(objects_ubo, dtype=np.float32).copy()
+        env = np.ascontiguousarray(env_faces)
+        assert basic.size == 36 and objs.size == 6656
+        assert env.dtype in (np.float32, np.uint8) and env.shape[0] == 6 and env.shape[3] == 4
+        return basic, objs, env
+
+    @staticmethod
+    def _params(width, height, num_spheres, num_cuboids, ray_depth, spp, focal_length, aperture, env):
+        return PtoParams(width, height, int(num_spheres), int(num_cuboids), ray_depth, spp, focal_length, aperture,
+                         env.shape[1], 0 if env.dtype == np.float32 else 1)
+
+    def render(self, width, height, basic_ubo, objects_ubo, env_faces, *, num_spheres, num_cuboids, ray_depth, spp=1,
+               focal_length=20.0, aperture=0.14, frame_start=0, num_frames=1, y0=0, rows=None, threads=None,
+               image=None, dump_each=False, want_stats=False):
+        """Accumulate frames [frame_start, frame_start+num_frames) onto `image` (zeros if None).
+        Returns (rows, W, 4) float32 (or (frames, rows, W, 4) with dump_each); with want_stats also a dict."""
+        basic, objs, env = self._inputs(basic_ubo, objects_ubo, env_faces)
+        p = self._params(width, height, num_spheres, num_cuboids, ray_depth, spp, focal_length, aperture, env)
+        rows = height - y0 if rows is None else rows
+        threads = threads or os.cpu_count() or 1
+        img = np.zeros((rows, width, 4), dtype=np.float32) if image is None else np.ascontiguousarray(image, np.float32)
+        stats = (C.c_uint64 * 6)()
+        total = np.zeros(6, dtype=np.uint64)
+        dumps = []
+        for f in range(frame_start, frame_start + num_frames):
+            rc = self.lib.pto_render_frame(C.byref(p), _ptr(basic), _ptr(objs), env.ctypes.data_as(C.c_void_p),
+                                           _ptr(img), y0, rows, f, threads, stats if want_stats else None)
+            assert rc == 0
+            total += np.array(list(stats), dtype=np.uint64)
+            if dump_each:
+                dumps.append(img.copy())
+        out = np.stack(dumps) if dump_each else img
+        if want_stats:
+            keys = ["samples", "bounces", "sphere_tests", "cuboid_tests", "env_lookups", "reserved"]
+            return out, {k: int(v) for k, v in zip(keys, total)}
+        return out
+
+    def render_pixels(self, width, height, basic_ubo, objects_ubo, env_faces, xy, *, num_spheres, num_cuboids,
+                      ray_depth, spp=1, focal_length=20.0, aperture=0.14, frame=0, last=None):
+        basic, objs, env = self._inputs(basic_ubo, objects_ubo, env_faces)
+        p = self._params(width, height, num_spheres, num_cuboids, ray_depth, spp, focal_length, aperture, env)
+        xy = np.ascontiguousarray(xy, dtype=np.int32)
+        n = xy.shape[0]
+        last = np.zeros((n, 4), np.float32) if last is None else np.ascontiguousarray(last, np.float32)
+        out = np.zeros((n, 4), dtype=np.float32)
+        self.lib.pto_render_pixels(C.byref(p), _ptr(basic), _ptr(objs), env.ctypes.data_as(C.c_void_p),
+                                   xy.ctypes.data_as(C.POINTER(C.c_int)), n, frame, _ptr(last), _ptr(out))
+        return out
+
+    def atmosphere(self, size, atmo_ubo: bytes, light_pos, light_intensity=15.0, i_steps=50, j_steps=15, threads=None):
+        ubo = np.frombuffer(atmo_ubo, dtype=np.float32).copy()
+        assert ubo.size == 116
+        lp = np.ascontiguousarray(light_pos, dtype=np.float32)
+        out = np.zeros((6, size, size, 4), dtype=np.float32)
+        self.lib.pto_atmosphere(_ptr(ubo), _ptr(lp), light_intensity, size, i_steps, j_steps, _ptr(out),
+                                threads or os.cpu_count() or 1)
+        return out
+
+    # ---------------------------------------------------------------- micro helpers
+    def rand_stream(self, seed: int, n: int):
+        s = C.c_uint32(seed)
+        return np.array([self.lib.pto_rand01(C.byref(s)) for _ in range(n)], dtype=np.float32)
+
+    def hash_stream(self, seed: int, n: int):
+        s = C.c_uint32(seed)
+        return np.array([self.lib.pto_pcg_hash(C.byref(s)) for _ in range(n)], dtype=np.uint32)
+
+    def pixel_seed(self, x, y, frame):
+        return int(self.lib.pto_pixel_seed(x, y, frame))
+
+    def sincos(self, a):
+        s, c = C.c_float(), C.c_float()
+        self.lib.pto_sincos(float(a), C.byref(s), C.byref(c))
+        return s.value, c.value
+
+    def exp(self, x):
+        return self.lib.pto_exp(float(x))
+
+    def ray_sphere(self, o, d, pos_r):
+        o, d, pos_r = (np.ascontiguousarray(a, np.float32) for a in (o, d, pos_r))
+        t = np.zeros(2, np.float32)
+        hit = self.lib.pto_ray_sphere(_ptr(o), _ptr(d), _ptr(pos_r), _ptr(t))
+        return bool(hit), float(t[0]), float(t[1])
+
+    def ray_cuboid(self, o, d, mn, mx):
+        o, d, mn, mx = (np.ascontiguousarray(a, np.float32) for a in (o, d, mn, mx))
+        t = np.zeros(2, np.float32)
+        hit = self.lib.pto_ray_cuboid(_ptr(o), _ptr(d), _ptr(mn), _ptr(mx), _ptr(t))
+        return bool(hit), float(t[0]), float(t[1])
+
+    def cuboid_normal(self, mn, mx, p):
+        mn, mx, p = (np.ascontiguousarray(a, np.float32) for a in (mn, mx, p))
+        n = np.zeros(3, np.float32)
+        self.lib.pto_cuboid_normal(_ptr(mn), _ptr(mx), _ptr(p), _ptr(n))
+        return n
+
+    def sample_env(self, env_faces, direction):
+        env = np.ascontiguousarray(env_faces)
+        d = np.ascontiguousarray(direction, np.float32)
+        out = np.zeros(3, np.float32)
+        self.lib.pto_sample_env(env.ctypes.data_as(C.c_void_p), env.shape[1], 0 if env.dtype == np.float32 else 1,
+                                _ptr(d), _ptr(out))
+        return out
