@@ -1,0 +1,155 @@
+/*
+ * mi355pt.h — C ABI of libmi355pt.so: the MI355X (gfx950) replacement for the reference's path-tracing
+ * compute dispatch.  Plain C, cdecl, blittable arguments only, so the reference's C# host can bind every
+ * entry point with [DllImport("mi355pt")] (binding shown in INTEGRATION.md).
+ *
+ * The reference has NO plugin/FFI interface for this path: the hot path is hard-wired GL calls inside the
+ * C# class PathTracer.  Each entry point below therefore replaces one thing the host does to the shader
+ * today; citations are relative to /root/reference/OpenTK-PathTracer/.
+ *
+ * Conventions
+ *   - every function returns PT_OK (0) or a negative PT_E_* code; nothing throws across the boundary
+ *     (reference: C# exceptions + console prints, src/Render/Objects/ShaderProgram.cs:25-27,70-74);
+ *     pt_last_error() returns a human-readable message for the last failure on that handle
+ *     (or for the last failed pt_create when handle == NULL);
+ *   - the host owns every source/destination array for the duration of the call only (as with
+ *     GL.NamedBufferSubData, src/Render/Objects/BufferObject.cs:37-48); the library owns all device memory;
+ *   - one handle = one renderer on one GPU, callable from one thread at a time (the reference calls
+ *     everything from the GameWindow thread, src/MainWindow.cs:40,72,146).  Work is enqueued on the handle's
+ *     HIP stream: pt_upload_*, pt_set_* and pt_render are stream-ordered; only pt_read_*, pt_synchronize,
+ *     pt_timer_end and pt_destroy block;
+ *   - image rows: row 0 is the BOTTOM of the image (NDC y = -1), as in the GL image the reference writes
+ *     (res/shaders/PathTracing/compute.glsl:104,114); pixels are RGBA32F, alpha = 1.
+ */
+#ifndef MI355PT_H
+#define MI355PT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define PT_API __declspec(dllexport)
+#else
+#define PT_API __attribute__((visibility("default")))
+#endif
+
+typedef struct pt_renderer *pt_handle;
+
+enum {
+    PT_OK = 0,
+    PT_E_BAD_HANDLE = -1,
+    PT_E_BAD_ARGUMENT = -2,  /* NULL pointer, bad dimensions, bad enum */
+    PT_E_OUT_OF_RANGE = -3,  /* byteOffset/size outside the 144 B / 26,624 B / 464 B blobs (GL would raise INVALID_VALUE) */
+    PT_E_NO_ENVIRONMENT = -4,/* pt_render before any environment map was set */
+    PT_E_HIP = -5,           /* a HIP runtime call failed; message has the hipError string */
+    PT_E_NO_DEVICE = -6,     /* no usable gfx950 device: the library has NO CPU fallback */
+    PT_E_OUT_OF_MEMORY = -7
+};
+
+enum { PT_ENV_RGBA32F = 0, PT_ENV_SRGB8_A8 = 1 };
+
+#define PT_BASIC_DATA_UBO_SIZE 144      /* src/MainWindow.cs:195-197 ; compute.glsl:59-64  */
+#define PT_GAME_OBJECTS_UBO_SIZE 26624  /* src/MainWindow.cs:17,199-201 ; compute.glsl:66-70 */
+#define PT_ATMOSPHERE_UBO_SIZE 464      /* src/Render/AtmosphericScatterer.cs:72 ; AtmosphericScattering/compute.glsl:11-15 */
+#define PT_MAX_SPHERES 256
+#define PT_MAX_CUBOIDS 64
+
+/* ---- lifetime -------------------------------------------------------------------------------------------- */
+
+/* new PathTracer(env, width, height, ...) — src/Render/PathTracer.cs:95-110 — on HIP device `device_id`.
+ * Allocates the RGBA32F accumulation image (the reference's `Result` texture, PathTracer.cs:97-99) ZEROED
+ * (the reference leaves it undefined, src/Render/Objects/Texture.cs:169-197; frame 0 multiplies it by 0). */
+PT_API int pt_create(int device_id, int width, int height, pt_handle *out);
+PT_API int pt_destroy(pt_handle h);
+
+/* PathTracer.SetSize — PathTracer.cs:131-135: frame counter = 0, image reallocated (and zeroed). The tile is
+ * reset to the whole image. */
+PT_API int pt_set_size(pt_handle h, int width, int height);
+
+/* Multi-GPU row-block tiling (no reference counterpart: the reference is single-GPU).  This handle renders
+ * and stores only rows [y0, y0+rows) of the width x height image; seeds and NDC still use global pixel
+ * coordinates, so tiled and untiled renders are bit-identical.  Resets the frame counter and zeroes. */
+PT_API int pt_set_tile(pt_handle h, int y0, int rows);
+
+/* PathTracer.ResetRenderer — PathTracer.cs:137-140: frame counter = 0 (image contents are irrelevant then). */
+PT_API int pt_reset(pt_handle h);
+
+/* ---- inputs ------------------------------------------------------------------------------------------------ */
+
+/* The six property setters NumSpheres/NumCuboids/RayDepth/SPP/FocalLength/ApertureDiameter —
+ * PathTracer.cs:11-83 (GLSL uniforms compute.glsl:88-94). */
+PT_API int pt_set_params(pt_handle h, int num_spheres, int num_cuboids, int ray_depth, int spp,
+                         float focal_length, float aperture_diameter);
+
+/* BasicDataUBO.SubData(offset, size, data) — src/MainWindow.cs:131-132,278-279: InvProjection@0, InvView@64,
+ * ViewPos@128 (OpenTK row-major bytes, consumed as GLSL column-major). 0 <= offset, offset+size <= 144. */
+PT_API int pt_upload_basic_data(pt_handle h, int byte_offset, int size, const void *src);
+
+/* GameObjectsUBO.SubData(BufferOffset, size, data) — src/BaseSTD140Compatible.cs:12-16: std140 Spheres[256]@0
+ * (80 B each), Cuboids[64]@20480 (96 B each). 0 <= offset, offset+size <= 26,624. */
+PT_API int pt_upload_game_objects(pt_handle h, int byte_offset, int size, const void *src);
+
+/* PathTracer.EnvironmentMap = <cube texture> — PathTracer.cs:85,118; cube creation src/MainWindow.cs:177-187,
+ * src/Helper.cs:41-48.  faces[0..5] = +X,-X,+Y,-Y,+Z,-Z, each face_size^2 tightly packed RGBA texels
+ * (float32 x4 for PT_ENV_RGBA32F, uint8 x4 sRGB-encoded for PT_ENV_SRGB8_A8), row 0 = t 0 as uploaded by
+ * glTextureSubImage3D.  Sampling = GL LINEAR magnification with seamless cube edges (MainWindow.cs:168,178). */
+PT_API int pt_set_environment(pt_handle h, int face_size, int format, const void *const faces[6]);
+
+/* ---- the hot path ------------------------------------------------------------------------------------------ */
+
+/* PathTracer.Render() — PathTracer.cs:114-123: enqueue one dispatch of the integrator with the current frame
+ * index, then post-increment it. Asynchronous. *out_total_samples (optional) = frames * SPP after this call
+ * (PathTracer.Samples, PathTracer.cs:112). */
+PT_API int pt_render(pt_handle h, int *out_total_samples);
+
+/* What ScreenEffect.Render reads (src/MainWindow.cs:51): blocks until the stream is idle and copies this
+ * handle's rows [y0, y0+rows) into dst (row_pitch_bytes >= width*16; 0 means tightly packed). */
+PT_API int pt_read_result(pt_handle h, float *dst_rgba32f, size_t row_pitch_bytes);
+
+/* Resume support (no reference counterpart; the reference discards accumulation on every event): replace the
+ * accumulation image of this tile and set the frame counter. */
+PT_API int pt_write_result(pt_handle h, const float *src_rgba32f, size_t row_pitch_bytes, int frame_index);
+
+PT_API int pt_get_frame_index(pt_handle h, int *out_frame_index);
+PT_API int pt_synchronize(pt_handle h);
+
+/* ---- atmosphere environment (secondary kernel) ------------------------------------------------------------- */
+
+/* AtmosphericScatterer: UBO upload (src/Render/AtmosphericScatterer.cs:72-89: InvProjection@0 + 6 InvView@64),
+ * the four uniforms (:11-57: ISteps, JSteps, lightPos from Time, LightIntensity) and Render() (:102-113),
+ * into a size^2 x 6 RGBA32F cube that then becomes the environment (MainWindow.cs:189). */
+PT_API int pt_atmosphere_upload_data(pt_handle h, int byte_offset, int size, const void *src);
+PT_API int pt_atmosphere_render(pt_handle h, int size, int i_steps, int j_steps, const float light_pos[3],
+                                float light_intensity);
+
+/* Read back the current environment cube as RGBA32F (6 * face_size^2 * 4 floats), e.g. the atmosphere result
+ * (the GUI shows / the tests check it).  sRGB environments are returned linearised. */
+PT_API int pt_read_environment(pt_handle h, float *dst_rgba32f, int *out_face_size);
+
+/* ---- plumbing for harnesses (torch.distributed, benchmarking); not part of the reference surface ----------- */
+
+/* Device pointer + byte size of this tile's accumulation image (for zero-copy wrapping, e.g. the RCCL gather at
+ * present time in multi-GPU runs). */
+PT_API int pt_result_device_ptr(pt_handle h, void **out_device_ptr, size_t *out_bytes);
+/* Render into caller-owned device memory (>= rows*width*16 bytes) instead of the internal image; NULL restores. */
+PT_API int pt_bind_result_buffer(pt_handle h, void *device_ptr, size_t bytes);
+/* Use an existing hipStream_t (passed as void*) instead of the handle's own stream; NULL restores. */
+PT_API int pt_set_stream(pt_handle h, void *hip_stream);
+/* hipEvent pair recorded on the handle's stream: elapsed GPU milliseconds between begin and end. */
+PT_API int pt_timer_begin(pt_handle h);
+PT_API int pt_timer_end(pt_handle h, float *out_milliseconds);
+/* Kernel variant selector for A/B measurements (0 = default); all variants produce bit-identical images. */
+PT_API int pt_set_variant(pt_handle h, int variant);
+
+PT_API const char *pt_last_error(pt_handle h);
+PT_API const char *pt_version(void);
+PT_API int pt_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355PT_H */

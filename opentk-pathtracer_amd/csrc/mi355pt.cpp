@@ -1,0 +1,510 @@
+// mi355pt.cpp — implementation of the C ABI declared in include/mi355pt.h.
+//
+// Host-side state of one renderer (what the reference keeps in the C# class PathTracer,
+// /root/reference/OpenTK-PathTracer/src/Render/PathTracer.cs:9-141, plus the two UBOs MainWindow owns,
+// src/MainWindow.cs:195-201) and the HIP plumbing around the kernels of pt_kernels.hip.
+// There is deliberately NO CPU fallback: without a HIP device every entry point fails with PT_E_NO_DEVICE.
+#include "../../include/mi355pt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "pt_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HandleMagic {
+    static constexpr uint32_t kAlive = 0x4d335054u; // "M3PT"
+};
+
+} // namespace
+
+struct pt_renderer {
+    uint32_t magic = HandleMagic::kAlive;
+    int device = 0;
+    int width = 0, height = 0;
+    int y0 = 0, rows = 0;
+    int numSpheres = 0, numCuboids = 0, rayDepth = 1, spp = 1;
+    float focalLength = 0.0f, apertureDiameter = 0.0f;
+    int frame = 0; // thisRenderNumFrame, PathTracer.cs:113
+    int variant = 0;
+
+    unsigned char basic[PT_BASIC_DATA_UBO_SIZE] = {0};      // host shadow of UBO 0 (travels as kernel argument)
+    unsigned char atmoUbo[PT_ATMOSPHERE_UBO_SIZE] = {0};    // host shadow of UBO 2
+
+    float *dObjects = nullptr; // 26,624 B device copy of UBO 1
+    float *dLut = nullptr;     // 256-entry sRGB table
+    void *dEnv = nullptr;      // current environment cube
+    size_t envBytes = 0;
+    int envSize = 0, envFormat = PT_ENV_RGBA32F;
+
+    float4 *dAccum = nullptr;  // internal accumulation image (rows x width)
+    size_t accumCapacity = 0;  // in pixels
+    float4 *boundAccum = nullptr; // caller-owned target (pt_bind_result_buffer)
+    size_t boundBytes = 0;
+
+    hipStream_t ownStream = nullptr, stream = nullptr;
+    hipEvent_t evBegin = nullptr, evEnd = nullptr;
+    std::string error;
+
+    float4 *accum() const { return boundAccum ? boundAccum : dAccum; }
+    size_t tilePixels() const { return (size_t)rows * (size_t)width; }
+};
+
+namespace {
+
+int fail(pt_handle h, int code, const std::string &msg)
+{
+    if (h) h->error = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+int hip_fail(pt_handle h, hipError_t e, const char *what)
+{
+    return fail(h, e == hipErrorOutOfMemory ? PT_E_OUT_OF_MEMORY : PT_E_HIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define PT_CHECK_HANDLE(h)                                                                                             \
+    do {                                                                                                               \
+        if (!(h) || (h)->magic != HandleMagic::kAlive) return fail(nullptr, PT_E_BAD_HANDLE, "bad handle");           \
+    } while (0)
+
+#define PT_HIP(h, call)                                                                                                \
+    do {                                                                                                               \
+        hipError_t e_ = (call);                                                                                        \
+        if (e_ != hipSuccess) return hip_fail((h), e_, #call);                                                         \
+    } while (0)
+
+int bind_device(pt_handle h)
+{
+    PT_HIP(h, hipSetDevice(h->device));
+    return PT_OK;
+}
+
+// GL 4.5 section 8.24 sRGB decode, evaluated in double and rounded once (same table as the oracle's).
+void make_srgb_lut(float *lut)
+{
+    for (int i = 0; i < 256; i++) {
+        double cs = i / 255.0;
+        double cl = cs <= 0.04045 ? cs / 12.92 : std::pow((cs + 0.055) / 1.055, 2.4);
+        lut[i] = (float)cl;
+    }
+}
+
+int ensure_accum(pt_handle h)
+{
+    size_t need = h->tilePixels();
+    if (need > h->accumCapacity) {
+        if (h->dAccum) PT_HIP(h, hipFree(h->dAccum));
+        h->dAccum = nullptr;
+        h->accumCapacity = 0;
+        PT_HIP(h, hipMalloc((void **)&h->dAccum, need * sizeof(float4)));
+        h->accumCapacity = need;
+    }
+    return PT_OK;
+}
+
+int clear_accum(pt_handle h)
+{
+    if (h->boundAccum && h->boundBytes < h->tilePixels() * sizeof(float4))
+        return fail(h, PT_E_BAD_ARGUMENT, "bound result buffer is smaller than the tile");
+    PT_HIP(h, pt::launch_clear(h->accum(), h->tilePixels(), h->stream));
+    return PT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+PT_API const char *pt_version(void) { return "mi355pt 0.1 (gfx950, pt-f32)"; }
+
+PT_API int pt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+PT_API const char *pt_last_error(pt_handle h)
+{
+    if (h && h->magic == HandleMagic::kAlive) return h->error.c_str();
+    return g_create_error.c_str();
+}
+
+PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
+{
+    if (!out) return fail(nullptr, PT_E_BAD_ARGUMENT, "out == NULL");
+    *out = nullptr;
+    if (width <= 0 || height <= 0) return fail(nullptr, PT_E_BAD_ARGUMENT, "width/height must be positive");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, PT_E_NO_DEVICE, "no HIP device available (libmi355pt has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, PT_E_BAD_ARGUMENT, "device_id out of range");
+    pt_renderer *h = new (std::nothrow) pt_renderer();
+    if (!h) return fail(nullptr, PT_E_OUT_OF_MEMORY, "host allocation failed");
+    h->device = device_id;
+    h->width = width;
+    h->height = height;
+    h->y0 = 0;
+    h->rows = height;
+#define PT_CREATE_HIP(call)                                                                                            \
+    do {                                                                                                               \
+        hipError_t e2_ = (call);                                                                                       \
+        if (e2_ != hipSuccess) {                                                                                       \
+            int rc_ = hip_fail(nullptr, e2_, #call);                                                                   \
+            pt_destroy(h);                                                                                             \
+            return rc_;                                                                                                \
+        }                                                                                                              \
+    } while (0)
+    PT_CREATE_HIP(hipSetDevice(device_id));
+    PT_CREATE_HIP(hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking));
+    h->stream = h->ownStream;
+    PT_CREATE_HIP(hipEventCreate(&h->evBegin));
+    PT_CREATE_HIP(hipEventCreate(&h->evEnd));
+    PT_CREATE_HIP(hipMalloc((void **)&h->dObjects, PT_GAME_OBJECTS_UBO_SIZE));
+    PT_CREATE_HIP(hipMemsetAsync(h->dObjects, 0, PT_GAME_OBJECTS_UBO_SIZE, h->stream));
+    PT_CREATE_HIP(hipMalloc((void **)&h->dLut, 256 * sizeof(float)));
+    float lut[256];
+    make_srgb_lut(lut);
+    PT_CREATE_HIP(hipMemcpyAsync(h->dLut, lut, sizeof lut, hipMemcpyHostToDevice, h->stream));
+    PT_CREATE_HIP(hipStreamSynchronize(h->stream)); // `lut` is a stack array
+#undef PT_CREATE_HIP
+    int rc = ensure_accum(h);
+    if (rc == PT_OK) rc = clear_accum(h);
+    if (rc != PT_OK) {
+        g_create_error = h->error;
+        pt_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return PT_OK;
+}
+
+PT_API int pt_destroy(pt_handle h)
+{
+    PT_CHECK_HANDLE(h);
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->dObjects) (void)hipFree(h->dObjects);
+    if (h->dLut) (void)hipFree(h->dLut);
+    if (h->dEnv) (void)hipFree(h->dEnv);
+    if (h->dAccum) (void)hipFree(h->dAccum);
+    if (h->evBegin) (void)hipEventDestroy(h->evBegin);
+    if (h->evEnd) (void)hipEventDestroy(h->evEnd);
+    if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
+    h->magic = 0;
+    delete h;
+    return PT_OK;
+}
+
+PT_API int pt_set_size(pt_handle h, int width, int height)
+{
+    PT_CHECK_HANDLE(h);
+    if (width <= 0 || height <= 0) return fail(h, PT_E_BAD_ARGUMENT, "width/height must be positive");
+    if (int rc = bind_device(h)) return rc;
+    h->width = width;
+    h->height = height;
+    h->y0 = 0;
+    h->rows = height;
+    h->frame = 0; // PathTracer.cs:133
+    if (int rc = ensure_accum(h)) return rc;
+    return clear_accum(h);
+}
+
+PT_API int pt_set_tile(pt_handle h, int y0, int rows)
+{
+    PT_CHECK_HANDLE(h);
+    if (y0 < 0 || rows <= 0 || y0 + rows > h->height) return fail(h, PT_E_BAD_ARGUMENT, "tile outside the image");
+    if (int rc = bind_device(h)) return rc;
+    h->y0 = y0;
+    h->rows = rows;
+    h->frame = 0;
+    if (int rc = ensure_accum(h)) return rc;
+    return clear_accum(h);
+}
+
+PT_API int pt_reset(pt_handle h)
+{
+    PT_CHECK_HANDLE(h);
+    h->frame = 0; // PathTracer.cs:139 — frame 0 weights the old contents by 0, so no clear is needed
+    return PT_OK;
+}
+
+PT_API int pt_set_params(pt_handle h, int num_spheres, int num_cuboids, int ray_depth, int spp, float focal_length,
+                         float aperture_diameter)
+{
+    PT_CHECK_HANDLE(h);
+    if (num_spheres < 0 || num_spheres > PT_MAX_SPHERES || num_cuboids < 0 || num_cuboids > PT_MAX_CUBOIDS)
+        return fail(h, PT_E_OUT_OF_RANGE, "object counts exceed the GameObjectsUBO arrays (256 spheres / 64 cuboids)");
+    if (ray_depth < 0 || spp < 1) return fail(h, PT_E_BAD_ARGUMENT, "ray_depth must be >= 0 and spp >= 1");
+    h->numSpheres = num_spheres;
+    h->numCuboids = num_cuboids;
+    h->rayDepth = ray_depth;
+    h->spp = spp;
+    h->focalLength = focal_length;
+    h->apertureDiameter = aperture_diameter;
+    return PT_OK;
+}
+
+PT_API int pt_upload_basic_data(pt_handle h, int byte_offset, int size, const void *src)
+{
+    PT_CHECK_HANDLE(h);
+    if (!src) return fail(h, PT_E_BAD_ARGUMENT, "src == NULL");
+    if (byte_offset < 0 || size < 0 || (long long)byte_offset + size > PT_BASIC_DATA_UBO_SIZE)
+        return fail(h, PT_E_OUT_OF_RANGE, "BasicDataUBO range outside [0,144)");
+    std::memcpy(h->basic + byte_offset, src, (size_t)size);
+    return PT_OK;
+}
+
+PT_API int pt_upload_game_objects(pt_handle h, int byte_offset, int size, const void *src)
+{
+    PT_CHECK_HANDLE(h);
+    if (!src) return fail(h, PT_E_BAD_ARGUMENT, "src == NULL");
+    if (byte_offset < 0 || size < 0 || (long long)byte_offset + size > PT_GAME_OBJECTS_UBO_SIZE)
+        return fail(h, PT_E_OUT_OF_RANGE, "GameObjectsUBO range outside [0,26624)");
+    if (size == 0) return PT_OK;
+    if (int rc = bind_device(h)) return rc;
+    // pageable source: HIP stages the bytes before returning, so the caller may reuse `src` immediately
+    PT_HIP(h, hipMemcpyAsync((char *)h->dObjects + byte_offset, src, (size_t)size, hipMemcpyHostToDevice, h->stream));
+    return PT_OK;
+}
+
+PT_API int pt_set_environment(pt_handle h, int face_size, int format, const void *const faces[6])
+{
+    PT_CHECK_HANDLE(h);
+    if (face_size <= 0 || face_size > 16384) return fail(h, PT_E_BAD_ARGUMENT, "face_size out of range");
+    if (format != PT_ENV_RGBA32F && format != PT_ENV_SRGB8_A8) return fail(h, PT_E_BAD_ARGUMENT, "unknown format");
+    if (!faces) return fail(h, PT_E_BAD_ARGUMENT, "faces == NULL");
+    for (int f = 0; f < 6; f++)
+        if (!faces[f]) return fail(h, PT_E_BAD_ARGUMENT, "faces[i] == NULL");
+    if (int rc = bind_device(h)) return rc;
+    size_t faceBytes = (size_t)face_size * face_size * (format == PT_ENV_RGBA32F ? 16 : 4);
+    size_t total = faceBytes * 6;
+    if (total > h->envBytes) {
+        PT_HIP(h, hipStreamSynchronize(h->stream)); // a queued frame may still sample the old cube
+        if (h->dEnv) PT_HIP(h, hipFree(h->dEnv));
+        h->dEnv = nullptr;
+        h->envBytes = 0;
+        PT_HIP(h, hipMalloc(&h->dEnv, total));
+        h->envBytes = total;
+    }
+    for (int f = 0; f < 6; f++)
+        PT_HIP(h, hipMemcpyAsync((char *)h->dEnv + f * faceBytes, faces[f], faceBytes, hipMemcpyHostToDevice, h->stream));
+    h->envSize = face_size;
+    h->envFormat = format;
+    return PT_OK;
+}
+
+PT_API int pt_render(pt_handle h, int *out_total_samples)
+{
+    PT_CHECK_HANDLE(h);
+    if (!h->dEnv) return fail(h, PT_E_NO_ENVIRONMENT, "pt_render called before pt_set_environment / pt_atmosphere_render");
+    if (h->boundAccum && h->boundBytes < h->tilePixels() * sizeof(float4))
+        return fail(h, PT_E_BAD_ARGUMENT, "bound result buffer is smaller than the tile");
+    if (int rc = bind_device(h)) return rc;
+    pt::FrameArgs a;
+    std::memcpy(a.invProj, h->basic, 64);
+    std::memcpy(a.invView, h->basic + 64, 64);
+    std::memcpy(a.viewPos, h->basic + 128, 12);
+    a.focalLength = h->focalLength;
+    a.apertureDiameter = h->apertureDiameter;
+    a.width = h->width;
+    a.height = h->height;
+    a.y0 = h->y0;
+    a.rows = h->rows;
+    a.numSpheres = h->numSpheres;
+    a.numCuboids = h->numCuboids;
+    a.rayDepth = h->rayDepth;
+    a.spp = h->spp;
+    a.frame = h->frame;
+    a.envSize = h->envSize;
+    a.envFormat = h->envFormat;
+    a.objects = h->dObjects;
+    a.env = h->dEnv;
+    a.srgbLut = h->dLut;
+    a.accum = h->accum();
+    a.tilesX = (h->width + 7) / 8;
+    a.tilesY = (h->rows + 7) / 8;
+    a.variant = h->variant;
+    PT_HIP(h, pt::launch_integrate(a, h->stream));
+    h->frame++; // PathTracer.cs:117 post-increment
+    if (out_total_samples) *out_total_samples = h->frame * h->spp; // PathTracer.cs:112
+    return PT_OK;
+}
+
+PT_API int pt_read_result(pt_handle h, float *dst, size_t row_pitch_bytes)
+{
+    PT_CHECK_HANDLE(h);
+    if (!dst) return fail(h, PT_E_BAD_ARGUMENT, "dst == NULL");
+    size_t rowBytes = (size_t)h->width * 16;
+    if (row_pitch_bytes == 0) row_pitch_bytes = rowBytes;
+    if (row_pitch_bytes < rowBytes) return fail(h, PT_E_BAD_ARGUMENT, "row pitch smaller than a row");
+    if (int rc = bind_device(h)) return rc;
+    PT_HIP(h, hipMemcpy2DAsync(dst, row_pitch_bytes, h->accum(), rowBytes, rowBytes, (size_t)h->rows,
+                               hipMemcpyDeviceToHost, h->stream));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return PT_OK;
+}
+
+PT_API int pt_write_result(pt_handle h, const float *src, size_t row_pitch_bytes, int frame_index)
+{
+    PT_CHECK_HANDLE(h);
+    if (!src || frame_index < 0) return fail(h, PT_E_BAD_ARGUMENT, "src == NULL or negative frame index");
+    size_t rowBytes = (size_t)h->width * 16;
+    if (row_pitch_bytes == 0) row_pitch_bytes = rowBytes;
+    if (row_pitch_bytes < rowBytes) return fail(h, PT_E_BAD_ARGUMENT, "row pitch smaller than a row");
+    if (int rc = bind_device(h)) return rc;
+    PT_HIP(h, hipMemcpy2DAsync(h->accum(), rowBytes, src, row_pitch_bytes, rowBytes, (size_t)h->rows,
+                               hipMemcpyHostToDevice, h->stream));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    h->frame = frame_index;
+    return PT_OK;
+}
+
+PT_API int pt_get_frame_index(pt_handle h, int *out)
+{
+    PT_CHECK_HANDLE(h);
+    if (!out) return fail(h, PT_E_BAD_ARGUMENT, "out == NULL");
+    *out = h->frame;
+    return PT_OK;
+}
+
+PT_API int pt_synchronize(pt_handle h)
+{
+    PT_CHECK_HANDLE(h);
+    if (int rc = bind_device(h)) return rc;
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return PT_OK;
+}
+
+PT_API int pt_atmosphere_upload_data(pt_handle h, int byte_offset, int size, const void *src)
+{
+    PT_CHECK_HANDLE(h);
+    if (!src) return fail(h, PT_E_BAD_ARGUMENT, "src == NULL");
+    if (byte_offset < 0 || size < 0 || (long long)byte_offset + size > PT_ATMOSPHERE_UBO_SIZE)
+        return fail(h, PT_E_OUT_OF_RANGE, "AtmosphericDataUBO range outside [0,464)");
+    std::memcpy(h->atmoUbo + byte_offset, src, (size_t)size);
+    return PT_OK;
+}
+
+PT_API int pt_atmosphere_render(pt_handle h, int size, int i_steps, int j_steps, const float light_pos[3],
+                                float light_intensity)
+{
+    PT_CHECK_HANDLE(h);
+    if (size <= 0 || size > 8192 || i_steps < 0 || j_steps < 0 || !light_pos)
+        return fail(h, PT_E_BAD_ARGUMENT, "bad atmosphere parameters");
+    if (int rc = bind_device(h)) return rc;
+    size_t total = (size_t)6 * size * size * 16;
+    if (total > h->envBytes) {
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->dEnv) PT_HIP(h, hipFree(h->dEnv));
+        h->dEnv = nullptr;
+        h->envBytes = 0;
+        PT_HIP(h, hipMalloc(&h->dEnv, total));
+        h->envBytes = total;
+    }
+    pt::AtmoArgs a;
+    std::memcpy(a.invProj, h->atmoUbo, 64);
+    std::memcpy(a.invView, h->atmoUbo + 64, 6 * 64);
+    a.lightPos[0] = light_pos[0];
+    a.lightPos[1] = light_pos[1];
+    a.lightPos[2] = light_pos[2];
+    a.lightIntensity = light_intensity < 0.0f ? 0.0f : light_intensity; // AtmosphericScatterer.cs:52
+    a.size = size;
+    a.iSteps = i_steps;
+    a.jSteps = j_steps;
+    a.out = (float4 *)h->dEnv;
+    PT_HIP(h, pt::launch_atmosphere(a, h->stream));
+    h->envSize = size;
+    h->envFormat = PT_ENV_RGBA32F;
+    return PT_OK;
+}
+
+PT_API int pt_read_environment(pt_handle h, float *dst, int *out_face_size)
+{
+    PT_CHECK_HANDLE(h);
+    if (!h->dEnv) return fail(h, PT_E_NO_ENVIRONMENT, "no environment set");
+    if (out_face_size) *out_face_size = h->envSize;
+    if (!dst) return PT_OK; // size query
+    if (int rc = bind_device(h)) return rc;
+    size_t n = (size_t)6 * h->envSize * h->envSize;
+    if (h->envFormat == PT_ENV_RGBA32F) {
+        PT_HIP(h, hipMemcpyAsync(dst, h->dEnv, n * 16, hipMemcpyDeviceToHost, h->stream));
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        return PT_OK;
+    }
+    float4 *tmp = nullptr;
+    PT_HIP(h, hipMalloc((void **)&tmp, n * 16));
+    hipError_t e = pt::launch_env_to_float(h->dEnv, h->envSize, h->envFormat, h->dLut, tmp, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, tmp, n * 16, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return hip_fail(h, e, "pt_read_environment");
+    return PT_OK;
+}
+
+PT_API int pt_result_device_ptr(pt_handle h, void **out_ptr, size_t *out_bytes)
+{
+    PT_CHECK_HANDLE(h);
+    if (out_ptr) *out_ptr = h->accum();
+    if (out_bytes) *out_bytes = h->tilePixels() * sizeof(float4);
+    return PT_OK;
+}
+
+PT_API int pt_bind_result_buffer(pt_handle h, void *device_ptr, size_t bytes)
+{
+    PT_CHECK_HANDLE(h);
+    if (device_ptr && bytes < h->tilePixels() * sizeof(float4))
+        return fail(h, PT_E_BAD_ARGUMENT, "buffer smaller than rows*width*16 bytes");
+    h->boundAccum = (float4 *)device_ptr;
+    h->boundBytes = device_ptr ? bytes : 0;
+    return PT_OK;
+}
+
+PT_API int pt_set_stream(pt_handle h, void *hip_stream)
+{
+    PT_CHECK_HANDLE(h);
+    if (int rc = bind_device(h)) return rc;
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->ownStream;
+    return PT_OK;
+}
+
+PT_API int pt_timer_begin(pt_handle h)
+{
+    PT_CHECK_HANDLE(h);
+    if (int rc = bind_device(h)) return rc;
+    PT_HIP(h, hipEventRecord(h->evBegin, h->stream));
+    return PT_OK;
+}
+
+PT_API int pt_timer_end(pt_handle h, float *out_ms)
+{
+    PT_CHECK_HANDLE(h);
+    if (!out_ms) return fail(h, PT_E_BAD_ARGUMENT, "out == NULL");
+    if (int rc = bind_device(h)) return rc;
+    PT_HIP(h, hipEventRecord(h->evEnd, h->stream));
+    PT_HIP(h, hipEventSynchronize(h->evEnd));
+    PT_HIP(h, hipEventElapsedTime(out_ms, h->evBegin, h->evEnd));
+    return PT_OK;
+}
+
+PT_API int pt_set_variant(pt_handle h, int variant)
+{
+    PT_CHECK_HANDLE(h);
+    h->variant = variant;
+    return PT_OK;
+}
+
+} // extern "C"

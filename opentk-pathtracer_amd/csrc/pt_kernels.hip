@@ -1,0 +1,575 @@
+// pt_kernels.hip — hand-written HIP kernels for gfx950 (CDNA4): the path-tracing integrator and the
+// atmosphere environment precompute.  Written from the algorithm, not transpiled: the control structure, data
+// staging and thread mapping are designed for wave64 / LDS / 8 XCDs.
+//
+// What it computes (per pixel, per frame) is the reference's compute shader
+//   /root/reference/OpenTK-PathTracer/res/shaders/PathTracing/compute.glsl:101-369
+// dispatched by src/Render/PathTracer.cs:114-123; each device function cites the GLSL lines it implements.
+//
+// Mapping
+//   * one wavefront (64 lanes) = one 8x8 pixel tile (the reference's 8x8 workgroup, compute.glsl:8);
+//     a 256-thread workgroup = 4 tiles, so the scene is staged into LDS once per 256 pixels;
+//   * the scene (std140 GameObjectsUBO) is re-packed while staging: sphere geometry as one float4 (c.xyz, r),
+//     cuboid geometry as two float4, materials as 4 x float4 — the traversal loop index is wave-uniform, so
+//     every LDS read in the hot loop is a conflict-free broadcast ds_read_b128;
+//   * camera + parameters travel in the kernel argument (SGPRs);
+//   * workgroup -> tile mapping is XCD-aware: consecutive workgroup ids are dealt round-robin to the 8 XCDs by
+//     the dispatcher, so id b is remapped to a contiguous band of tiles per XCD (neighbouring tiles share
+//     environment-map texels in that XCD's L2);
+//   * the accumulation image is read and written as one float4 per lane: a wave covers 8 rows x 128 B segments.
+//
+// Arithmetic: the "pt-f32" contract of pt_math.hpp (bit-identical to oracle/pt_oracle.c).
+// Build flags (see __graft_entry__.build): -O3 -ffp-contract=off -fno-fast-math --offload-arch=gfx950
+#include "pt_kernels.hpp"
+#include "pt_math.hpp"
+
+namespace pt {
+
+struct Material { // std140 Material, compute.glsl:13-26
+    v3 albedo;
+    float specularChance;
+    v3 emissiv;
+    float specularRoughness;
+    v3 absorbance;
+    float refractionChance;
+    float refractionRoughness, ior;
+};
+
+struct Hit { // compute.glsl:44-51 HitInfo
+    float T;
+    bool fromInside;
+    v3 nearHitPos, normal;
+    Material m;
+};
+
+struct SceneLds {
+    const float4 *sph;  // [numSpheres]  (centre.xyz, radius)
+    const float4 *cmin; // [numCuboids]
+    const float4 *cmax; // [numCuboids]
+    const float4 *mat;  // [(numSpheres + numCuboids) * 4]
+    const float *lut;   // [256] sRGB8 -> linear (only staged for SRGB8_A8 environments)
+};
+
+__host__ __device__ inline size_t scene_lds_bytes(int ns, int nc, int envFormat)
+{
+    return (size_t)(ns + 2 * nc + 4 * (ns + nc)) * 16 + (envFormat == 1 ? 1024 : 0);
+}
+
+// ---------------------------------------------------------------------------------------------- environment
+// texture(SamplerEnvironment, dir) (compute.glsl:177): LOD 0, LINEAR magnification, seamless cube edges
+// (src/MainWindow.cs:168,178).  Face selection per OpenGL 4.5 table 8.19 (ties: Z, then X, then Y).
+struct EnvRef {
+    const void *data;
+    const float *lut;
+    int size, format;
+};
+
+PT_DEV v3 env_texel(const EnvRef &e, int face, int x, int y)
+{
+    size_t idx = ((size_t)face * e.size + (size_t)y) * e.size + (size_t)x;
+    if (e.format == 0) {
+        float4 t = ((const float4 *)e.data)[idx];
+        return V(t.x, t.y, t.z);
+    }
+    uchar4 t = ((const uchar4 *)e.data)[idx];
+    return V(e.lut[t.x], e.lut[t.y], e.lut[t.z]);
+}
+
+PT_DEV void face_to_dir(int face, float sc, float tc, float &x, float &y, float &z)
+{
+    switch (face) {
+    case 0: x = 1.0f; y = -tc; z = -sc; break;
+    case 1: x = -1.0f; y = -tc; z = sc; break;
+    case 2: x = sc; y = 1.0f; z = tc; break;
+    case 3: x = sc; y = -1.0f; z = -tc; break;
+    case 4: x = sc; y = -tc; z = 1.0f; break;
+    default: x = -sc; y = -tc; z = -1.0f; break;
+    }
+}
+
+PT_DEV void dir_to_face(float x, float y, float z, int &face, float &sc, float &tc, float &ma)
+{
+    float ax = f_abs(x), ay = f_abs(y), az = f_abs(z);
+    if (az >= f_max(ax, ay)) {
+        face = z < 0.0f ? 5 : 4; ma = az; sc = z < 0.0f ? -x : x; tc = -y;
+    } else if (ax >= ay) {
+        face = x < 0.0f ? 1 : 0; ma = ax; sc = x < 0.0f ? z : -z; tc = -y;
+    } else {
+        face = y < 0.0f ? 3 : 2; ma = ay; sc = x; tc = y < 0.0f ? -z : z;
+    }
+}
+
+// texel (ix,iy), possibly one step outside `face` in one direction -> the texel across the seam
+PT_DEV v3 env_texel_wrapped(const EnvRef &e, int face, int ix, int iy)
+{
+    int S = e.size;
+    if (ix >= 0 && ix < S && iy >= 0 && iy < S) return env_texel(e, face, ix, iy);
+    float fs = (float)S;
+    float sc = ((float)ix + 0.5f) / fs * 2.0f - 1.0f;
+    float tc = ((float)iy + 0.5f) / fs * 2.0f - 1.0f;
+    float x, y, z, ma, nsc, ntc;
+    int nface;
+    face_to_dir(face, sc, tc, x, y, z);
+    dir_to_face(x, y, z, nface, nsc, ntc, ma);
+    float u = (nsc / ma * 0.5f + 0.5f) * fs;
+    float v = (ntc / ma * 0.5f + 0.5f) * fs;
+    int nx = (int)__builtin_floorf(u), ny = (int)__builtin_floorf(v);
+    nx = nx < 0 ? 0 : (nx > S - 1 ? S - 1 : nx);
+    ny = ny < 0 ? 0 : (ny > S - 1 ? S - 1 : ny);
+    return env_texel(e, nface, nx, ny);
+}
+
+PT_DEV v3 sample_env(const EnvRef &e, v3 d)
+{
+    int S = e.size, face;
+    float sc, tc, ma;
+    dir_to_face(d.x, d.y, d.z, face, sc, tc, ma);
+    float ima = 0.5f / ma;
+    float fs = (float)S;
+    float u = f_fma(sc, ima, 0.5f) * fs - 0.5f;
+    float v = f_fma(tc, ima, 0.5f) * fs - 0.5f;
+    u = f_min(f_max(u, -1.0f), fs); // NaN / inf directions: defined, identical clamp on CPU and GPU
+    v = f_min(f_max(v, -1.0f), fs);
+    float fu = __builtin_floorf(u), fv = __builtin_floorf(v);
+    float wu = u - fu, wv = v - fv;
+    int x0 = (int)fu, y0 = (int)fv, x1 = x0 + 1, y1 = y0 + 1;
+    bool offx0 = x0 < 0, offx1 = x1 >= S, offy0 = y0 < 0, offy1 = y1 >= S;
+    float w00 = (1.0f - wu) * (1.0f - wv), w10 = wu * (1.0f - wv), w01 = (1.0f - wu) * wv, w11 = wu * wv;
+    v3 t00, t10, t01, t11;
+    if (!(offx0 || offx1 || offy0 || offy1)) { // interior: the overwhelmingly common case
+        t00 = env_texel(e, face, x0, y0);
+        t10 = env_texel(e, face, x1, y0);
+        t01 = env_texel(e, face, x0, y1);
+        t11 = env_texel(e, face, x1, y1);
+    } else {
+        bool miss00 = offx0 && offy0, miss10 = offx1 && offy0, miss01 = offx0 && offy1, miss11 = offx1 && offy1;
+        v3 zero = V(0.0f, 0.0f, 0.0f);
+        t00 = miss00 ? zero : env_texel_wrapped(e, face, x0, y0);
+        t10 = miss10 ? zero : env_texel_wrapped(e, face, x1, y0);
+        t01 = miss01 ? zero : env_texel_wrapped(e, face, x0, y1);
+        t11 = miss11 ? zero : env_texel_wrapped(e, face, x1, y1);
+        if (miss00 || miss10 || miss01 || miss11) {
+            // cube corner: the missing tap's weight is shared equally by the three existing taps
+            float a = (miss00 ? w00 : miss10 ? w10 : miss01 ? w01 : w11) * 0.333333343f;
+            w00 = miss00 ? 0.0f : w00 + a;
+            w10 = miss10 ? 0.0f : w10 + a;
+            w01 = miss01 ? 0.0f : w01 + a;
+            w11 = miss11 ? 0.0f : w11 + a;
+        }
+    }
+    v3 o;
+    o.x = f_fma(t11.x, w11, f_fma(t01.x, w01, f_fma(t10.x, w10, t00.x * w00)));
+    o.y = f_fma(t11.y, w11, f_fma(t01.y, w01, f_fma(t10.y, w10, t00.y * w00)));
+    o.z = f_fma(t11.z, w11, f_fma(t01.z, w01, f_fma(t10.z, w10, t00.z * w00)));
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------- traversal
+PT_DEV float f_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+PT_DEV float f_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+
+// compute.glsl:322-332 GetNormal(Cuboid)
+PT_DEV v3 cuboid_normal(v3 mn, v3 mx, v3 p)
+{
+    v3 half = v_scale(v_sub(mx, mn), 0.5f);
+    v3 cs = v_sub(p, v_scale(v_add(mx, mn), 0.5f));
+    v3 n;
+    n.x = f_sign(cs.x) * f_step(f_abs(f_abs(cs.x) - half.x), EPSILON);
+    n.y = f_sign(cs.y) * f_step(f_abs(f_abs(cs.y) - half.y), EPSILON);
+    n.z = f_sign(cs.z) * f_step(f_abs(f_abs(cs.z) - half.z), EPSILON);
+    return v_normalize(n);
+}
+
+PT_DEV Material load_material(const float4 *m)
+{
+    float4 a = m[0], b = m[1], c = m[2], d = m[3];
+    Material r;
+    r.albedo = V(a.x, a.y, a.z);     r.specularChance = a.w;
+    r.emissiv = V(b.x, b.y, b.z);    r.specularRoughness = b.w;
+    r.absorbance = V(c.x, c.y, c.z); r.refractionChance = c.w;
+    r.refractionRoughness = d.x;     r.ior = d.y;
+    return r;
+}
+
+// compute.glsl:226-258 RayTrace (+ :261-294 intersections, :316-332 normals).
+// Acceptance uses the ENTRY distance t1 against the stored GetSmallestPositive (compute.glsl:234,247,347-350);
+// objects are visited in reference order; material + normal are evaluated once for the surviving candidate.
+PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h)
+{
+    float T = FLOAT_MAX, wt2 = 0.0f;
+    int winner = -1;
+    for (int i = 0; i < ns; i++) {
+        float4 s = sc.sph[i]; // wave-uniform address: LDS broadcast
+        v3 oc = V(o.x - s.x, o.y - s.y, o.z - s.z);
+        float b = v_dot(d, oc);
+        float c = f_fma(-s.w, s.w, v_dot(oc, oc));
+        float disc = f_fma(b, b, -c);
+        if (!(disc < 0.0f)) {
+            float sq = f_sqrt(disc);
+            float t1 = -b - sq, t2 = -b + sq;
+            if (t1 <= t2 && t2 > 0.0f && t1 < T) {
+                T = t1 < 0.0f ? t2 : t1;
+                wt2 = t2;
+                winner = i;
+            }
+        }
+    }
+    v3 invd = V(f_rcp(d.x), f_rcp(d.y), f_rcp(d.z)); // slab test by reciprocal (pt-f32 contract)
+    for (int i = 0; i < nc; i++) {
+        float4 mn = sc.cmin[i], mx = sc.cmax[i];
+        v3 t0s = V((mn.x - o.x) * invd.x, (mn.y - o.y) * invd.y, (mn.z - o.z) * invd.z);
+        v3 t1s = V((mx.x - o.x) * invd.x, (mx.y - o.y) * invd.y, (mx.z - o.z) * invd.z);
+        v3 sm = V(f_min(t0s.x, t1s.x), f_min(t0s.y, t1s.y), f_min(t0s.z, t1s.z));
+        v3 bg = V(f_max(t0s.x, t1s.x), f_max(t0s.y, t1s.y), f_max(t0s.z, t1s.z));
+        float t1 = f_max(FLOAT_MIN, f_max(sm.x, f_max(sm.y, sm.z)));
+        float t2 = f_min(FLOAT_MAX, f_min(bg.x, f_min(bg.y, bg.z)));
+        if (t1 <= t2 && t2 > 0.0f && t1 < T) {
+            T = t1 < 0.0f ? t2 : t1;
+            wt2 = t2;
+            winner = 256 + i;
+        }
+    }
+    if (winner < 0 || !(T != FLOAT_MAX)) return false; // compute.glsl:257
+    h.T = T;
+    h.fromInside = (T == wt2);
+    h.nearHitPos = v_fma(d, T, o);
+    if (winner < 256) {
+        float4 s = sc.sph[winner];
+        h.m = load_material(sc.mat + 4 * winner);
+        v3 pc = V(h.nearHitPos.x - s.x, h.nearHitPos.y - s.y, h.nearHitPos.z - s.z);
+        h.normal = V(pc.x / s.w, pc.y / s.w, pc.z / s.w); // compute.glsl:316-319
+    } else {
+        int ci = winner - 256;
+        float4 mn = sc.cmin[ci], mx = sc.cmax[ci];
+        h.m = load_material(sc.mat + 4 * (ns + ci));
+        h.normal = cuboid_normal(V(mn.x, mn.y, mn.z), V(mx.x, mx.y, mx.z), h.nearHitPos);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------- sampling / BSDF
+// compute.glsl:297-307
+PT_DEV v3 cosine_sample_hemisphere(v3 n, uint32_t &seed)
+{
+    float z = f_fma(rand01(seed), 2.0f, -1.0f);
+    float a = rand01(seed) * 2.0f * PI;
+    float r = f_sqrt(f_fma(-z, z, 1.0f));
+    float sn, cs;
+    pt_sincos(a, sn, cs);
+    return v_normalize(v_add(n, V(r * cs, r * sn, z)));
+}
+
+// compute.glsl:359-364
+PT_DEV float fresnel_schlick(float cosTheta, float n1, float n2)
+{
+    float r0 = (n1 - n2) / (n1 + n2);
+    r0 *= r0;
+    return f_fma(1.0f - r0, pt_pow5(1.0f - cosTheta), r0);
+}
+
+PT_DEV v3 f_reflect(v3 i, v3 n) { return v_fma(n, -(2.0f * v_dot(n, i)), i); }
+
+PT_DEV v3 f_refract(v3 i, v3 n, float eta)
+{
+    float ni = v_dot(n, i);
+    float k = f_fma(-(eta * eta), f_fma(-ni, ni, 1.0f), 1.0f);
+    if (k < 0.0f) return V(0.0f, 0.0f, 0.0f);
+    float f = f_fma(eta, ni, f_sqrt(k));
+    return V(f_fma(eta, i.x, -(f * n.x)), f_fma(eta, i.y, -(f * n.y)), f_fma(eta, i.z, -(f * n.z)));
+}
+
+// compute.glsl:184-224 BSDF: picks the next ray, returns its probability
+PT_DEV float bsdf(v3 &ro, v3 &rd, const Hit &h, bool &isRefractive, uint32_t &seed)
+{
+    isRefractive = false;
+    float spec = h.m.specularChance, refr = h.m.refractionChance;
+    if (spec > 0.0f) {
+        float n1 = h.fromInside ? h.m.ior : 1.0f, n2 = !h.fromInside ? h.m.ior : 1.0f;
+        spec = f_mix(spec, 1.0f, fresnel_schlick(v_dot(v_neg(rd), h.normal), n1, n2));
+        float diffuse = 1.0f - spec - refr;
+        refr = 1.0f - spec - diffuse;
+    }
+    v3 diffuseRay = cosine_sample_hemisphere(h.normal, seed);
+    float prob;
+    float roll = rand01(seed);
+    if (spec > roll) {
+        v3 refl = f_reflect(rd, h.normal);
+        rd = v_normalize(v_mix(refl, diffuseRay, h.m.specularRoughness * h.m.specularRoughness));
+        prob = spec;
+    } else if (spec + refr > roll) {
+        v3 rf = f_refract(rd, h.normal, h.fromInside ? (h.m.ior / 1.0f) : (1.0f / h.m.ior));
+        v3 rough = cosine_sample_hemisphere(v_neg(h.normal), seed);
+        rd = v_normalize(v_mix(rf, rough, h.m.refractionRoughness * h.m.refractionRoughness));
+        prob = refr;
+        isRefractive = true;
+    } else {
+        rd = diffuseRay;
+        prob = 1.0f - spec - refr;
+    }
+    ro = v_fma(rd, EPSILON, h.nearHitPos);
+    return f_max(prob, EPSILON);
+}
+
+// compute.glsl:132-182 Radiance
+PT_DEV v3 radiance(const FrameArgs &a, const SceneLds &sc, const EnvRef &env, v3 ro, v3 rd, uint32_t &seed)
+{
+    v3 throughput = V(1.0f, 1.0f, 1.0f), rad = V(0.0f, 0.0f, 0.0f);
+    Hit h;
+    for (int i = 0; i < a.rayDepth; i++) {
+        if (ray_trace(sc, a.numSpheres, a.numCuboids, ro, rd, h)) {
+            if (h.fromInside) { // Beer's law, compute.glsl:145-149
+                h.normal = v_neg(h.normal);
+                throughput.x *= pt_exp(-h.m.absorbance.x * h.T);
+                throughput.y *= pt_exp(-h.m.absorbance.y * h.T);
+                throughput.z *= pt_exp(-h.m.absorbance.z * h.T);
+            }
+            bool isRefractive;
+            float prob = bsdf(ro, rd, h, isRefractive, seed);
+            rad = V(f_fma(h.m.emissiv.x, throughput.x, rad.x), f_fma(h.m.emissiv.y, throughput.y, rad.y),
+                    f_fma(h.m.emissiv.z, throughput.z, rad.z));
+            if (!isRefractive) throughput = v_mul(throughput, h.m.albedo);
+            throughput = V(throughput.x / prob, throughput.y / prob, throughput.z / prob);
+            float p = f_max(throughput.x, f_max(throughput.y, throughput.z)); // Russian roulette, :167-173
+            if (rand01(seed) > p) break;
+            throughput = V(throughput.x / p, throughput.y / p, throughput.z / p);
+        } else {
+            v3 e = sample_env(env, rd); // compute.glsl:177
+            rad = V(f_fma(e.x, throughput.x, rad.x), f_fma(e.y, throughput.y, rad.y), f_fma(e.z, throughput.z, rad.z));
+            break;
+        }
+    }
+    return rad;
+}
+
+// GLSL mat4 * vec4 on the column-major view of the UBO bytes: m[4c + r]
+PT_DEV void mat_vec(const float *m, float x, float y, float z, float w, float *out)
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) out[r] = f_fma(m[12 + r], w, f_fma(m[8 + r], z, f_fma(m[4 + r], y, m[r] * x)));
+}
+
+// compute.glsl:101-130 main for one pixel: returns the new accumulation value
+PT_DEV float4 shade_pixel(const FrameArgs &a, const SceneLds &sc, const EnvRef &env, int px, int py, float4 last)
+{
+    uint32_t seed = ((uint32_t)px * 1973u + (uint32_t)py * 9277u + (uint32_t)a.frame * 2699u) | 1u; // :106
+    v3 irr = V(0.0f, 0.0f, 0.0f);
+    v3 viewPos = V(a.viewPos[0], a.viewPos[1], a.viewPos[2]);
+    for (int s = 0; s < a.spp; s++) {
+        float u0 = rand01(seed), u1 = rand01(seed); // :113
+        float ndcx = f_fma(((float)px + u0) / (float)a.width, 2.0f, -1.0f);
+        float ndcy = f_fma(((float)py + u1) / (float)a.height, 2.0f, -1.0f);
+        float eye[4], wd[4]; // GetWorldSpaceRay :352-357
+        mat_vec(a.invProj, ndcx, ndcy, -1.0f, 0.0f, eye);
+        mat_vec(a.invView, eye[0], eye[1], -1.0f, 0.0f, wd);
+        v3 dir = v_normalize(V(wd[0], wd[1], wd[2]));
+        v3 focal = v_fma(dir, a.focalLength, viewPos); // :117
+        float angle = rand01(seed) * 2.0f * PI;        // UniformSampleUnitCircle :309-314
+        float rr = f_sqrt(rand01(seed));
+        float sn, cs;
+        pt_sincos(angle, sn, cs);
+        float half_ap = a.apertureDiameter * 0.5f;
+        float ox = half_ap * (cs * rr), oy = half_ap * (sn * rr);
+        float org[4];
+        mat_vec(a.invView, ox, oy, 0.0f, 1.0f, org); // :120
+        v3 ro = V(org[0], org[1], org[2]);
+        v3 rd = v_normalize(v_sub(focal, ro));
+        irr = v_add(irr, radiance(a, sc, env, ro, rd, seed));
+    }
+    float fspp = (float)a.spp;
+    irr = V(irr.x / fspp, irr.y / fspp, irr.z / fspp); // :125
+    float w = 1.0f / (float)(a.frame + 1);             // :128
+    return make_float4(f_mix(last.x, irr.x, w), f_mix(last.y, irr.y, w), f_mix(last.z, irr.z, w), 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------- kernels
+extern __shared__ float4 g_lds[];
+
+__global__ __launch_bounds__(256) void pt_integrate_kernel(const FrameArgs a)
+{
+    const int ns = a.numSpheres, nc = a.numCuboids;
+    float4 *sph = g_lds;
+    float4 *cmin = sph + ns;
+    float4 *cmax = cmin + nc;
+    float4 *mat = cmax + nc;
+    float *lut = (float *)(mat + 4 * (ns + nc));
+    const int tid = threadIdx.x;
+
+    // ---- stage + re-pack the scene: std140 Sphere = 5 x float4 (geometry, 4 x material), Cuboid = 6 x float4
+    const float4 *obj = (const float4 *)a.objects;
+    for (int i = tid; i < ns * 5; i += 256) {
+        int s = i / 5, part = i - s * 5;
+        float4 v = obj[i];
+        if (part == 0) sph[s] = v;
+        else mat[4 * s + part - 1] = v;
+    }
+    for (int i = tid; i < nc * 6; i += 256) {
+        int c = i / 6, part = i - c * 6;
+        float4 v = obj[1280 + i]; // Cuboids[] start at byte 20480 = float4 index 1280
+        if (part == 0) cmin[c] = v;
+        else if (part == 1) cmax[c] = v;
+        else mat[4 * (ns + c) + part - 2] = v;
+    }
+    if (a.envFormat == 1) lut[tid] = a.srgbLut[tid];
+    __syncthreads();
+
+    SceneLds sc{sph, cmin, cmax, mat, lut};
+    EnvRef env{a.env, lut, a.envSize, a.envFormat};
+
+    // ---- XCD-aware workgroup -> tile-quad mapping (workgroup b runs on XCD b % 8)
+    const int nwg = gridDim.x;
+    int b = blockIdx.x;
+    {
+        int per = nwg >> 3; // workgroups per XCD band (the tail nwg & 7 keeps its identity mapping)
+        if (b < per * 8) b = (b & 7) * per + (b >> 3);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    const int tile = b * 4 + wave;
+    if (tile >= a.tilesX * a.tilesY) return;
+    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const int px = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3); // row inside this GPU's row block
+    if (px >= a.width || ly >= a.rows) return;
+    const size_t idx = (size_t)ly * a.width + px;
+    float4 last = a.accum[idx];                                // imageLoad  (compute.glsl:126)
+    a.accum[idx] = shade_pixel(a, sc, env, px, a.y0 + ly, last); // imageStore (compute.glsl:129)
+}
+
+hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream)
+{
+    int tiles = a.tilesX * a.tilesY;
+    int nwg = (tiles + 3) / 4;
+    size_t lds = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat);
+    hipLaunchKernelGGL(pt_integrate_kernel, dim3(nwg), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- clear
+__global__ void pt_clear_kernel(float4 *p, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+hipError_t launch_clear(float4 *p, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pt_clear_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, n);
+    return hipGetLastError();
+}
+
+__global__ void pt_env_to_float_kernel(const void *env, int size, int format, const float *lut, float4 *out)
+{
+    size_t n = (size_t)6 * size * size;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (format == 0) {
+        out[i] = ((const float4 *)env)[i];
+    } else {
+        uchar4 t = ((const uchar4 *)env)[i];
+        out[i] = make_float4(lut[t.x], lut[t.y], lut[t.z], (float)t.w / 255.0f);
+    }
+}
+
+hipError_t launch_env_to_float(const void *env, int envSize, int envFormat, const float *srgbLut, float4 *out,
+                               hipStream_t stream)
+{
+    size_t n = (size_t)6 * envSize * envSize;
+    hipLaunchKernelGGL(pt_env_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, env, envSize,
+                       envFormat, srgbLut, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- atmosphere
+// /root/reference/OpenTK-PathTracer/res/shaders/AtmosphericScattering/compute.glsl:30-171
+// (algorithm credited there to github.com/wwwtyro/glsl-atmosphere); one thread per cube texel.
+PT_DEV void atmo_rsi(v3 r0, v3 rd, float sr, float &x, float &y) // :58-71
+{
+    float a = v_dot(rd, rd);
+    float b = 2.0f * v_dot(rd, r0);
+    float c = f_fma(-sr, sr, v_dot(r0, r0));
+    float d = f_fma(b, b, -(4.0f * a * c));
+    if (d < 0.0f) { x = 1e5f; y = -1e5f; return; }
+    float sq = f_sqrt(d), den = 2.0f * a;
+    x = (-b - sq) / den;
+    y = (-b + sq) / den;
+}
+
+PT_DEV v3 atmosphere(v3 r, v3 r0, v3 pSun, float iSun, float rPlanet, float rAtmos, v3 kRlh, float kMie, float shRlh,
+                     float shMie, float g, int iSteps, int jSteps) // :73-159
+{
+    pSun = v_normalize(pSun);
+    r = v_normalize(r);
+    float px, py, qx, qy;
+    atmo_rsi(r0, r, rAtmos, px, py);
+    if (px > py) return V(0.0f, 0.0f, 0.0f);
+    atmo_rsi(r0, r, rPlanet, qx, qy);
+    py = f_min(py, qx);
+    float iStepSize = (py - px) / (float)iSteps;
+    float iTime = 0.0f;
+    v3 totalRlh = V(0.0f, 0.0f, 0.0f), totalMie = V(0.0f, 0.0f, 0.0f);
+    float iOdRlh = 0.0f, iOdMie = 0.0f;
+    float mu = v_dot(r, pSun), mumu = mu * mu, gg = g * g;
+    float pRlh = 3.0f / (16.0f * PI) * (1.0f + mumu);
+    float base = 1.0f + gg - 2.0f * mu * g;
+    float pMie = 3.0f / (8.0f * PI) * ((1.0f - gg) * (mumu + 1.0f)) / ((base * f_sqrt(base)) * (2.0f + gg));
+    float invShRlh = -1.0f / shRlh, invShMie = -1.0f / shMie;
+    for (int i = 0; i < iSteps; i++) {
+        v3 iPos = v_fma(r, f_fma(iStepSize, 0.5f, iTime), r0);
+        float iHeight = f_sqrt(v_dot(iPos, iPos)) - rPlanet;
+        float odStepRlh = pt_exp(iHeight * invShRlh) * iStepSize;
+        float odStepMie = pt_exp(iHeight * invShMie) * iStepSize;
+        iOdRlh += odStepRlh;
+        iOdMie += odStepMie;
+        float sx, sy;
+        atmo_rsi(iPos, pSun, rAtmos, sx, sy);
+        float jStepSize = sy / (float)jSteps;
+        float jTime = 0.0f, jOdRlh = 0.0f, jOdMie = 0.0f;
+        for (int j = 0; j < jSteps; j++) {
+            v3 jPos = v_fma(pSun, f_fma(jStepSize, 0.5f, jTime), iPos);
+            float jHeight = f_sqrt(v_dot(jPos, jPos)) - rPlanet;
+            jOdRlh = f_fma(pt_exp(jHeight * invShRlh), jStepSize, jOdRlh);
+            jOdMie = f_fma(pt_exp(jHeight * invShMie), jStepSize, jOdMie);
+            jTime += jStepSize;
+        }
+        float mieTerm = kMie * (iOdMie + jOdMie), rl = iOdRlh + jOdRlh;
+        v3 attn = V(pt_exp(-f_fma(kRlh.x, rl, mieTerm)), pt_exp(-f_fma(kRlh.y, rl, mieTerm)),
+                    pt_exp(-f_fma(kRlh.z, rl, mieTerm)));
+        totalRlh = v_fma(attn, odStepRlh, totalRlh);
+        totalMie = v_fma(attn, odStepMie, totalMie);
+        iTime += iStepSize;
+    }
+    float pm = pMie * kMie;
+    return V(iSun * f_fma(pRlh * kRlh.x, totalRlh.x, pm * totalMie.x),
+             iSun * f_fma(pRlh * kRlh.y, totalRlh.y, pm * totalMie.y),
+             iSun * f_fma(pRlh * kRlh.z, totalRlh.z, pm * totalMie.z));
+}
+
+__global__ __launch_bounds__(256) void atmo_precompute_kernel(const AtmoArgs a)
+{
+    const int S = a.size;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)6 * S * S) return;
+    int x = (int)(i % S), y = (int)((i / S) % S), face = (int)(i / ((size_t)S * S));
+    // main :30-56 — ndc from the texel's integer coordinate (no half-texel offset)
+    float ndcx = f_fma((float)x / (float)S, 2.0f, -1.0f), ndcy = f_fma((float)y / (float)S, 2.0f, -1.0f);
+    float eye[4], wd[4];
+    mat_vec(a.invProj, ndcx, ndcy, -1.0f, 0.0f, eye);
+    mat_vec(a.invView[face], eye[0], eye[1], -1.0f, 0.0f, wd);
+    v3 dir = v_normalize(V(wd[0], wd[1], wd[2]));
+    v3 col = atmosphere(dir, V(0.0f, 6376e3f, 0.0f), V(a.lightPos[0], a.lightPos[1], a.lightPos[2]), a.lightIntensity,
+                        6371e3f, 6471e3f, V(5.5e-6f, 13.0e-6f, 22.4e-6f), 21e-6f, 8e3f, 1.2e3f, 0.758f, a.iSteps,
+                        a.jSteps);
+    a.out[i] = make_float4(col.x, col.y, col.z, 1.0f);
+}
+
+hipError_t launch_atmosphere(const AtmoArgs &a, hipStream_t stream)
+{
+    size_t n = (size_t)6 * a.size * a.size;
+    hipLaunchKernelGGL(atmo_precompute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace pt

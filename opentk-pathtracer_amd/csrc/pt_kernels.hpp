@@ -1,0 +1,46 @@
+// pt_kernels.hpp — host-visible launch interface of the HIP kernels (implemented in pt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pt {
+
+// Everything one dispatch of the integrator needs; passed BY VALUE as the kernel argument so that all of it is
+// wave-uniform scalar (SGPR) data.  Mirrors what the reference binds around GL.DispatchCompute
+// (src/Render/PathTracer.cs:116-123): UBO 0 (camera), UBO 1 (scene), the 7 uniforms, sampler unit 1, image unit 0.
+struct FrameArgs {
+    float invProj[16]; // BasicDataUBO.InvProjection, GLSL column-major view of the bytes (compute.glsl:61)
+    float invView[16]; // BasicDataUBO.InvView (compute.glsl:62)
+    float viewPos[3];  // BasicDataUBO.ViewPos (compute.glsl:63)
+    float focalLength, apertureDiameter; // compute.glsl:93-94
+    int width, height; // full image size: imageSize(ImgResult) (compute.glsl:103)
+    int y0, rows;      // row block owned by this GPU (multi-GPU tiling); y0=0, rows=height on one GPU
+    int numSpheres, numCuboids; // uboGameObjectsSize (compute.glsl:88)
+    int rayDepth, spp; // compute.glsl:90-91
+    int frame;         // thisRendererFrame (compute.glsl:96)
+    int envSize, envFormat; // cube face size; 0 = RGBA32F, 1 = SRGB8_A8
+    const float *objects;   // device copy of the raw 26,624-byte GameObjectsUBO (std140)
+    const void *env;        // device cube: [6][envSize][envSize] texels (float4 or uchar4)
+    const float *srgbLut;   // 256-entry sRGB8 -> linear table (device)
+    float4 *accum;          // rows x width RGBA32F accumulation image (row 0 = image row y0)
+    int tilesX, tilesY;     // 8x8-pixel tiles covering width x rows
+    int variant;            // kernel variant for A/B runs; all variants are bit-identical in output
+};
+
+struct AtmoArgs {
+    float invProj[16];
+    float invView[6][16];
+    float lightPos[3];
+    float lightIntensity;
+    int size, iSteps, jSteps;
+    float4 *out; // [6][size][size]
+};
+
+hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream);
+hipError_t launch_atmosphere(const AtmoArgs &a, hipStream_t stream);
+hipError_t launch_clear(float4 *p, size_t n, hipStream_t stream);
+// linearise any environment into RGBA32F for read-back
+hipError_t launch_env_to_float(const void *env, int envSize, int envFormat, const float *srgbLut, float4 *out,
+                               hipStream_t stream);
+
+} // namespace pt

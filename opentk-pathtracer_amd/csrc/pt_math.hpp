@@ -1,0 +1,109 @@
+// pt_math.hpp — the "pt-f32" arithmetic contract on the device side (gfx950).
+//
+// Every routine here is a fixed sequence of IEEE-754 binary32 operations (correctly rounded +,-,*,/,sqrt and
+// explicitly written fma), so the HIP integrator reproduces the CPU oracle bit for bit.  The translation unit
+// that includes this header must be compiled with  -ffp-contract=off -fno-fast-math  and WITHOUT
+// -fgpu-flush-denormals-to-zero (hipcc's default keeps denormals and uses correctly rounded fp32 divide/sqrt).
+// No hardware approximations (v_rcp/v_rsq/v_sin/v_exp) are used on the parity path.
+//
+// GLSL built-ins of the reference shader (res/shaders/PathTracing/compute.glsl) map as follows:
+//   dot -> v_dot (fma chain), normalize -> v * (1/sqrt(dot)), mix -> fma(y,a,x*(1-a)), min/max -> minNum/maxNum,
+//   sin/cos -> pt_sincos, exp -> pt_exp, pow(x,5.0) -> pt_pow5, reflect/refract -> GLSL 4.50 section 8.5 formulas.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pt {
+
+#define PT_DEV __device__ __forceinline__
+
+constexpr float FLOAT_MAX = 3.4028235e+38f;  // compute.glsl:2
+constexpr float FLOAT_MIN = -3.4028235e+38f; // compute.glsl:3
+constexpr float EPSILON = 0.001f;            // compute.glsl:4
+constexpr float PI = 3.14159265f;            // compute.glsl:5
+
+struct v3 {
+    float x, y, z;
+};
+
+PT_DEV float f_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PT_DEV float f_min(float a, float b) { return __builtin_fminf(a, b); }
+PT_DEV float f_max(float a, float b) { return __builtin_fmaxf(a, b); }
+PT_DEV float f_rcp(float a) { return 1.0f / a; }
+PT_DEV float f_sqrt(float a) { return __builtin_sqrtf(a); }
+PT_DEV float f_abs(float a) { return __builtin_fabsf(a); }
+PT_DEV float f_mix(float x, float y, float a) { return f_fma(y, a, x * (1.0f - a)); }
+
+PT_DEV v3 V(float x, float y, float z) { return v3{x, y, z}; }
+PT_DEV v3 v_add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV v3 v_sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV v3 v_mul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV v3 v_scale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+PT_DEV v3 v_neg(v3 a) { return V(-a.x, -a.y, -a.z); }
+PT_DEV v3 v_fma(v3 b, float s, v3 a) { return V(f_fma(b.x, s, a.x), f_fma(b.y, s, a.y), f_fma(b.z, s, a.z)); }
+PT_DEV float v_dot(v3 a, v3 b) { return f_fma(a.z, b.z, f_fma(a.y, b.y, a.x * b.x)); }
+PT_DEV v3 v_normalize(v3 a) { return v_scale(a, f_rcp(f_sqrt(v_dot(a, a)))); }
+PT_DEV v3 v_mix(v3 x, v3 y, float a)
+{
+    float ia = 1.0f - a;
+    return V(f_fma(y.x, a, x.x * ia), f_fma(y.y, a, x.y * ia), f_fma(y.z, a, x.z * ia));
+}
+
+// sin/cos on the small arguments the integrator produces ([0, 2*pi]): Cody-Waite by pi/2 (two fused steps),
+// single-precision minimax polynomials on [-pi/4, pi/4], quadrant fix-up.
+PT_DEV void pt_sincos(float a, float &sn, float &cs)
+{
+    float k = __builtin_rintf(a * 0.636619772f);
+    float r = f_fma(k, -1.57079637050628662109375f, a);
+    r = f_fma(k, 4.37113900018624283e-8f, r);
+    float z = r * r;
+    float ps = f_fma(f_fma(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float s = f_fma(ps * z, r, r);
+    float pc = f_fma(f_fma(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    float c = f_fma(pc * z, z, f_fma(-0.5f, z, 1.0f));
+    int q = (int)k & 3;
+    float s_out = (q & 1) ? c : s;
+    float c_out = (q & 1) ? s : c;
+    if (q == 1 || q == 2) c_out = -c_out;
+    if (q >= 2) s_out = -s_out;
+    sn = s_out;
+    cs = c_out;
+}
+
+// e^x: n = rint(x*log2 e), two-step fused reduction, degree-6 polynomial, 2^n as two exact power-of-two factors.
+PT_DEV float pt_exp(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return __builtin_inff();
+    if (x < -104.0f) return 0.0f;
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = f_fma(n, -0.693145751953125f, x);
+    r = f_fma(n, -1.428606765330187045e-06f, r);
+    float p = f_fma(1.9875691500e-4f, r, 1.3981999507e-3f);
+    p = f_fma(p, r, 8.3334519073e-3f);
+    p = f_fma(p, r, 4.1665795894e-2f);
+    p = f_fma(p, r, 1.6666665459e-1f);
+    p = f_fma(p, r, 5.0000001201e-1f);
+    float y = f_fma(p, r * r, r) + 1.0f;
+    int ni = (int)n;
+    int n1 = ni >> 1, n2 = ni - n1;
+    y = y * __uint_as_float((uint32_t)(n1 + 127) << 23);
+    return y * __uint_as_float((uint32_t)(n2 + 127) << 23);
+}
+
+PT_DEV float pt_pow5(float x)
+{
+    float x2 = x * x;
+    return x * (x2 * x2);
+}
+
+// compute.glsl:334-344 — PCG hash RNG; uint -> float conversion is round-to-nearest-even, /2^32 is exact.
+PT_DEV uint32_t pcg_hash(uint32_t &seed)
+{
+    seed = seed * 747796405u + 2891336453u;
+    uint32_t word = ((seed >> ((seed >> 28u) + 4u)) ^ seed) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+PT_DEV float rand01(uint32_t &seed) { return (float)pcg_hash(seed) * 2.3283064365386962890625e-10f; }
+
+} // namespace pt

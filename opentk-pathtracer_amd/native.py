@@ -1,0 +1,125 @@
+"""ctypes binding of libmi355pt.so (the C ABI in include/mi355pt.h) + the build recipe.
+
+The library is built IN-TREE (opentk-pathtracer_amd/libmi355pt.so) with hipcc for gfx950; there is no CPU
+fallback anywhere in this package: if the shared object is missing or no HIP device is present, calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libmi355pt.so")
+HEADER = os.path.join(REPO, "include", "mi355pt.h")
+SOURCES = ["pt_kernels.hip", "mi355pt.cpp"]
+# -ffp-contract=off / -fno-fast-math are part of the pt-f32 arithmetic contract (csrc/pt_math.hpp)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+               "-fvisibility=hidden"]
+
+PT_OK = 0
+PT_E_BAD_HANDLE, PT_E_BAD_ARGUMENT, PT_E_OUT_OF_RANGE, PT_E_NO_ENVIRONMENT, PT_E_HIP, PT_E_NO_DEVICE, PT_E_OOM = \
+    -1, -2, -3, -4, -5, -6, -7
+PT_ENV_RGBA32F, PT_ENV_SRGB8_A8 = 0, 1
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libmi355pt error {code}: {message}")
+        self.code = code
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libmi355pt.so")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [HEADER]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 ... -> opentk-pathtracer_amd/libmi355pt.so (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [hipcc_path()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or p.returncode != 0:
+        print(" ".join(cmd))
+        print(p.stdout + p.stderr)
+    if p.returncode != 0:
+        raise RuntimeError("hipcc failed building libmi355pt.so")
+    return LIB_PATH
+
+
+def declared_symbols() -> list[str]:
+    """Every function the public header declares with PT_API."""
+    text = open(HEADER).read()
+    return sorted(set(re.findall(r"PT_API\s+[\w\s\*]+?\b(pt_\w+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library (never builds implicitly on a box without hipcc; never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing — run __graft_entry__.build() (hipcc, gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+    sig = {
+        "pt_create": [C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+        "pt_destroy": [vp],
+        "pt_set_size": [vp, C.c_int, C.c_int],
+        "pt_set_tile": [vp, C.c_int, C.c_int],
+        "pt_reset": [vp],
+        "pt_set_params": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float],
+        "pt_upload_basic_data": [vp, C.c_int, C.c_int, vp],
+        "pt_upload_game_objects": [vp, C.c_int, C.c_int, vp],
+        "pt_set_environment": [vp, C.c_int, C.c_int, C.POINTER(vp)],
+        "pt_render": [vp, ip],
+        "pt_read_result": [vp, fp, C.c_size_t],
+        "pt_write_result": [vp, fp, C.c_size_t, C.c_int],
+        "pt_get_frame_index": [vp, ip],
+        "pt_synchronize": [vp],
+        "pt_atmosphere_upload_data": [vp, C.c_int, C.c_int, vp],
+        "pt_atmosphere_render": [vp, C.c_int, C.c_int, C.c_int, fp, C.c_float],
+        "pt_read_environment": [vp, fp, ip],
+        "pt_result_device_ptr": [vp, C.POINTER(vp), C.POINTER(C.c_size_t)],
+        "pt_bind_result_buffer": [vp, vp, C.c_size_t],
+        "pt_set_stream": [vp, vp],
+        "pt_timer_begin": [vp],
+        "pt_timer_end": [vp, fp],
+        "pt_set_variant": [vp, C.c_int],
+        "pt_device_count": [],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    L.pt_last_error.argtypes = [vp]
+    L.pt_last_error.restype = C.c_char_p
+    L.pt_version.argtypes = []
+    L.pt_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc: int, handle=None) -> int:
+    if rc != PT_OK:
+        msg = load().pt_last_error(handle)
+        raise NativeError(rc, msg.decode() if msg else "")
+    return rc

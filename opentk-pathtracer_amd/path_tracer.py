@@ -1,0 +1,239 @@
+"""Host-side mirror of the reference's renderer classes over the C ABI (harness glue for tests and bench).
+
+  PathTracer            /root/reference/OpenTK-PathTracer/src/Render/PathTracer.cs:9-141
+  AtmosphericScatterer  /root/reference/OpenTK-PathTracer/src/Render/AtmosphericScatterer.cs:9-119
+  BufferObject.SubData  /root/reference/OpenTK-PathTracer/src/Render/Objects/BufferObject.cs:37-48
+
+Member names and argument meaning follow the C# classes (NumSpheres, RayDepth, SPP, Render(), SetSize(),
+ResetRenderer(), Samples, Result ...), so the call sequence of the reference's MainWindow can be replayed as is.
+Every method is a thin call into libmi355pt.so; there is no Python or CPU implementation of the integrator here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import native
+from .native import check
+
+
+class EnvironmentMap:
+    """A cube texture as the host would hand it to GL: 6 faces (+X,-X,+Y,-Y,+Z,-Z), RGBA32F or SRGB8_A8
+    (MainWindow.cs:177-187)."""
+
+    def __init__(self, faces: np.ndarray):
+        faces = np.ascontiguousarray(faces)
+        if faces.ndim != 4 or faces.shape[0] != 6 or faces.shape[1] != faces.shape[2] or faces.shape[3] != 4:
+            raise ValueError("faces must have shape (6, S, S, 4)")
+        if faces.dtype == np.float32:
+            self.format = native.PT_ENV_RGBA32F
+        elif faces.dtype == np.uint8:
+            self.format = native.PT_ENV_SRGB8_A8
+        else:
+            raise ValueError("faces must be float32 (RGBA32F) or uint8 (SRGB8_A8)")
+        self.faces = faces
+        self.size = faces.shape[1]
+
+
+class UniformBuffer:
+    """BufferObject bound as UBO 0 (BasicDataUBO) or UBO 1 (GameObjectsUBO): SubData(offset, size, data)."""
+
+    def __init__(self, tracer: "PathTracer", which: str):
+        self._t, self._which = tracer, which
+
+    def SubData(self, offset: int, size: int, data) -> None:
+        buf = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8) if isinstance(data, (bytes, bytearray))
+                                   else np.asarray(data))
+        if buf.nbytes < size:
+            raise ValueError("data shorter than size")
+        fn = self._t._lib.pt_upload_basic_data if self._which == "basic" else self._t._lib.pt_upload_game_objects
+        check(fn(self._t._h, offset, size, buf.ctypes.data_as(C.c_void_p)), self._t._h)
+
+
+class PathTracer:
+    def __init__(self, environmentMap, width: int, height: int, rayDepth: int, spp: int, focalLength: float,
+                 apertureDiamater: float, device: int = 0):
+        self._lib = native.load()
+        h = C.c_void_p()
+        check(self._lib.pt_create(device, width, height, C.byref(h)))
+        self._h = h
+        self.Width, self.Height = width, height
+        self._numSpheres = self._numCuboids = 0
+        self._rayDepth, self._spp = rayDepth, spp
+        self._focalLength, self._apertureDiameter = focalLength, apertureDiamater
+        self._push_params()
+        self._env = None
+        self.BasicDataUBO = UniformBuffer(self, "basic")       # MainWindow.cs:195-197
+        self.GameObjectsUBO = UniformBuffer(self, "objects")   # MainWindow.cs:199-201
+        self.y0, self.rows = 0, height
+        if environmentMap is not None:
+            self.EnvironmentMap = environmentMap
+
+    # -- the six uniform-setting properties, PathTracer.cs:11-83
+    def _push_params(self):
+        check(self._lib.pt_set_params(self._h, self._numSpheres, self._numCuboids, self._rayDepth, self._spp,
+                                      self._focalLength, self._apertureDiameter), self._h)
+
+    def _prop(name):  # noqa: N805
+        def get(self):
+            return getattr(self, name)
+
+        def set_(self, v):
+            setattr(self, name, v)
+            self._push_params()
+        return property(get, set_)
+
+    NumSpheres = _prop("_numSpheres")
+    NumCuboids = _prop("_numCuboids")
+    RayDepth = _prop("_rayDepth")
+    SPP = _prop("_spp")
+    FocalLength = _prop("_focalLength")
+    ApertureDiameter = _prop("_apertureDiameter")
+    del _prop
+
+    @property
+    def EnvironmentMap(self):  # PathTracer.cs:85
+        return self._env
+
+    @EnvironmentMap.setter
+    def EnvironmentMap(self, env):
+        if isinstance(env, AtmosphericScatterer):
+            env._select(self)
+        else:
+            if not isinstance(env, EnvironmentMap):
+                env = EnvironmentMap(env)
+            ptrs = (C.c_void_p * 6)(*[env.faces[f].ctypes.data_as(C.c_void_p) for f in range(6)])
+            check(self._lib.pt_set_environment(self._h, env.size, env.format, ptrs), self._h)
+        self._env = env
+
+    @property
+    def Samples(self) -> int:  # PathTracer.cs:112
+        return self.FrameIndex * self._spp
+
+    @property
+    def FrameIndex(self) -> int:
+        v = C.c_int()
+        check(self._lib.pt_get_frame_index(self._h, C.byref(v)), self._h)
+        return v.value
+
+    def Render(self) -> int:  # PathTracer.cs:114-129
+        total = C.c_int()
+        check(self._lib.pt_render(self._h, C.byref(total)), self._h)
+        return total.value
+
+    def SetSize(self, width: int, height: int) -> None:  # PathTracer.cs:131-135
+        check(self._lib.pt_set_size(self._h, width, height), self._h)
+        self.Width, self.Height = width, height
+        self.y0, self.rows = 0, height
+
+    def ResetRenderer(self) -> None:  # PathTracer.cs:137-140
+        check(self._lib.pt_reset(self._h), self._h)
+
+    # -- multi-GPU tiling + plumbing (no reference counterpart)
+    def SetTile(self, y0: int, rows: int) -> None:
+        check(self._lib.pt_set_tile(self._h, y0, rows), self._h)
+        self.y0, self.rows = y0, rows
+
+    @property
+    def Result(self) -> np.ndarray:
+        """The RGBA32F `Result` image of this tile, read back to the host: (rows, Width, 4), row 0 = image row y0."""
+        out = np.empty((self.rows, self.Width, 4), dtype=np.float32)
+        check(self._lib.pt_read_result(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), 0), self._h)
+        return out
+
+    def WriteResult(self, image: np.ndarray, frame_index: int) -> None:
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        assert img.shape == (self.rows, self.Width, 4)
+        check(self._lib.pt_write_result(self._h, img.ctypes.data_as(C.POINTER(C.c_float)), 0, frame_index), self._h)
+
+    def Synchronize(self) -> None:
+        check(self._lib.pt_synchronize(self._h), self._h)
+
+    def ResultDevicePtr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(self._lib.pt_result_device_ptr(self._h, C.byref(p), C.byref(n)), self._h)
+        return p.value, n.value
+
+    def BindResultBuffer(self, device_ptr: int | None, nbytes: int = 0) -> None:
+        check(self._lib.pt_bind_result_buffer(self._h, C.c_void_p(device_ptr), nbytes), self._h)
+
+    def SetStream(self, hip_stream: int | None) -> None:
+        check(self._lib.pt_set_stream(self._h, C.c_void_p(hip_stream)), self._h)
+
+    def SetVariant(self, variant: int) -> None:
+        check(self._lib.pt_set_variant(self._h, variant), self._h)
+
+    def TimerBegin(self) -> None:
+        check(self._lib.pt_timer_begin(self._h), self._h)
+
+    def TimerEnd(self) -> float:
+        ms = C.c_float()
+        check(self._lib.pt_timer_end(self._h, C.byref(ms)), self._h)
+        return ms.value
+
+    def ReadEnvironment(self) -> np.ndarray:
+        s = C.c_int()
+        check(self._lib.pt_read_environment(self._h, None, C.byref(s)), self._h)
+        out = np.empty((6, s.value, s.value, 4), dtype=np.float32)
+        check(self._lib.pt_read_environment(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(s)), self._h)
+        return out
+
+    # -- convenience: replay the host's upload sequence for a whole scene + camera
+    def UploadScene(self, scene) -> None:
+        """LoadScene()'s upload loop (MainWindow.cs:265-266): one SubData per object, then the counts."""
+        for obj in scene.objects():
+            d = obj.gpu_data()
+            self.GameObjectsUBO.SubData(obj.buffer_offset, d.nbytes, d)
+        self._numSpheres, self._numCuboids = scene.num_spheres, scene.num_cuboids
+        self._push_params()
+
+    def UploadBasicData(self, blob: bytes) -> None:
+        """The three SubData calls of MainWindow.cs:131-132,279 (InvProjection, InvView, ViewPos)."""
+        self.BasicDataUBO.SubData(0, 64, blob[0:64])
+        self.BasicDataUBO.SubData(64, 64, blob[64:128])
+        self.BasicDataUBO.SubData(128, 16, blob[128:144])
+
+    def Dispose(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.pt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.Dispose()
+        except Exception:
+            pass
+
+
+class AtmosphericScatterer:
+    """AtmosphericScatterer.cs:9-119 — precomputes the sky cube on the GPU of the PathTracer it is attached to."""
+
+    def __init__(self, size: int, atmo_ubo: bytes, light_pos, tracer: PathTracer | None = None):
+        self.Size = size
+        self.ISteps, self.JSteps = 50, 15          # AtmosphericScatterer.cs:92-93
+        self.LightIntensity = 15.0                 # :94
+        self.LightPos = np.asarray(light_pos, dtype=np.float32)  # from Time, :41
+        self._ubo = bytes(atmo_ubo)
+        self._tracer = tracer
+
+    def SetSize(self, size: int) -> None:  # :115-118
+        self.Size = size
+
+    def _select(self, tracer: PathTracer) -> None:
+        self._tracer = tracer
+        self.Render()
+
+    def Render(self) -> None:  # :102-113
+        t = self._tracer
+        if t is None:
+            raise RuntimeError("AtmosphericScatterer is not attached to a PathTracer")
+        buf = np.frombuffer(self._ubo, dtype=np.uint8)
+        check(t._lib.pt_atmosphere_upload_data(t._h, 0, buf.nbytes, buf.ctypes.data_as(C.c_void_p)), t._h)
+        lp = np.ascontiguousarray(self.LightPos, dtype=np.float32)
+        check(t._lib.pt_atmosphere_render(t._h, self.Size, self.ISteps, self.JSteps,
+                                          lp.ctypes.data_as(C.POINTER(C.c_float)), max(self.LightIntensity, 0.0)), t._h)
+
+    @property
+    def Result(self) -> np.ndarray:
+        return self._tracer.ReadEnvironment()
