@@ -638,6 +638,16 @@ PTO_API void pto_sample_env(const void *env, int size, int format, const float *
     rgb_out[0] = o.r; rgb_out[1] = o.g; rgb_out[2] = o.b;
 }
 PTO_API float pto_srgb_to_linear(int v) { return srgb_to_linear(v); }
+PTO_API float pto_pow5(float x) { return f_pow5(x); }
+PTO_API float pto_fresnel_schlick(float cosTheta, float n1, float n2) { return fresnel_schlick(cosTheta, n1, n2); }
+PTO_API void pto_refract(const float *i, const float *n, float eta, float *out)
+{ v3 r = f_refract(V(i[0], i[1], i[2]), V(n[0], n[1], n[2]), eta); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+PTO_API void pto_reflect(const float *i, const float *n, float *out)
+{ v3 r = f_reflect(V(i[0], i[1], i[2]), V(n[0], n[1], n[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+PTO_API void pto_cosine_sample_hemisphere(const float *n, uint32_t *seed, float *out)
+{ v3 r = cosine_sample_hemisphere(V(n[0], n[1], n[2]), seed); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+PTO_API void pto_normalize(const float *v, float *out)
+{ v3 r = v_normalize(V(v[0], v[1], v[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
 
 /* ------------------------------------------------------------------ atmosphere precompute
  * res/shaders/AtmosphericScattering/compute.glsl:30-171 (algorithm credited there to

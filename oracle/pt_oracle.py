@@ -65,6 +65,15 @@ class Oracle:
         L.pto_sample_env.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _fp]
         L.pto_srgb_to_linear.restype = C.c_float
         L.pto_srgb_to_linear.argtypes = [C.c_int]
+        L.pto_pow5.restype = C.c_float
+        L.pto_pow5.argtypes = [C.c_float]
+        L.pto_fresnel_schlick.restype = C.c_float
+        L.pto_fresnel_schlick.argtypes = [C.c_float, C.c_float, C.c_float]
+        L.pto_refract.argtypes = [_fp, _fp, C.c_float, _fp]
+        L.pto_reflect.argtypes = [_fp, _fp, _fp]
+        L.pto_cosine_sample_hemisphere.argtypes = [_fp, C.POINTER(C.c_uint32), _fp]
+        L.pto_normalize.argtypes = [_fp, _fp]
+        L.pto_set_srgb_lut.argtypes = [_fp]
         L.pto_atmosphere.restype = C.c_int
         L.pto_atmosphere.argtypes = [_fp, _fp, C.c_float, C.c_int, C.c_int, C.c_int, _fp, C.c_int]
 
@@ -167,6 +176,46 @@ class Oracle:
         n = np.zeros(3, np.float32)
         self.lib.pto_cuboid_normal(_ptr(mn), _ptr(mx), _ptr(p), _ptr(n))
         return n
+
+    def pow5(self, x):
+        return self.lib.pto_pow5(float(x))
+
+    def fresnel_schlick(self, cos_theta, n1, n2):
+        return self.lib.pto_fresnel_schlick(float(cos_theta), float(n1), float(n2))
+
+    def refract(self, i, n, eta):
+        i, n = (np.ascontiguousarray(a, np.float32) for a in (i, n))
+        out = np.zeros(3, np.float32)
+        self.lib.pto_refract(_ptr(i), _ptr(n), float(eta), _ptr(out))
+        return out
+
+    def reflect(self, i, n):
+        i, n = (np.ascontiguousarray(a, np.float32) for a in (i, n))
+        out = np.zeros(3, np.float32)
+        self.lib.pto_reflect(_ptr(i), _ptr(n), _ptr(out))
+        return out
+
+    def normalize(self, v):
+        v = np.ascontiguousarray(v, np.float32)
+        out = np.zeros(3, np.float32)
+        self.lib.pto_normalize(_ptr(v), _ptr(out))
+        return out
+
+    def cosine_sample_hemisphere(self, n, seed: int):
+        n = np.ascontiguousarray(n, np.float32)
+        out = np.zeros(3, np.float32)
+        s = C.c_uint32(seed)
+        self.lib.pto_cosine_sample_hemisphere(_ptr(n), C.byref(s), _ptr(out))
+        return out, s.value
+
+    def set_srgb_lut(self, lut256=None):
+        """Test-only: override the exact sRGB8 decode table (None restores it)."""
+        if lut256 is None:
+            self.lib.pto_set_srgb_lut(None)
+        else:
+            self._lut = np.ascontiguousarray(lut256, np.float32)
+            assert self._lut.size == 256
+            self.lib.pto_set_srgb_lut(_ptr(self._lut))
 
     def sample_env(self, env_faces, direction):
         env = np.ascontiguousarray(env_faces)

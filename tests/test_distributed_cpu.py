@@ -1,0 +1,67 @@
+"""The N>1 path on CPU: 2 (and 3) processes over gloo run the product's tiling + present() logic
+(opentk-pathtracer_amd/distributed.py).  The tile CONTENT comes from the oracle here (there is no GPU), which is
+allowed: the oracle is only the stand-in renderer of the test; the code under test is the partition + gather."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import configs
+
+torch = pytest.importorskip("torch")
+mp = pytest.importorskip("torch.multiprocessing")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, height, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch as t
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    import configs as cfg
+
+    pkg = graft.load_package()
+    from opentk_pathtracer_amd import distributed as D
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    wl = cfg.Workload("t", "default", 64, height, 5, "sky_f32_32")
+    sc, basic, objs, env, kw = cfg.inputs(wl)
+    oracle = graft.load_oracle().Oracle()
+    y0, rows = D.row_block(height, rank, world)
+    tile = t.zeros((D.max_rows(height, world), wl.width, 4), dtype=t.float32)
+    img = oracle.render(wl.width, wl.height, basic, objs, env, num_frames=2, y0=y0, rows=rows, threads=2, **kw)
+    tile[:rows] = t.from_numpy(img)
+    full = D.present(tile, height, rank, world, dst=0)
+    if rank == 0:
+        np.save(out_path, full.numpy())
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height", [(2, 36), (3, 37)])
+def test_tiled_present_over_gloo(tmp_path, oracle, world, height):
+    out = str(tmp_path / "full.npy")
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, height, out), nprocs=world, join=True)
+    got = np.load(out)
+    wl = configs.Workload("t", "default", 64, height, 5, "sky_f32_32")
+    sc, basic, objs, env, kw = configs.inputs(wl)
+    want = oracle.render(wl.width, wl.height, basic, objs, env, num_frames=2, **kw)
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "tiled+gathered image differs from untiled"
