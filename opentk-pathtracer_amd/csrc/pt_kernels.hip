@@ -198,13 +198,13 @@ PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h)
 {
     float T = FLOAT_MAX, wt2 = 0.0f;
     int winner = -1;
-    for (int i = 0; i < ns; i++) {
-        float4 s = sc.sph[i]; // wave-uniform address: LDS broadcast
-        v3 oc = V(o.x - s.x, o.y - s.y, o.z - s.z);
-        float b = v_dot(d, oc);
-        float c = f_fma(-s.w, s.w, v_dot(oc, oc));
-        float disc = f_fma(b, b, -c);
-        if (!(disc < 0.0f)) {
+    // Sphere pass, 4 spheres per step: the four discriminants are computed branch-free from four broadcast LDS
+    // reads issued together (ILP instead of one exposed LDS latency per sphere); only lanes with a real
+    // forward candidate enter the exact sqrt path, and candidates are accepted strictly in index order.
+    // A sphere entirely behind the origin (c > 0: origin outside, b > 0: pointing away) can never pass `t2 > 0`
+    // (sqrt(b*b - c) <= b when c > 0), so it is rejected before the square root — an exact shortcut.
+    auto candidate = [&](int i, float b, float c, float disc) {
+        if (!(disc < 0.0f) && !(c > 0.0f && b > 1e-10f)) {
             float sq = f_sqrt(disc);
             float t1 = -b - sq, t2 = -b + sq;
             if (t1 <= t2 && t2 > 0.0f && t1 < T) {
@@ -213,6 +213,28 @@ PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h)
                 winner = i;
             }
         }
+    };
+    int i = 0;
+    for (; i + 4 <= ns; i += 4) {
+        float4 s0 = sc.sph[i], s1 = sc.sph[i + 1], s2 = sc.sph[i + 2], s3 = sc.sph[i + 3];
+        float b[4], c[4], disc[4];
+        const float4 sv[4] = {s0, s1, s2, s3};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v3 oc = V(o.x - sv[k].x, o.y - sv[k].y, o.z - sv[k].z);
+            b[k] = v_dot(d, oc);
+            c[k] = f_fma(-sv[k].w, sv[k].w, v_dot(oc, oc));
+            disc[k] = f_fma(b[k], b[k], -c[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) candidate(i + k, b[k], c[k], disc[k]); // one wave-level branch per sphere
+    }
+    for (; i < ns; i++) {
+        float4 s = sc.sph[i];
+        v3 oc = V(o.x - s.x, o.y - s.y, o.z - s.z);
+        float b = v_dot(d, oc);
+        float c = f_fma(-s.w, s.w, v_dot(oc, oc));
+        candidate(i, b, c, f_fma(b, b, -c));
     }
     v3 invd = V(f_rcp(d.x), f_rcp(d.y), f_rcp(d.z)); // slab test by reciprocal (pt-f32 contract)
     for (int i = 0; i < nc; i++) {
@@ -310,34 +332,41 @@ PT_DEV float bsdf(v3 &ro, v3 &rd, const Hit &h, bool &isRefractive, uint32_t &se
     return f_max(prob, EPSILON);
 }
 
+// One iteration of Radiance's bounce loop (compute.glsl:140-180) for one path.  Returns true when the path
+// continues (hit, survived Russian roulette), false when it ended (miss -> environment, or roulette kill).
+PT_DEV bool bounce_step(const SceneLds &sc, int ns, int nc, const EnvRef &env, v3 &ro, v3 &rd, v3 &throughput, v3 &rad,
+                        uint32_t &seed)
+{
+    Hit h;
+    if (ray_trace(sc, ns, nc, ro, rd, h)) {
+        if (h.fromInside) { // Beer's law, compute.glsl:145-149
+            h.normal = v_neg(h.normal);
+            throughput.x *= pt_exp(-h.m.absorbance.x * h.T);
+            throughput.y *= pt_exp(-h.m.absorbance.y * h.T);
+            throughput.z *= pt_exp(-h.m.absorbance.z * h.T);
+        }
+        bool isRefractive;
+        float prob = bsdf(ro, rd, h, isRefractive, seed);
+        rad = V(f_fma(h.m.emissiv.x, throughput.x, rad.x), f_fma(h.m.emissiv.y, throughput.y, rad.y),
+                f_fma(h.m.emissiv.z, throughput.z, rad.z));
+        if (!isRefractive) throughput = v_mul(throughput, h.m.albedo);
+        throughput = V(throughput.x / prob, throughput.y / prob, throughput.z / prob);
+        float p = f_max(throughput.x, f_max(throughput.y, throughput.z)); // Russian roulette, :167-173
+        if (rand01(seed) > p) return false;
+        throughput = V(throughput.x / p, throughput.y / p, throughput.z / p);
+        return true;
+    }
+    v3 e = sample_env(env, rd); // compute.glsl:177
+    rad = V(f_fma(e.x, throughput.x, rad.x), f_fma(e.y, throughput.y, rad.y), f_fma(e.z, throughput.z, rad.z));
+    return false;
+}
+
 // compute.glsl:132-182 Radiance
 PT_DEV v3 radiance(const FrameArgs &a, const SceneLds &sc, const EnvRef &env, v3 ro, v3 rd, uint32_t &seed)
 {
     v3 throughput = V(1.0f, 1.0f, 1.0f), rad = V(0.0f, 0.0f, 0.0f);
-    Hit h;
-    for (int i = 0; i < a.rayDepth; i++) {
-        if (ray_trace(sc, a.numSpheres, a.numCuboids, ro, rd, h)) {
-            if (h.fromInside) { // Beer's law, compute.glsl:145-149
-                h.normal = v_neg(h.normal);
-                throughput.x *= pt_exp(-h.m.absorbance.x * h.T);
-                throughput.y *= pt_exp(-h.m.absorbance.y * h.T);
-                throughput.z *= pt_exp(-h.m.absorbance.z * h.T);
-            }
-            bool isRefractive;
-            float prob = bsdf(ro, rd, h, isRefractive, seed);
-            rad = V(f_fma(h.m.emissiv.x, throughput.x, rad.x), f_fma(h.m.emissiv.y, throughput.y, rad.y),
-                    f_fma(h.m.emissiv.z, throughput.z, rad.z));
-            if (!isRefractive) throughput = v_mul(throughput, h.m.albedo);
-            throughput = V(throughput.x / prob, throughput.y / prob, throughput.z / prob);
-            float p = f_max(throughput.x, f_max(throughput.y, throughput.z)); // Russian roulette, :167-173
-            if (rand01(seed) > p) break;
-            throughput = V(throughput.x / p, throughput.y / p, throughput.z / p);
-        } else {
-            v3 e = sample_env(env, rd); // compute.glsl:177
-            rad = V(f_fma(e.x, throughput.x, rad.x), f_fma(e.y, throughput.y, rad.y), f_fma(e.z, throughput.z, rad.z));
-            break;
-        }
-    }
+    for (int i = 0; i < a.rayDepth; i++)
+        if (!bounce_step(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed)) break;
     return rad;
 }
 
@@ -348,43 +377,64 @@ PT_DEV void mat_vec(const float *m, float x, float y, float z, float w, float *o
     for (int r = 0; r < 4; r++) out[r] = f_fma(m[12 + r], w, f_fma(m[8 + r], z, f_fma(m[4 + r], y, m[r] * x)));
 }
 
+// compute.glsl:113-121: sub-pixel jitter, GetWorldSpaceRay (:352-357), thin lens (UniformSampleUnitCircle :309-314).
+// Consumes 4 RNG draws.
+PT_DEV void primary_ray(const FrameArgs &a, int px, int py, uint32_t &seed, v3 &ro, v3 &rd)
+{
+    v3 viewPos = V(a.viewPos[0], a.viewPos[1], a.viewPos[2]);
+    float u0 = rand01(seed), u1 = rand01(seed); // :113
+    float ndcx = f_fma(((float)px + u0) / (float)a.width, 2.0f, -1.0f);
+    float ndcy = f_fma(((float)py + u1) / (float)a.height, 2.0f, -1.0f);
+    float eye[4], wd[4];
+    mat_vec(a.invProj, ndcx, ndcy, -1.0f, 0.0f, eye);
+    mat_vec(a.invView, eye[0], eye[1], -1.0f, 0.0f, wd);
+    v3 dir = v_normalize(V(wd[0], wd[1], wd[2]));
+    v3 focal = v_fma(dir, a.focalLength, viewPos); // :117
+    float angle = rand01(seed) * 2.0f * PI;
+    float rr = f_sqrt(rand01(seed));
+    float sn, cs;
+    pt_sincos(angle, sn, cs);
+    float half_ap = a.apertureDiameter * 0.5f;
+    float ox = half_ap * (cs * rr), oy = half_ap * (sn * rr);
+    float org[4];
+    mat_vec(a.invView, ox, oy, 0.0f, 1.0f, org); // :120
+    ro = V(org[0], org[1], org[2]);
+    rd = v_normalize(v_sub(focal, ro));
+}
+
+PT_DEV uint32_t pixel_seed(int px, int py, int frame)
+{
+    return ((uint32_t)px * 1973u + (uint32_t)py * 9277u + (uint32_t)frame * 2699u) | 1u; // compute.glsl:106
+}
+
+// compute.glsl:125-129: irradiance /= SPP; running mean with the previous accumulation value; alpha = 1
+PT_DEV float4 resolve_pixel(const FrameArgs &a, v3 irr, float4 last)
+{
+    float fspp = (float)a.spp;
+    irr = V(irr.x / fspp, irr.y / fspp, irr.z / fspp);
+    float w = 1.0f / (float)(a.frame + 1);
+    return make_float4(f_mix(last.x, irr.x, w), f_mix(last.y, irr.y, w), f_mix(last.z, irr.z, w), 1.0f);
+}
+
 // compute.glsl:101-130 main for one pixel: returns the new accumulation value
 PT_DEV float4 shade_pixel(const FrameArgs &a, const SceneLds &sc, const EnvRef &env, int px, int py, float4 last)
 {
-    uint32_t seed = ((uint32_t)px * 1973u + (uint32_t)py * 9277u + (uint32_t)a.frame * 2699u) | 1u; // :106
+    uint32_t seed = pixel_seed(px, py, a.frame);
     v3 irr = V(0.0f, 0.0f, 0.0f);
-    v3 viewPos = V(a.viewPos[0], a.viewPos[1], a.viewPos[2]);
     for (int s = 0; s < a.spp; s++) {
-        float u0 = rand01(seed), u1 = rand01(seed); // :113
-        float ndcx = f_fma(((float)px + u0) / (float)a.width, 2.0f, -1.0f);
-        float ndcy = f_fma(((float)py + u1) / (float)a.height, 2.0f, -1.0f);
-        float eye[4], wd[4]; // GetWorldSpaceRay :352-357
-        mat_vec(a.invProj, ndcx, ndcy, -1.0f, 0.0f, eye);
-        mat_vec(a.invView, eye[0], eye[1], -1.0f, 0.0f, wd);
-        v3 dir = v_normalize(V(wd[0], wd[1], wd[2]));
-        v3 focal = v_fma(dir, a.focalLength, viewPos); // :117
-        float angle = rand01(seed) * 2.0f * PI;        // UniformSampleUnitCircle :309-314
-        float rr = f_sqrt(rand01(seed));
-        float sn, cs;
-        pt_sincos(angle, sn, cs);
-        float half_ap = a.apertureDiameter * 0.5f;
-        float ox = half_ap * (cs * rr), oy = half_ap * (sn * rr);
-        float org[4];
-        mat_vec(a.invView, ox, oy, 0.0f, 1.0f, org); // :120
-        v3 ro = V(org[0], org[1], org[2]);
-        v3 rd = v_normalize(v_sub(focal, ro));
+        v3 ro, rd;
+        primary_ray(a, px, py, seed, ro, rd);
         irr = v_add(irr, radiance(a, sc, env, ro, rd, seed));
     }
-    float fspp = (float)a.spp;
-    irr = V(irr.x / fspp, irr.y / fspp, irr.z / fspp); // :125
-    float w = 1.0f / (float)(a.frame + 1);             // :128
-    return make_float4(f_mix(last.x, irr.x, w), f_mix(last.y, irr.y, w), f_mix(last.z, irr.z, w), 1.0f);
+    return resolve_pixel(a, irr, last);
 }
 
 // ---------------------------------------------------------------------------------------------- kernels
 extern __shared__ float4 g_lds[];
 
-__global__ __launch_bounds__(256) void pt_integrate_kernel(const FrameArgs a)
+// Stage + re-pack the scene into LDS (all 256 threads): std140 Sphere = 5 x float4 (geometry, 4 x material),
+// Cuboid = 6 x float4.  Ends with a workgroup barrier.
+PT_DEV SceneLds stage_scene(const FrameArgs &a)
 {
     const int ns = a.numSpheres, nc = a.numCuboids;
     float4 *sph = g_lds;
@@ -393,8 +443,6 @@ __global__ __launch_bounds__(256) void pt_integrate_kernel(const FrameArgs a)
     float4 *mat = cmax + nc;
     float *lut = (float *)(mat + 4 * (ns + nc));
     const int tid = threadIdx.x;
-
-    // ---- stage + re-pack the scene: std140 Sphere = 5 x float4 (geometry, 4 x material), Cuboid = 6 x float4
     const float4 *obj = (const float4 *)a.objects;
     for (int i = tid; i < ns * 5; i += 256) {
         int s = i / 5, part = i - s * 5;
@@ -411,17 +459,24 @@ __global__ __launch_bounds__(256) void pt_integrate_kernel(const FrameArgs a)
     }
     if (a.envFormat == 1) lut[tid] = a.srgbLut[tid];
     __syncthreads();
+    return SceneLds{sph, cmin, cmax, mat, lut};
+}
 
-    SceneLds sc{sph, cmin, cmax, mat, lut};
-    EnvRef env{a.env, lut, a.envSize, a.envFormat};
+// XCD-aware workgroup id: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, so id b is
+// remapped to a contiguous band of work per XCD (the tail nwg & 7 keeps its identity mapping).
+PT_DEV int xcd_band_id(int b, int nwg)
+{
+    int per = nwg >> 3;
+    return b < per * 8 ? (b & 7) * per + (b >> 3) : b;
+}
 
-    // ---- XCD-aware workgroup -> tile-quad mapping (workgroup b runs on XCD b % 8)
-    const int nwg = gridDim.x;
-    int b = blockIdx.x;
-    {
-        int per = nwg >> 3; // workgroups per XCD band (the tail nwg & 7 keeps its identity mapping)
-        if (b < per * 8) b = (b & 7) * per + (b >> 3);
-    }
+// ---- variant 0: one wavefront = one 8x8 tile, one pixel per lane, the wave runs until its longest path ends
+__global__ __launch_bounds__(256) void pt_integrate_kernel(const FrameArgs a)
+{
+    SceneLds sc = stage_scene(a);
+    EnvRef env{a.env, sc.lut, a.envSize, a.envFormat};
+    const int tid = threadIdx.x;
+    const int b = xcd_band_id(blockIdx.x, gridDim.x);
     const int wave = tid >> 6, lane = tid & 63;
     const int tile = b * 4 + wave;
     if (tile >= a.tilesX * a.tilesY) return;
@@ -430,16 +485,119 @@ __global__ __launch_bounds__(256) void pt_integrate_kernel(const FrameArgs a)
     const int ly = ty * 8 + (lane >> 3); // row inside this GPU's row block
     if (px >= a.width || ly >= a.rows) return;
     const size_t idx = (size_t)ly * a.width + px;
-    float4 last = a.accum[idx];                                // imageLoad  (compute.glsl:126)
+    float4 last = a.accum[idx];                                  // imageLoad  (compute.glsl:126)
     a.accum[idx] = shade_pixel(a, sc, env, px, a.y0 + ly, last); // imageStore (compute.glsl:129)
+}
+
+// ---- variant >= 1: wave-level pixel pool with path regeneration.
+// Russian roulette and environment misses end paths after very different numbers of bounces (mean 2.7 of 8 in the
+// default scene), so a wave that keeps one pixel per lane idles most lanes most of the time.  Here a wavefront
+// owns a pool of POOL consecutive 8x8 tiles; whenever a lane's pixel is finished it takes the next pixel of the
+// pool (ballot + prefix count, no atomics), so the traversal loops run with (almost) all 64 lanes busy.  Every
+// pixel still owns its RNG stream (seeded by its global coordinate, compute.glsl:106) and the samples of a pixel
+// stay on one lane in order, so the image is bit-identical to variant 0.
+__global__ __launch_bounds__(256) void pt_integrate_pool_kernel(const FrameArgs a, const int poolTiles)
+{
+    SceneLds sc = stage_scene(a);
+    EnvRef env{a.env, sc.lut, a.envSize, a.envFormat};
+    const int tid = threadIdx.x;
+    const int b = xcd_band_id(blockIdx.x, gridDim.x);
+    const int wave = tid >> 6;
+    const int numTiles = a.tilesX * a.tilesY;
+    const int pool = b * 4 + wave;
+    int next = pool * poolTiles * 64;                               // wave-uniform cursor into the pool
+    int tileEnd = (pool + 1) * poolTiles;
+    const int poolEnd = (tileEnd < numTiles ? tileEnd : numTiles) * 64;
+    if (next >= poolEnd) return;
+
+    // per-lane path state
+    int pix = -1;           // linear index into accum, -1 = lane has no pixel
+    int px = 0, py = 0, sample = 0, bounce = 0;
+    bool needRay = false;
+    uint32_t seed = 0;
+    v3 ro = V(0, 0, 0), rd = V(0, 0, 1), throughput = V(1, 1, 1), rad = V(0, 0, 0), irr = V(0, 0, 0);
+
+    for (;;) {
+        // ---- refill idle lanes from the pool
+        bool idle = pix < 0;
+        unsigned long long m = __ballot(idle);
+        if (m != 0ull && next < poolEnd) {
+            int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            int cand = next + rank;
+            if (idle && cand < poolEnd) {
+                int tile = cand >> 6, q = cand & 63;
+                int tx = tile % a.tilesX, ty = tile / a.tilesX;
+                int x = tx * 8 + (q & 7), ly = ty * 8 + (q >> 3);
+                if (x < a.width && ly < a.rows) { // ragged right/bottom tiles: skip the pixel, stay idle
+                    px = x;
+                    py = a.y0 + ly;
+                    pix = ly * a.width + x;
+                    seed = pixel_seed(px, py, a.frame);
+                    sample = 0;
+                    irr = V(0.0f, 0.0f, 0.0f);
+                    needRay = true;
+                }
+            }
+            next += __builtin_popcountll(m);
+        }
+        bool active = pix >= 0;
+        if (!__any(active)) {
+            if (next >= poolEnd) break;
+            continue;
+        }
+        // ---- (re)generate the primary ray of the lane's current sample
+        if (active && needRay) {
+            primary_ray(a, px, py, seed, ro, rd);
+            throughput = V(1.0f, 1.0f, 1.0f);
+            rad = V(0.0f, 0.0f, 0.0f);
+            bounce = 0;
+            needRay = false;
+        }
+        // ---- one bounce for every active lane
+        if (active) {
+            bool cont = false;
+            if (bounce < a.rayDepth) cont = bounce_step(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed);
+            bounce++;
+            if (!cont || bounce >= a.rayDepth) {
+                irr = v_add(irr, rad);
+                sample++;
+                if (sample < a.spp) {
+                    needRay = true;
+                } else {
+                    float4 last = a.accum[pix];
+                    a.accum[pix] = resolve_pixel(a, irr, last);
+                    pix = -1;
+                }
+            }
+        }
+    }
+}
+
+static int pool_tiles_for_variant(int variant)
+{
+    switch (variant) {
+    case 1: return 8;
+    case 2: return 4;
+    case 3: return 16;
+    case 4: return 32;
+    case 5: return 2;
+    default: return 8;
+    }
 }
 
 hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream)
 {
     int tiles = a.tilesX * a.tilesY;
-    int nwg = (tiles + 3) / 4;
     size_t lds = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat);
-    hipLaunchKernelGGL(pt_integrate_kernel, dim3(nwg), dim3(256), lds, stream, a);
+    if (a.variant == 0) {
+        int nwg = (tiles + 3) / 4;
+        hipLaunchKernelGGL(pt_integrate_kernel, dim3(nwg), dim3(256), lds, stream, a);
+    } else {
+        int poolTiles = pool_tiles_for_variant(a.variant);
+        int pools = (tiles + poolTiles - 1) / poolTiles;
+        int nwg = (pools + 3) / 4;
+        hipLaunchKernelGGL(pt_integrate_pool_kernel, dim3(nwg), dim3(256), lds, stream, a, poolTiles);
+    }
     return hipGetLastError();
 }
 

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(HERE, "libmi355pt.so")
 HEADER = os.path.join(REPO, "include", "mi355pt.h")
 SOURCES = ["pt_kernels.hip", "mi355pt.cpp"]
 # -ffp-contract=off / -fno-fast-math are part of the pt-f32 arithmetic contract (csrc/pt_math.hpp)
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared",
                "-fvisibility=hidden"]
 
 PT_OK = 0

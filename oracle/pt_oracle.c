@@ -611,6 +611,23 @@ PTO_API int pto_render_pixels(const PtoParams *p, const float *basic144, const f
     return 0;
 }
 
+/* Per-pixel bounce counts of one frame (diagnostics for the divergence study in DESIGN.md): counts[y*W+x] = number
+ * of RayTrace calls the pixel's samples made. */
+PTO_API int pto_bounce_counts(const PtoParams *p, const float *basic144, const float *objects26624, const void *env,
+                              int frame, int *counts)
+{
+    Ctx c;
+    make_ctx(&c, p, basic144, objects26624, env);
+    float last[4] = { 0, 0, 0, 0 }, out[4];
+    for (int y = 0; y < c.height; y++)
+        for (int x = 0; x < c.width; x++) {
+            Stats st = { 0, 0, 0, 0, 0, 0 };
+            shade_pixel(&c, x, y, frame, last, out, &st);
+            counts[(size_t)y * c.width + x] = (int)st.bounces;
+        }
+    return 0;
+}
+
 /* ---- micro entry points for unit tests ---- */
 PTO_API uint32_t pto_pcg_hash(uint32_t *seed) { return pcg_hash(seed); }
 PTO_API float pto_rand01(uint32_t *seed) { return rand01(seed); }
