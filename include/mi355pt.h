@@ -142,7 +142,9 @@ PT_API int pt_set_stream(pt_handle h, void *hip_stream);
 /* hipEvent pair recorded on the handle's stream: elapsed GPU milliseconds between begin and end. */
 PT_API int pt_timer_begin(pt_handle h);
 PT_API int pt_timer_end(pt_handle h, float *out_milliseconds);
-/* Kernel variant selector for A/B measurements (0 = default); all variants produce bit-identical images. */
+/* Kernel variant selector for A/B measurements; all variants produce bit-identical images.
+ * 0 = default (persistent queue kernel), 1 = one wavefront per 8x8 tile, 2..6 = wave-local pools, 10+k = persistent
+ * kernel with k+1 workgroups per CU. */
 PT_API int pt_set_variant(pt_handle h, int variant);
 
 PT_API const char *pt_last_error(pt_handle h);

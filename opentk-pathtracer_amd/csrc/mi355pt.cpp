@@ -42,6 +42,8 @@ struct pt_renderer {
 
     float *dObjects = nullptr; // 26,624 B device copy of UBO 1
     float *dLut = nullptr;     // 256-entry sRGB table
+    unsigned int *dQueue = nullptr; // 8 per-XCD work counters of the persistent-queue kernel
+    int numCUs = 256;
     void *dEnv = nullptr;      // current environment cube
     size_t envBytes = 0;
     int envSize = 0, envFormat = PT_ENV_RGBA32F;
@@ -175,6 +177,12 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     PT_CREATE_HIP(hipMalloc((void **)&h->dObjects, PT_GAME_OBJECTS_UBO_SIZE));
     PT_CREATE_HIP(hipMemsetAsync(h->dObjects, 0, PT_GAME_OBJECTS_UBO_SIZE, h->stream));
     PT_CREATE_HIP(hipMalloc((void **)&h->dLut, 256 * sizeof(float)));
+    PT_CREATE_HIP(hipMalloc((void **)&h->dQueue, 64 * sizeof(unsigned int)));
+    {
+        hipDeviceProp_t prop;
+        PT_CREATE_HIP(hipGetDeviceProperties(&prop, device_id));
+        h->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     float lut[256];
     make_srgb_lut(lut);
     PT_CREATE_HIP(hipMemcpyAsync(h->dLut, lut, sizeof lut, hipMemcpyHostToDevice, h->stream));
@@ -198,6 +206,7 @@ PT_API int pt_destroy(pt_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->dObjects) (void)hipFree(h->dObjects);
     if (h->dLut) (void)hipFree(h->dLut);
+    if (h->dQueue) (void)hipFree(h->dQueue);
     if (h->dEnv) (void)hipFree(h->dEnv);
     if (h->dAccum) (void)hipFree(h->dAccum);
     if (h->evBegin) (void)hipEventDestroy(h->evBegin);
@@ -337,6 +346,9 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     a.tilesX = (h->width + 7) / 8;
     a.tilesY = (h->rows + 7) / 8;
     a.variant = h->variant;
+    a.queue = h->dQueue;
+    a.numCUs = h->numCUs;
+    if (h->variant == 0 || h->variant >= 10) PT_HIP(h, hipMemsetAsync(h->dQueue, 0, 64 * sizeof(unsigned int), h->stream));
     PT_HIP(h, pt::launch_integrate(a, h->stream));
     h->frame++; // PathTracer.cs:117 post-increment
     if (out_total_samples) *out_total_samples = h->frame * h->spp; // PathTracer.cs:112

@@ -470,7 +470,7 @@ PT_DEV int xcd_band_id(int b, int nwg)
     return b < per * 8 ? (b & 7) * per + (b >> 3) : b;
 }
 
-// ---- variant 0: one wavefront = one 8x8 tile, one pixel per lane, the wave runs until its longest path ends
+// ---- variant 1: one wavefront = one 8x8 tile, one pixel per lane, the wave runs until its longest path ends
 __global__ __launch_bounds__(256) void pt_integrate_kernel(const FrameArgs a)
 {
     SceneLds sc = stage_scene(a);
@@ -489,13 +489,13 @@ __global__ __launch_bounds__(256) void pt_integrate_kernel(const FrameArgs a)
     a.accum[idx] = shade_pixel(a, sc, env, px, a.y0 + ly, last); // imageStore (compute.glsl:129)
 }
 
-// ---- variant >= 1: wave-level pixel pool with path regeneration.
+// ---- variants 2..6: wave-level pixel pool with path regeneration.
 // Russian roulette and environment misses end paths after very different numbers of bounces (mean 2.7 of 8 in the
 // default scene), so a wave that keeps one pixel per lane idles most lanes most of the time.  Here a wavefront
 // owns a pool of POOL consecutive 8x8 tiles; whenever a lane's pixel is finished it takes the next pixel of the
 // pool (ballot + prefix count, no atomics), so the traversal loops run with (almost) all 64 lanes busy.  Every
 // pixel still owns its RNG stream (seeded by its global coordinate, compute.glsl:106) and the samples of a pixel
-// stay on one lane in order, so the image is bit-identical to variant 0.
+// stay on one lane in order, so the image is bit-identical to variant 1.
 __global__ __launch_bounds__(256) void pt_integrate_pool_kernel(const FrameArgs a, const int poolTiles)
 {
     SceneLds sc = stage_scene(a);
@@ -573,14 +573,149 @@ __global__ __launch_bounds__(256) void pt_integrate_pool_kernel(const FrameArgs 
     }
 }
 
+// ---- variant 0 (default) and >= 10: persistent wavefronts + global tile queue + LDS ring of primary rays.
+// The grid is sized to the machine (blocksPerCU x CUs), not to the image.  Each wavefront repeatedly
+//   1. takes an 8x8 tile from a global queue (8 counters, one per XCD; counter x hands out tiles x, x+8, x+16, ...;
+//      one returning atomic per 64 pixels, issued one tile ahead so its latency is hidden),
+//   2. generates the tile's 64 primary rays with ALL lanes (camera code at full utilisation) into a per-wave LDS
+//      ring (pixel, RNG state after the 4 camera draws, origin, direction),
+//   3. runs bounce iterations in which every lane whose path ended pops the next ray of the ring.
+// So the traversal loops always run (nearly) full, the camera code is never executed divergently (for spp = 1),
+// and the only tail is the drain at the very end of the frame.  Pixels keep their own RNG streams -> bit-identical.
+struct RingEntry { // 40 bytes
+    int pix;       // linear index into accum, -1 = pixel outside the image (ragged tile)
+    int pxy;       // px | py << 16 (global coordinates)
+    uint32_t seed; // RNG state after the primary-ray draws
+    float ox, oy, oz, dx, dy, dz;
+    int pad;
+};
+
+PT_DEV unsigned int queue_pop(unsigned int *counter)
+{
+    unsigned int v = 0;
+    if ((threadIdx.x & 63) == 0) v = atomicAdd(counter, 1u);
+    return (unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+__global__ __launch_bounds__(256) void pt_integrate_persistent_kernel(const FrameArgs a)
+{
+    SceneLds sc = stage_scene(a);
+    EnvRef env{a.env, sc.lut, a.envSize, a.envFormat};
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int numTiles = a.tilesX * a.tilesY;
+    // the ring lives behind the staged scene in dynamic LDS
+    RingEntry *ring = (RingEntry *)((char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat)) + wave * 64;
+    const int xcd = blockIdx.x & 7; // dispatcher deals workgroups round-robin over the XCDs (speed only)
+    unsigned int *counter = a.queue + xcd * 8;
+
+    int avail = 0;                              // wave-uniform: ring entries [0, avail) are unconsumed
+    unsigned int ticket = queue_pop(counter);   // tile ticket fetched one step ahead
+    bool exhausted = false;
+
+    int pix = -1, px = 0, py = 0, sample = 0, bounce = 0;
+    bool needRay = false;
+    uint32_t seed = 0;
+    v3 ro = V(0, 0, 0), rd = V(0, 0, 1), throughput = V(1, 1, 1), rad = V(0, 0, 0), irr = V(0, 0, 0);
+
+    for (;;) {
+        bool idle = pix < 0;
+        unsigned long long m = __ballot(idle);
+        if (m != 0ull) {
+            if (avail == 0 && !exhausted) {
+                // ---- refill the ring: one tile, every lane generates one primary ray
+                long long tile = (long long)ticket * 8 + xcd;
+                if (tile >= numTiles) {
+                    exhausted = true;
+                } else {
+                    ticket = queue_pop(counter); // prefetch the next ticket; consumed at the next refill
+                    int tx = (int)(tile % a.tilesX), ty = (int)(tile / a.tilesX);
+                    int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+                    RingEntry e;
+                    e.pix = -1;
+                    e.pxy = 0; e.seed = 0; e.ox = e.oy = e.oz = e.dx = e.dy = e.dz = 0.0f; e.pad = 0;
+                    if (x < a.width && ly < a.rows) {
+                        int gy = a.y0 + ly;
+                        uint32_t sd = pixel_seed(x, gy, a.frame);
+                        v3 o, d;
+                        primary_ray(a, x, gy, sd, o, d);
+                        e.pix = ly * a.width + x;
+                        e.pxy = x | (gy << 16);
+                        e.seed = sd;
+                        e.ox = o.x; e.oy = o.y; e.oz = o.z; e.dx = d.x; e.dy = d.y; e.dz = d.z;
+                    }
+                    ring[lane] = e;
+                    __builtin_amdgcn_wave_barrier(); // ring entries are read by other lanes of this wave below
+                    avail = 64;
+                }
+            }
+            if (avail > 0) {
+                // ---- idle lanes pop ring entries (top down); a popped out-of-image entry leaves the lane idle
+                int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (idle && rank < avail) {
+                    RingEntry e = ring[avail - 1 - rank];
+                    if (e.pix >= 0) {
+                        pix = e.pix;
+                        px = e.pxy & 0xffff;
+                        py = e.pxy >> 16;
+                        seed = e.seed;
+                        ro = V(e.ox, e.oy, e.oz);
+                        rd = V(e.dx, e.dy, e.dz);
+                        throughput = V(1.0f, 1.0f, 1.0f);
+                        rad = V(0.0f, 0.0f, 0.0f);
+                        irr = V(0.0f, 0.0f, 0.0f);
+                        sample = 0;
+                        bounce = 0;
+                        needRay = false;
+                    }
+                }
+                int n = __builtin_popcountll(m);
+                avail = n < avail ? avail - n : 0;
+            }
+        }
+        bool active = pix >= 0;
+        if (!__any(active)) {
+            if (exhausted && avail == 0) break;
+            continue;
+        }
+        if (active && needRay) { // only for spp > 1: the next sample continues the pixel's RNG stream (compute.glsl:110)
+            primary_ray(a, px, py, seed, ro, rd);
+            throughput = V(1.0f, 1.0f, 1.0f);
+            rad = V(0.0f, 0.0f, 0.0f);
+            bounce = 0;
+            needRay = false;
+        }
+        if (active) {
+            bool cont = false;
+            if (bounce < a.rayDepth) cont = bounce_step(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed);
+            bounce++;
+            if (!cont || bounce >= a.rayDepth) {
+                irr = v_add(irr, rad);
+                sample++;
+                if (sample < a.spp) {
+                    needRay = true;
+                } else {
+                    float4 last = a.accum[pix];
+                    a.accum[pix] = resolve_pixel(a, irr, last);
+                    pix = -1;
+                }
+            }
+        }
+    }
+}
+
+// Kernel variants (pt_set_variant; every variant produces the same bits):
+//   0        default = persistent queue kernel, 4 workgroups per CU
+//   1        one wavefront per 8x8 tile, one pixel per lane (the reference's own mapping; simplest kernel)
+//   2..6     wave-local pixel pools of 8 / 4 / 16 / 32 / 2 tiles with path regeneration
+//   10 + k   persistent queue kernel with k + 1 workgroups per CU
 static int pool_tiles_for_variant(int variant)
 {
     switch (variant) {
-    case 1: return 8;
-    case 2: return 4;
-    case 3: return 16;
-    case 4: return 32;
-    case 5: return 2;
+    case 2: return 8;
+    case 3: return 4;
+    case 4: return 16;
+    case 5: return 32;
+    case 6: return 2;
     default: return 8;
     }
 }
@@ -589,9 +724,17 @@ hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream)
 {
     int tiles = a.tilesX * a.tilesY;
     size_t lds = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat);
-    if (a.variant == 0) {
+    if (a.variant == 1) {
         int nwg = (tiles + 3) / 4;
         hipLaunchKernelGGL(pt_integrate_kernel, dim3(nwg), dim3(256), lds, stream, a);
+    } else if (a.variant == 0 || a.variant >= 10) {
+        int blocksPerCU = a.variant == 0 ? 4 : a.variant - 9;
+        int nwg = a.numCUs * blocksPerCU;
+        int maxUseful = (tiles + 3) / 4;
+        if (nwg > maxUseful) nwg = maxUseful;
+        nwg = (nwg + 7) & ~7; // a multiple of 8 so every XCD counter has the same number of consumers
+        size_t ldsTotal = lds + 4 * 64 * sizeof(RingEntry);
+        hipLaunchKernelGGL(pt_integrate_persistent_kernel, dim3(nwg), dim3(256), ldsTotal, stream, a);
     } else {
         int poolTiles = pool_tiles_for_variant(a.variant);
         int pools = (tiles + poolTiles - 1) / poolTiles;

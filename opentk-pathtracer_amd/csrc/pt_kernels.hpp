@@ -25,6 +25,8 @@ struct FrameArgs {
     float4 *accum;          // rows x width RGBA32F accumulation image (row 0 = image row y0)
     int tilesX, tilesY;     // 8x8-pixel tiles covering width x rows
     int variant;            // kernel variant for A/B runs; all variants are bit-identical in output
+    unsigned int *queue;    // 8 per-XCD tile counters (persistent-queue variants); zeroed before every launch
+    int numCUs;             // compute units of the device (grid sizing of persistent variants)
 };
 
 struct AtmoArgs {

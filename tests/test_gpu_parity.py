@@ -55,6 +55,15 @@ def test_hip_equals_oracle_bit_exact(pkg, native_lib, oracle, w):
     assert_bit_exact(hip_render(pkg, w), oracle_render(oracle, w), w.name)
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3, 6, 10, 12], ids=lambda v: f"variant{v}")
+@pytest.mark.parametrize("w", [configs.SMALL_FRAMES[1], configs.SMALL_FRAMES[4], configs.SMALL_FRAMES[8],
+                               configs.SMALL_FRAMES[9]], ids=lambda w: w.name)
+def test_every_kernel_variant_is_bit_exact(pkg, native_lib, oracle, w, variant):
+    """The tile-per-wave kernel, the wave-pool kernels and the persistent-queue kernel (pt_set_variant) all produce
+    the oracle's bits: path regeneration re-orders work across lanes, never the arithmetic of a pixel."""
+    assert_bit_exact(hip_render(pkg, w, variant=variant), oracle_render(oracle, w), f"{w.name} variant {variant}")
+
+
 @pytest.mark.parametrize("w", [
     configs.Workload("one_pixel", "default", 1, 1, 8, "sky_f32_32"),
     configs.Workload("one_row", "default", 77, 1, 8, "sky_f32_32"),
