@@ -1,0 +1,62 @@
+// pt_host_demo — replays the reference host's start-up and frame loop over the C ABI, in C++:
+//   MainWindow.OnLoad  (src/MainWindow.cs:146-206): AtmosphericScatterer(256).Render() -> PathTracer(env = atmosphere,
+//                      W, H, rayDepth 13, spp 1, focalLength 20, aperture 0.14) -> UBOs -> LoadScene()
+//   OnResize / OnUpdateFrame camera uploads (:131-132,278-279), then N x PathTracer.Render() (:49)
+// and writes the RGBA32F `Result` (raw floats, row 0 = bottom) so it can be compared with the oracle.
+//
+//   pt_host_demo render <W> <H> <frames> <out.f32> [rayDepth] [atmosphereSize]
+//   pt_host_demo dump-scene <out.bin>            (no GPU needed: the 26,624-byte GameObjectsUBO image)
+//   pt_host_demo dump-camera <W> <H> <out.bin>   (no GPU needed: the 144-byte BasicDataUBO image)
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "pt_host.hpp"
+
+using namespace opentk_pathtracer;
+
+static void write_file(const char *path, const void *data, size_t n)
+{
+    FILE *f = std::fopen(path, "wb");
+    if (!f || std::fwrite(data, 1, n, f) != n) { std::perror(path); std::exit(2); }
+    std::fclose(f);
+}
+
+int main(int argc, char **argv)
+{
+    try {
+        std::string mode = argc > 1 ? argv[1] : "";
+        Camera camera(Vector3(-17.14f, 3.53f, -8.62f), Vector3(0, 1, 0), -32.2f, 0.8f); // MainWindow.cs:36
+        if (mode == "dump-scene" && argc == 3) {
+            Scene sc = BuildDefaultScene();
+            auto blob = GameObjectsUboImage(sc);
+            write_file(argv[2], blob.data(), blob.size());
+            std::printf("%d spheres, %d cuboids\n", sc.NumSpheres, sc.NumCuboids);
+            return 0;
+        }
+        if (mode == "dump-camera" && argc == 5) {
+            auto blob = BasicDataUboImage(camera, std::atoi(argv[2]), std::atoi(argv[3]));
+            write_file(argv[4], blob.data(), blob.size());
+            return 0;
+        }
+        if (mode == "render" && argc >= 6) {
+            int W = std::atoi(argv[2]), H = std::atoi(argv[3]), frames = std::atoi(argv[4]);
+            int rayDepth = argc > 6 ? std::atoi(argv[6]) : 13, atmo = argc > 7 ? std::atoi(argv[7]) : 256;
+            PathTracer pathTracer(nullptr, W, H, rayDepth, 1, 20.0f, 0.14f);
+            AtmosphericScatterer atmosphericScatterer(pathTracer, atmo);
+            atmosphericScatterer.Render();
+            LoadScene(pathTracer);
+            UploadCamera(pathTracer, camera, W, H);
+            for (int i = 0; i < frames; i++) pathTracer.Render();
+            std::vector<float> img = pathTracer.Result();
+            write_file(argv[5], img.data(), img.size() * sizeof(float));
+            std::printf("rendered %dx%d, %d samples/pixel\n", W, H, pathTracer.Samples());
+            return 0;
+        }
+        std::fprintf(stderr, "usage: pt_host_demo render W H frames out.f32 [rayDepth] [atmoSize] | dump-scene out.bin | dump-camera W H out.bin\n");
+        return 1;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "pt_host_demo: %s\n", e.what()); // Program.cs:15-25: catch-all prints the exception
+        return 3;
+    }
+}

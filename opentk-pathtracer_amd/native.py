@@ -62,6 +62,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+HOST_DEMO = os.path.join(HERE, "host", "pt_host_demo")
+
+
+def build_host_demo(force: bool = False) -> str:
+    """g++ the C++ host mirror's demo (host/pt_host_demo.cpp) against the in-tree libmi355pt.so."""
+    src = [os.path.join(HERE, "host", "pt_host_demo.cpp"), os.path.join(HERE, "host", "pt_host.hpp"), HEADER]
+    if not force and os.path.exists(HOST_DEMO) and all(os.path.getmtime(f) <= os.path.getmtime(HOST_DEMO) for f in src):
+        return HOST_DEMO
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", src[0], "-o", HOST_DEMO, "-L" + HERE, "-lmi355pt", "-Wl,-rpath,$ORIGIN/.."]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("g++ failed building pt_host_demo:\n" + p.stdout + p.stderr)
+    return HOST_DEMO
+
+
 def declared_symbols() -> list[str]:
     """Every function the public header declares with PT_API."""
     text = open(HEADER).read()
