@@ -42,7 +42,8 @@ struct pt_renderer {
 
     float *dObjects = nullptr; // 26,624 B device copy of UBO 1
     float *dLut = nullptr;     // 256-entry sRGB table
-    unsigned int *dQueue = nullptr; // 8 per-XCD work counters of the persistent-queue kernel
+    unsigned int *dQueue = nullptr; // global chunk-ticket counter of the persistent kernel (never reset: epoch scheme)
+    unsigned int queueBase = 0;     // value of *dQueue at the start of the next launch
     int numCUs = 256;
     void *dEnv = nullptr;      // current environment cube
     size_t envBytes = 0;
@@ -178,6 +179,7 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     PT_CREATE_HIP(hipMemsetAsync(h->dObjects, 0, PT_GAME_OBJECTS_UBO_SIZE, h->stream));
     PT_CREATE_HIP(hipMalloc((void **)&h->dLut, 256 * sizeof(float)));
     PT_CREATE_HIP(hipMalloc((void **)&h->dQueue, 64 * sizeof(unsigned int)));
+    PT_CREATE_HIP(hipMemsetAsync(h->dQueue, 0, 64 * sizeof(unsigned int), h->stream));
     {
         hipDeviceProp_t prop;
         PT_CREATE_HIP(hipGetDeviceProperties(&prop, device_id));
@@ -348,8 +350,10 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     a.variant = h->variant;
     a.queue = h->dQueue;
     a.numCUs = h->numCUs;
-    if (h->variant == 0 || h->variant >= 10) PT_HIP(h, hipMemsetAsync(h->dQueue, 0, 64 * sizeof(unsigned int), h->stream));
-    PT_HIP(h, pt::launch_integrate(a, h->stream));
+    a.queueBase = h->queueBase;
+    unsigned int tickets = 0;
+    PT_HIP(h, pt::launch_integrate(a, h->stream, &tickets));
+    h->queueBase += tickets; // unsigned wrap-around is fine: the kernel subtracts queueBase modulo 2^32
     h->frame++; // PathTracer.cs:117 post-increment
     if (out_total_samples) *out_total_samples = h->frame * h->spp; // PathTracer.cs:112
     return PT_OK;

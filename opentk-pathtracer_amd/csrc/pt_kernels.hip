@@ -573,15 +573,17 @@ __global__ __launch_bounds__(256) void pt_integrate_pool_kernel(const FrameArgs 
     }
 }
 
-// ---- variant 0 (default) and >= 10: persistent wavefronts + global tile queue + LDS ring of primary rays.
+// ---- variant 0 (default) and >= 10: persistent wavefronts + two-level tile queue + LDS ring of primary rays.
 // The grid is sized to the machine (blocksPerCU x CUs), not to the image.  Each wavefront repeatedly
-//   1. takes an 8x8 tile from a global queue (8 counters, one per XCD; counter x hands out tiles x, x+8, x+16, ...;
-//      one returning atomic per 64 pixels, issued one tile ahead so its latency is hidden),
+//   1. takes an 8x8 tile from its workgroup's queue: an LDS (cursor,end) pair advanced with one 64-bit LDS atomic
+//      per tile; when the pair runs dry ONE wavefront of the workgroup refills it with a chunk of QUEUE_CHUNK tiles
+//      from the global counter (one device atomic per 512 pixels; the workgroup's first chunk is static),
 //   2. generates the tile's 64 primary rays with ALL lanes (camera code at full utilisation) into a per-wave LDS
 //      ring (pixel, RNG state after the 4 camera draws, origin, direction),
 //   3. runs bounce iterations in which every lane whose path ended pops the next ray of the ring.
 // So the traversal loops always run (nearly) full, the camera code is never executed divergently (for spp = 1),
-// and the only tail is the drain at the very end of the frame.  Pixels keep their own RNG streams -> bit-identical.
+// work is balanced dynamically across the chip and the only tail is the drain at the very end of the frame.
+// Pixels keep their own RNG streams -> bit-identical to every other variant.
 struct RingEntry { // 40 bytes
     int pix;       // linear index into accum, -1 = pixel outside the image (ragged tile)
     int pxy;       // px | py << 16 (global coordinates)
@@ -590,26 +592,71 @@ struct RingEntry { // 40 bytes
     int pad;
 };
 
-PT_DEV unsigned int queue_pop(unsigned int *counter)
+constexpr int QUEUE_CHUNK = 8; // tiles per global ticket
+
+struct BlockQueue {            // one per workgroup, in static LDS
+    unsigned long long pair;   // (end << 32) | cursor : absolute tile indices of the current chunk
+    unsigned int lock;         // refill lock
+    unsigned int done;         // global queue exhausted
+};
+
+// Next tile for this wavefront, or -1 when the frame's tiles are all handed out.  Wave-uniform result.
+PT_DEV int queue_pop_tile(BlockQueue *q, const FrameArgs &a, int numTiles)
 {
-    unsigned int v = 0;
-    if ((threadIdx.x & 63) == 0) v = atomicAdd(counter, 1u);
-    return (unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+    const bool leader = (threadIdx.x & 63) == 0;
+    for (;;) {
+        unsigned long long old = 0;
+        if (leader) old = atomicAdd(&q->pair, 1ull);
+        unsigned int cursor = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)old);
+        unsigned int end = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(old >> 32));
+        if (cursor < end) return (int)cursor;
+        if (__builtin_amdgcn_readfirstlane((int)((volatile BlockQueue *)q)->done)) return -1;
+        unsigned int got = 1;
+        if (leader) got = atomicCAS(&q->lock, 0u, 1u);
+        if (__builtin_amdgcn_readfirstlane((int)got) == 0) { // this wavefront refills
+            // re-check under the lock: another wavefront may have refilled or hit the end meanwhile (a workgroup
+            // must draw exactly ONE failing ticket per launch — the host's queueBase accounting relies on it)
+            unsigned long long cur = ((volatile BlockQueue *)q)->pair;
+            unsigned int isDone = ((volatile BlockQueue *)q)->done;
+            if (!isDone && (unsigned int)cur >= (unsigned int)(cur >> 32)) {
+                unsigned int ticket = 0;
+                if (leader) ticket = atomicAdd(a.queue, 1u) - a.queueBase;
+                ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+                long long first = ((long long)gridDim.x + ticket) * QUEUE_CHUNK;
+                if (first >= numTiles) {
+                    if (leader) ((volatile BlockQueue *)q)->done = 1u;
+                } else {
+                    long long last = first + QUEUE_CHUNK < numTiles ? first + QUEUE_CHUNK : numTiles;
+                    if (leader) atomicExch(&q->pair, ((unsigned long long)last << 32) | (unsigned long long)first);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (leader) atomicExch(&q->lock, 0u);
+        } else {
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void pt_integrate_persistent_kernel(const FrameArgs a)
 {
-    SceneLds sc = stage_scene(a);
+    __shared__ __attribute__((aligned(16))) BlockQueue queue; // 16 B: keeps the dynamic-LDS base 16-byte aligned
+    const int numTiles = a.tilesX * a.tilesY;
+    if (threadIdx.x == 0) { // the workgroup's first chunk is static: chunk index = workgroup index
+        long long first = (long long)blockIdx.x * QUEUE_CHUNK;
+        long long last = first + QUEUE_CHUNK < numTiles ? first + QUEUE_CHUNK : numTiles;
+        if (first >= numTiles) { first = 0; last = 0; }
+        queue.pair = ((unsigned long long)last << 32) | (unsigned long long)first;
+        queue.lock = 0u;
+        queue.done = 0u;
+    }
+    SceneLds sc = stage_scene(a); // ends with __syncthreads()
     EnvRef env{a.env, sc.lut, a.envSize, a.envFormat};
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int numTiles = a.tilesX * a.tilesY;
     // the ring lives behind the staged scene in dynamic LDS
     RingEntry *ring = (RingEntry *)((char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat)) + wave * 64;
-    const int xcd = blockIdx.x & 7; // dispatcher deals workgroups round-robin over the XCDs (speed only)
-    unsigned int *counter = a.queue + xcd * 8;
 
-    int avail = 0;                              // wave-uniform: ring entries [0, avail) are unconsumed
-    unsigned int ticket = queue_pop(counter);   // tile ticket fetched one step ahead
+    int avail = 0;           // wave-uniform: ring entries [0, avail) are unconsumed
     bool exhausted = false;
 
     int pix = -1, px = 0, py = 0, sample = 0, bounce = 0;
@@ -623,11 +670,10 @@ __global__ __launch_bounds__(256) void pt_integrate_persistent_kernel(const Fram
         if (m != 0ull) {
             if (avail == 0 && !exhausted) {
                 // ---- refill the ring: one tile, every lane generates one primary ray
-                long long tile = (long long)ticket * 8 + xcd;
-                if (tile >= numTiles) {
+                int tile = queue_pop_tile(&queue, a, numTiles);
+                if (tile < 0) {
                     exhausted = true;
                 } else {
-                    ticket = queue_pop(counter); // prefetch the next ticket; consumed at the next refill
                     int tx = (int)(tile % a.tilesX), ty = (int)(tile / a.tilesX);
                     int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
                     RingEntry e;
@@ -720,8 +766,9 @@ static int pool_tiles_for_variant(int variant)
     }
 }
 
-hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream)
+hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int *ticketsConsumed)
 {
+    *ticketsConsumed = 0;
     int tiles = a.tilesX * a.tilesY;
     size_t lds = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat);
     if (a.variant == 1) {
@@ -730,11 +777,13 @@ hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream)
     } else if (a.variant == 0 || a.variant >= 10) {
         int blocksPerCU = a.variant == 0 ? 4 : a.variant - 9;
         int nwg = a.numCUs * blocksPerCU;
-        int maxUseful = (tiles + 3) / 4;
-        if (nwg > maxUseful) nwg = maxUseful;
-        nwg = (nwg + 7) & ~7; // a multiple of 8 so every XCD counter has the same number of consumers
+        int numChunks = (tiles + QUEUE_CHUNK - 1) / QUEUE_CHUNK;
+        if (nwg > numChunks) nwg = numChunks;
+        if (nwg < 1) nwg = 1;
         size_t ldsTotal = lds + 4 * 64 * sizeof(RingEntry);
         hipLaunchKernelGGL(pt_integrate_persistent_kernel, dim3(nwg), dim3(256), ldsTotal, stream, a);
+        // every workgroup draws tickets until its first failing one: (numChunks - nwg) successful + nwg failing
+        *ticketsConsumed = (unsigned int)(numChunks > nwg ? numChunks : nwg);
     } else {
         int poolTiles = pool_tiles_for_variant(a.variant);
         int pools = (tiles + poolTiles - 1) / poolTiles;

@@ -25,7 +25,8 @@ struct FrameArgs {
     float4 *accum;          // rows x width RGBA32F accumulation image (row 0 = image row y0)
     int tilesX, tilesY;     // 8x8-pixel tiles covering width x rows
     int variant;            // kernel variant for A/B runs; all variants are bit-identical in output
-    unsigned int *queue;    // 8 per-XCD tile counters (persistent-queue variants); zeroed before every launch
+    unsigned int *queue;    // global chunk-ticket counter of the persistent kernel (monotonic across launches)
+    unsigned int queueBase; // value of *queue when this launch starts (every launch consumes exactly numChunks tickets)
     int numCUs;             // compute units of the device (grid sizing of persistent variants)
 };
 
@@ -38,7 +39,8 @@ struct AtmoArgs {
     float4 *out; // [6][size][size]
 };
 
-hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream);
+// ticketsConsumed: by how much the launch advances *a.queue (the caller adds it to the next launch's queueBase)
+hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int *ticketsConsumed);
 hipError_t launch_atmosphere(const AtmoArgs &a, hipStream_t stream);
 hipError_t launch_clear(float4 *p, size_t n, hipStream_t stream);
 // linearise any environment into RGBA32F for read-back

@@ -338,3 +338,10 @@ def test_cpp_host_startup_sequence(pkg, native_lib, oracle, tmp_path):
                          num_frames=frames)
     close = np.abs(got - want) <= 1e-3 * np.maximum(1.0, np.abs(want))
     assert close.all(-1).mean() > 0.99
+
+
+def test_many_consecutive_frames_queue_accounting(pkg, native_lib, oracle):
+    """The persistent kernel's global ticket counter is never reset (every launch must consume exactly the number of
+    tickets the host accounts for): 48 consecutive frames, then bit-compare the accumulation with the oracle."""
+    w = configs.Workload("queue", "default", 416, 234, 8, "sky_f32_32")
+    assert_bit_exact(hip_render(pkg, w, frames=48), oracle_render(oracle, w, frames=48), "48 frames")
