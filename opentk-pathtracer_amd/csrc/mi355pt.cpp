@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -43,7 +44,8 @@ struct pt_renderer {
     float *dObjects = nullptr; // 26,624 B device copy of UBO 1
     float *dLut = nullptr;     // 256-entry sRGB table
     unsigned int *dQueue = nullptr; // global chunk-ticket counter of the persistent kernel (never reset: epoch scheme)
-    unsigned int queueBase = 0;     // value of *dQueue at the start of the next launch
+    int queueChunk = 8;             // tiles per global ticket (PT_QUEUE_CHUNK overrides, for tuning runs)
+    unsigned long long *dTimeline = nullptr; // tuning only (pt_debug_timeline)
     int numCUs = 256;
     void *dEnv = nullptr;      // current environment cube
     size_t envBytes = 0;
@@ -55,6 +57,14 @@ struct pt_renderer {
     size_t boundBytes = 0;
 
     hipStream_t ownStream = nullptr, stream = nullptr;
+    // Stripes: one frame = `stripes` persistent kernels over contiguous row ranges of the tile, each on its own
+    // stream, so that one stripe's frame-end drain overlaps the other stripe's main phase.
+    static constexpr int kMaxStripes = 4;
+    hipStream_t stripeStream[kMaxStripes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t stripeDone[kMaxStripes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t inputsReady = nullptr;
+    bool stripePending[kMaxStripes] = {false, false, false, false};
+    unsigned int stripeQueueBase[kMaxStripes] = {0, 0, 0, 0};
     hipEvent_t evBegin = nullptr, evEnd = nullptr;
     std::string error;
 
@@ -104,6 +114,19 @@ void make_srgb_lut(float *lut)
     }
 }
 
+// Make the main stream wait for every stripe kernel still in flight (before anything that reads their output or
+// overwrites their inputs).
+int join_stripes(pt_handle h)
+{
+    for (int j = 0; j < pt_renderer::kMaxStripes; j++) {
+        if (h->stripePending[j]) {
+            PT_HIP(h, hipStreamWaitEvent(h->stream, h->stripeDone[j], 0));
+            h->stripePending[j] = false;
+        }
+    }
+    return PT_OK;
+}
+
 int ensure_accum(pt_handle h)
 {
     size_t need = h->tilePixels();
@@ -121,6 +144,7 @@ int clear_accum(pt_handle h)
 {
     if (h->boundAccum && h->boundBytes < h->tilePixels() * sizeof(float4))
         return fail(h, PT_E_BAD_ARGUMENT, "bound result buffer is smaller than the tile");
+    if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, pt::launch_clear(h->accum(), h->tilePixels(), h->stream));
     return PT_OK;
 }
@@ -157,6 +181,10 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     pt_renderer *h = new (std::nothrow) pt_renderer();
     if (!h) return fail(nullptr, PT_E_OUT_OF_MEMORY, "host allocation failed");
     h->device = device_id;
+    if (const char *qc = std::getenv("PT_QUEUE_CHUNK")) {
+        int v = std::atoi(qc);
+        if (v >= 1 && v <= 1024) h->queueChunk = v;
+    }
     h->width = width;
     h->height = height;
     h->y0 = 0;
@@ -173,6 +201,11 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     PT_CREATE_HIP(hipSetDevice(device_id));
     PT_CREATE_HIP(hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking));
     h->stream = h->ownStream;
+    for (int j = 0; j < pt_renderer::kMaxStripes; j++) {
+        PT_CREATE_HIP(hipStreamCreateWithFlags(&h->stripeStream[j], hipStreamNonBlocking));
+        PT_CREATE_HIP(hipEventCreateWithFlags(&h->stripeDone[j], hipEventDisableTiming));
+    }
+    PT_CREATE_HIP(hipEventCreateWithFlags(&h->inputsReady, hipEventDisableTiming));
     PT_CREATE_HIP(hipEventCreate(&h->evBegin));
     PT_CREATE_HIP(hipEventCreate(&h->evEnd));
     PT_CREATE_HIP(hipMalloc((void **)&h->dObjects, PT_GAME_OBJECTS_UBO_SIZE));
@@ -205,7 +238,14 @@ PT_API int pt_destroy(pt_handle h)
 {
     PT_CHECK_HANDLE(h);
     (void)hipSetDevice(h->device);
+    for (int j = 0; j < pt_renderer::kMaxStripes; j++)
+        if (h->stripeStream[j]) (void)hipStreamSynchronize(h->stripeStream[j]);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int j = 0; j < pt_renderer::kMaxStripes; j++) {
+        if (h->stripeDone[j]) (void)hipEventDestroy(h->stripeDone[j]);
+        if (h->stripeStream[j]) (void)hipStreamDestroy(h->stripeStream[j]);
+    }
+    if (h->inputsReady) (void)hipEventDestroy(h->inputsReady);
     if (h->dObjects) (void)hipFree(h->dObjects);
     if (h->dLut) (void)hipFree(h->dLut);
     if (h->dQueue) (void)hipFree(h->dQueue);
@@ -286,6 +326,7 @@ PT_API int pt_upload_game_objects(pt_handle h, int byte_offset, int size, const 
         return fail(h, PT_E_OUT_OF_RANGE, "GameObjectsUBO range outside [0,26624)");
     if (size == 0) return PT_OK;
     if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc;
     // pageable source: HIP stages the bytes before returning, so the caller may reuse `src` immediately
     PT_HIP(h, hipMemcpyAsync((char *)h->dObjects + byte_offset, src, (size_t)size, hipMemcpyHostToDevice, h->stream));
     return PT_OK;
@@ -300,6 +341,7 @@ PT_API int pt_set_environment(pt_handle h, int face_size, int format, const void
     for (int f = 0; f < 6; f++)
         if (!faces[f]) return fail(h, PT_E_BAD_ARGUMENT, "faces[i] == NULL");
     if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc;
     size_t faceBytes = (size_t)face_size * face_size * (format == PT_ENV_RGBA32F ? 16 : 4);
     size_t total = faceBytes * 6;
     if (total > h->envBytes) {
@@ -332,8 +374,6 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     a.apertureDiameter = h->apertureDiameter;
     a.width = h->width;
     a.height = h->height;
-    a.y0 = h->y0;
-    a.rows = h->rows;
     a.numSpheres = h->numSpheres;
     a.numCuboids = h->numCuboids;
     a.rayDepth = h->rayDepth;
@@ -344,16 +384,53 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     a.objects = h->dObjects;
     a.env = h->dEnv;
     a.srgbLut = h->dLut;
-    a.accum = h->accum();
     a.tilesX = (h->width + 7) / 8;
-    a.tilesY = (h->rows + 7) / 8;
-    a.variant = h->variant;
-    a.queue = h->dQueue;
     a.numCUs = h->numCUs;
-    a.queueBase = h->queueBase;
-    unsigned int tickets = 0;
-    PT_HIP(h, pt::launch_integrate(a, h->stream, &tickets));
-    h->queueBase += tickets; // unsigned wrap-around is fine: the kernel subtracts queueBase modulo 2^32
+    a.queueChunk = h->queueChunk;
+    a.timeline = h->dTimeline;
+
+    // variant -> (kernel variant, stripes): 0 = default (2 stripes x 5 workgroups/CU); 20+k / 30+k / 40+k = 2 / 3 / 4
+    // stripes of the persistent kernel with k+1 workgroups per CU; everything else = one kernel on the main stream
+    int stripes = 1, kernelVariant = h->variant;
+    if (h->variant == 0) { stripes = 2; kernelVariant = 14; }
+    else if (h->variant >= 20 && h->variant < 50) { stripes = h->variant / 10; kernelVariant = 10 + h->variant % 10; }
+    if (h->rows < 16 * stripes) stripes = 1; // tiny tiles: not worth splitting
+    a.variant = kernelVariant;
+
+    if (stripes == 1) {
+        if (int rc = join_stripes(h)) return rc;
+        a.y0 = h->y0;
+        a.rows = h->rows;
+        a.accum = h->accum();
+        a.tilesY = (h->rows + 7) / 8;
+        a.queue = h->dQueue;
+        a.queueBase = h->stripeQueueBase[0];
+        unsigned int tickets = 0;
+        PT_HIP(h, pt::launch_integrate(a, h->stream, &tickets));
+        h->stripeQueueBase[0] += tickets; // unsigned wrap-around is fine: the kernel subtracts queueBase modulo 2^32
+    } else {
+        // inputs uploaded on the main stream (scene, environment, clears) must be visible to the stripe streams;
+        // a stripe's frame f+1 follows its own frame f in stream order, which is the only dependency between frames
+        PT_HIP(h, hipEventRecord(h->inputsReady, h->stream));
+        for (int j = 0; j < stripes; j++) {
+            int r0 = (int)((long long)h->rows * j / stripes), r1 = (int)((long long)h->rows * (j + 1) / stripes);
+            r0 &= ~7; // stripe boundaries on 8-row tile boundaries (the last stripe takes the ragged remainder)
+            if (j + 1 < stripes) r1 &= ~7;
+            if (r1 <= r0) continue;
+            a.y0 = h->y0 + r0;
+            a.rows = r1 - r0;
+            a.accum = h->accum() + (size_t)r0 * h->width;
+            a.tilesY = (a.rows + 7) / 8;
+            a.queue = h->dQueue + 16 * j;
+            a.queueBase = h->stripeQueueBase[j];
+            PT_HIP(h, hipStreamWaitEvent(h->stripeStream[j], h->inputsReady, 0));
+            unsigned int tickets = 0;
+            PT_HIP(h, pt::launch_integrate(a, h->stripeStream[j], &tickets));
+            h->stripeQueueBase[j] += tickets;
+            PT_HIP(h, hipEventRecord(h->stripeDone[j], h->stripeStream[j]));
+            h->stripePending[j] = true;
+        }
+    }
     h->frame++; // PathTracer.cs:117 post-increment
     if (out_total_samples) *out_total_samples = h->frame * h->spp; // PathTracer.cs:112
     return PT_OK;
@@ -367,6 +444,7 @@ PT_API int pt_read_result(pt_handle h, float *dst, size_t row_pitch_bytes)
     if (row_pitch_bytes == 0) row_pitch_bytes = rowBytes;
     if (row_pitch_bytes < rowBytes) return fail(h, PT_E_BAD_ARGUMENT, "row pitch smaller than a row");
     if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, hipMemcpy2DAsync(dst, row_pitch_bytes, h->accum(), rowBytes, rowBytes, (size_t)h->rows,
                                hipMemcpyDeviceToHost, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -381,6 +459,7 @@ PT_API int pt_write_result(pt_handle h, const float *src, size_t row_pitch_bytes
     if (row_pitch_bytes == 0) row_pitch_bytes = rowBytes;
     if (row_pitch_bytes < rowBytes) return fail(h, PT_E_BAD_ARGUMENT, "row pitch smaller than a row");
     if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, hipMemcpy2DAsync(h->accum(), rowBytes, src, row_pitch_bytes, rowBytes, (size_t)h->rows,
                                hipMemcpyHostToDevice, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -400,6 +479,7 @@ PT_API int pt_synchronize(pt_handle h)
 {
     PT_CHECK_HANDLE(h);
     if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, hipStreamSynchronize(h->stream));
     return PT_OK;
 }
@@ -421,6 +501,7 @@ PT_API int pt_atmosphere_render(pt_handle h, int size, int i_steps, int j_steps,
     if (size <= 0 || size > 8192 || i_steps < 0 || j_steps < 0 || !light_pos)
         return fail(h, PT_E_BAD_ARGUMENT, "bad atmosphere parameters");
     if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc;
     size_t total = (size_t)6 * size * size * 16;
     if (total > h->envBytes) {
         PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -454,6 +535,7 @@ PT_API int pt_read_environment(pt_handle h, float *dst, int *out_face_size)
     if (out_face_size) *out_face_size = h->envSize;
     if (!dst) return PT_OK; // size query
     if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc;
     size_t n = (size_t)6 * h->envSize * h->envSize;
     if (h->envFormat == PT_ENV_RGBA32F) {
         PT_HIP(h, hipMemcpyAsync(dst, h->dEnv, n * 16, hipMemcpyDeviceToHost, h->stream));
@@ -483,6 +565,8 @@ PT_API int pt_bind_result_buffer(pt_handle h, void *device_ptr, size_t bytes)
     PT_CHECK_HANDLE(h);
     if (device_ptr && bytes < h->tilePixels() * sizeof(float4))
         return fail(h, PT_E_BAD_ARGUMENT, "buffer smaller than rows*width*16 bytes");
+    if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc;
     h->boundAccum = (float4 *)device_ptr;
     h->boundBytes = device_ptr ? bytes : 0;
     return PT_OK;
@@ -492,6 +576,7 @@ PT_API int pt_set_stream(pt_handle h, void *hip_stream)
 {
     PT_CHECK_HANDLE(h);
     if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, hipStreamSynchronize(h->stream));
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->ownStream;
     return PT_OK;
@@ -501,6 +586,7 @@ PT_API int pt_timer_begin(pt_handle h)
 {
     PT_CHECK_HANDLE(h);
     if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, hipEventRecord(h->evBegin, h->stream));
     return PT_OK;
 }
@@ -510,15 +596,34 @@ PT_API int pt_timer_end(pt_handle h, float *out_ms)
     PT_CHECK_HANDLE(h);
     if (!out_ms) return fail(h, PT_E_BAD_ARGUMENT, "out == NULL");
     if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, hipEventRecord(h->evEnd, h->stream));
     PT_HIP(h, hipEventSynchronize(h->evEnd));
     PT_HIP(h, hipEventElapsedTime(out_ms, h->evBegin, h->evEnd));
     return PT_OK;
 }
 
+// Tuning aid (not declared in the public header): per-wavefront timestamps of the next persistent-kernel launches.
+extern "C" __attribute__((visibility("default"))) int pt_debug_timeline(pt_handle h, unsigned long long *host_out, int max_waves)
+{
+    PT_CHECK_HANDLE(h);
+    if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc;
+    if (!h->dTimeline) {
+        PT_HIP(h, hipMalloc((void **)&h->dTimeline, (size_t)65536 * 4 * sizeof(unsigned long long)));
+        PT_HIP(h, hipMemsetAsync(h->dTimeline, 0, (size_t)65536 * 4 * sizeof(unsigned long long), h->stream));
+        return PT_OK;
+    }
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    if (host_out) PT_HIP(h, hipMemcpy(host_out, h->dTimeline, (size_t)max_waves * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 PT_API int pt_set_variant(pt_handle h, int variant)
 {
     PT_CHECK_HANDLE(h);
+    if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc; // a different stripe partition must not overlap frames in flight
     h->variant = variant;
     return PT_OK;
 }

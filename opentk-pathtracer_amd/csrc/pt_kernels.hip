@@ -576,8 +576,8 @@ __global__ __launch_bounds__(256) void pt_integrate_pool_kernel(const FrameArgs 
 // ---- variant 0 (default) and >= 10: persistent wavefronts + two-level tile queue + LDS ring of primary rays.
 // The grid is sized to the machine (blocksPerCU x CUs), not to the image.  Each wavefront repeatedly
 //   1. takes an 8x8 tile from its workgroup's queue: an LDS (cursor,end) pair advanced with one 64-bit LDS atomic
-//      per tile; when the pair runs dry ONE wavefront of the workgroup refills it with a chunk of QUEUE_CHUNK tiles
-//      from the global counter (one device atomic per 512 pixels; the workgroup's first chunk is static),
+//      per tile; when the pair runs dry ONE wavefront of the workgroup refills it with a chunk of a.queueChunk tiles
+//      from the global counter (one device atomic per queueChunk x 64 pixels; the workgroup's first chunk is static),
 //   2. generates the tile's 64 primary rays with ALL lanes (camera code at full utilisation) into a per-wave LDS
 //      ring (pixel, RNG state after the 4 camera draws, origin, direction),
 //   3. runs bounce iterations in which every lane whose path ended pops the next ray of the ring.
@@ -592,7 +592,6 @@ struct RingEntry { // 40 bytes
     int pad;
 };
 
-constexpr int QUEUE_CHUNK = 8; // tiles per global ticket
 
 struct BlockQueue {            // one per workgroup, in static LDS
     unsigned long long pair;   // (end << 32) | cursor : absolute tile indices of the current chunk
@@ -622,11 +621,11 @@ PT_DEV int queue_pop_tile(BlockQueue *q, const FrameArgs &a, int numTiles)
                 unsigned int ticket = 0;
                 if (leader) ticket = atomicAdd(a.queue, 1u) - a.queueBase;
                 ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
-                long long first = ((long long)gridDim.x + ticket) * QUEUE_CHUNK;
+                long long first = ((long long)gridDim.x + ticket) * a.queueChunk;
                 if (first >= numTiles) {
                     if (leader) ((volatile BlockQueue *)q)->done = 1u;
                 } else {
-                    long long last = first + QUEUE_CHUNK < numTiles ? first + QUEUE_CHUNK : numTiles;
+                    long long last = first + a.queueChunk < numTiles ? first + a.queueChunk : numTiles;
                     if (leader) atomicExch(&q->pair, ((unsigned long long)last << 32) | (unsigned long long)first);
                 }
             }
@@ -643,8 +642,8 @@ __global__ __launch_bounds__(256) void pt_integrate_persistent_kernel(const Fram
     __shared__ __attribute__((aligned(16))) BlockQueue queue; // 16 B: keeps the dynamic-LDS base 16-byte aligned
     const int numTiles = a.tilesX * a.tilesY;
     if (threadIdx.x == 0) { // the workgroup's first chunk is static: chunk index = workgroup index
-        long long first = (long long)blockIdx.x * QUEUE_CHUNK;
-        long long last = first + QUEUE_CHUNK < numTiles ? first + QUEUE_CHUNK : numTiles;
+        long long first = (long long)blockIdx.x * a.queueChunk;
+        long long last = first + a.queueChunk < numTiles ? first + a.queueChunk : numTiles;
         if (first >= numTiles) { first = 0; last = 0; }
         queue.pair = ((unsigned long long)last << 32) | (unsigned long long)first;
         queue.lock = 0u;
@@ -658,6 +657,8 @@ __global__ __launch_bounds__(256) void pt_integrate_persistent_kernel(const Fram
 
     int avail = 0;           // wave-uniform: ring entries [0, avail) are unconsumed
     bool exhausted = false;
+    unsigned long long tStart = 0, tExhausted = 0, nIter = 0;
+    if (a.timeline) tStart = wall_clock64();
 
     int pix = -1, px = 0, py = 0, sample = 0, bounce = 0;
     bool needRay = false;
@@ -673,6 +674,7 @@ __global__ __launch_bounds__(256) void pt_integrate_persistent_kernel(const Fram
                 int tile = queue_pop_tile(&queue, a, numTiles);
                 if (tile < 0) {
                     exhausted = true;
+                    if (a.timeline) tExhausted = wall_clock64();
                 } else {
                     int tx = (int)(tile % a.tilesX), ty = (int)(tile / a.tilesX);
                     int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
@@ -723,6 +725,7 @@ __global__ __launch_bounds__(256) void pt_integrate_persistent_kernel(const Fram
             if (exhausted && avail == 0) break;
             continue;
         }
+        nIter++;
         if (active && needRay) { // only for spp > 1: the next sample continues the pixel's RNG stream (compute.glsl:110)
             primary_ray(a, px, py, seed, ro, rd);
             throughput = V(1.0f, 1.0f, 1.0f);
@@ -746,6 +749,10 @@ __global__ __launch_bounds__(256) void pt_integrate_persistent_kernel(const Fram
                 }
             }
         }
+    }
+    if (a.timeline && lane == 0) {
+        unsigned long long *t = a.timeline + ((size_t)blockIdx.x * 4 + wave) * 4;
+        t[0] = tStart; t[1] = tExhausted; t[2] = wall_clock64(); t[3] = nIter;
     }
 }
 
@@ -777,7 +784,7 @@ hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int
     } else if (a.variant == 0 || a.variant >= 10) {
         int blocksPerCU = a.variant == 0 ? 4 : a.variant - 9;
         int nwg = a.numCUs * blocksPerCU;
-        int numChunks = (tiles + QUEUE_CHUNK - 1) / QUEUE_CHUNK;
+        int numChunks = (tiles + a.queueChunk - 1) / a.queueChunk;
         if (nwg > numChunks) nwg = numChunks;
         if (nwg < 1) nwg = 1;
         size_t ldsTotal = lds + 4 * 64 * sizeof(RingEntry);

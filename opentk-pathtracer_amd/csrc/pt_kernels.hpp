@@ -28,6 +28,8 @@ struct FrameArgs {
     unsigned int *queue;    // global chunk-ticket counter of the persistent kernel (monotonic across launches)
     unsigned int queueBase; // value of *queue when this launch starts (every launch consumes exactly numChunks tickets)
     int numCUs;             // compute units of the device (grid sizing of persistent variants)
+    int queueChunk;         // tiles per global ticket of the persistent kernel's queue
+    unsigned long long *timeline; // optional (tuning): per wavefront {start, queue exhausted, end, iterations} timestamps
 };
 
 struct AtmoArgs {
