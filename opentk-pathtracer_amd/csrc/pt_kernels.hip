@@ -105,14 +105,16 @@ PT_DEV v3 env_texel_wrapped(const EnvRef &e, int face, int ix, int iy)
     int S = e.size;
     if (ix >= 0 && ix < S && iy >= 0 && iy < S) return env_texel(e, face, ix, iy);
     float fs = (float)S;
-    float sc = ((float)ix + 0.5f) / fs * 2.0f - 1.0f;
-    float tc = ((float)iy + 0.5f) / fs * 2.0f - 1.0f;
+    float rfs = f_div_ieee(1.0f, fs); // uniform
+    float sc = ((float)ix + 0.5f) * rfs * 2.0f - 1.0f;
+    float tc = ((float)iy + 0.5f) * rfs * 2.0f - 1.0f;
     float x, y, z, ma, nsc, ntc;
     int nface;
     face_to_dir(face, sc, tc, x, y, z);
     dir_to_face(x, y, z, nface, nsc, ntc, ma);
-    float u = (nsc / ma * 0.5f + 0.5f) * fs;
-    float v = (ntc / ma * 0.5f + 0.5f) * fs;
+    float rma = f_rcp(ma);
+    float u = (nsc * rma * 0.5f + 0.5f) * fs;
+    float v = (ntc * rma * 0.5f + 0.5f) * fs;
     int nx = (int)__builtin_floorf(u), ny = (int)__builtin_floorf(v);
     nx = nx < 0 ? 0 : (nx > S - 1 ? S - 1 : nx);
     ny = ny < 0 ? 0 : (ny > S - 1 ? S - 1 : ny);
@@ -124,7 +126,7 @@ PT_DEV v3 sample_env(const EnvRef &e, v3 d)
     int S = e.size, face;
     float sc, tc, ma;
     dir_to_face(d.x, d.y, d.z, face, sc, tc, ma);
-    float ima = 0.5f / ma;
+    float ima = 0.5f * f_rcp(ma);
     float fs = (float)S;
     float u = f_fma(sc, ima, 0.5f) * fs - 0.5f;
     float v = f_fma(tc, ima, 0.5f) * fs - 0.5f;
@@ -259,7 +261,7 @@ PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h)
         float4 s = sc.sph[winner];
         h.m = load_material(sc.mat + 4 * winner);
         v3 pc = V(h.nearHitPos.x - s.x, h.nearHitPos.y - s.y, h.nearHitPos.z - s.z);
-        h.normal = V(pc.x / s.w, pc.y / s.w, pc.z / s.w); // compute.glsl:316-319
+        h.normal = v_scale(pc, f_div_ieee(1.0f, s.w)); // compute.glsl:316-319; 1/radius = IEEE quotient
     } else {
         int ci = winner - 256;
         float4 mn = sc.cmin[ci], mx = sc.cmax[ci];
@@ -284,7 +286,7 @@ PT_DEV v3 cosine_sample_hemisphere(v3 n, uint32_t &seed)
 // compute.glsl:359-364
 PT_DEV float fresnel_schlick(float cosTheta, float n1, float n2)
 {
-    float r0 = (n1 - n2) / (n1 + n2);
+    float r0 = (n1 - n2) * f_rcp(n1 + n2);
     r0 *= r0;
     return f_fma(1.0f - r0, pt_pow5(1.0f - cosTheta), r0);
 }
@@ -319,7 +321,7 @@ PT_DEV float bsdf(v3 &ro, v3 &rd, const Hit &h, bool &isRefractive, uint32_t &se
         rd = v_normalize(v_mix(refl, diffuseRay, h.m.specularRoughness * h.m.specularRoughness));
         prob = spec;
     } else if (spec + refr > roll) {
-        v3 rf = f_refract(rd, h.normal, h.fromInside ? (h.m.ior / 1.0f) : (1.0f / h.m.ior));
+        v3 rf = f_refract(rd, h.normal, h.fromInside ? h.m.ior : f_rcp(h.m.ior));
         v3 rough = cosine_sample_hemisphere(v_neg(h.normal), seed);
         rd = v_normalize(v_mix(rf, rough, h.m.refractionRoughness * h.m.refractionRoughness));
         prob = refr;
@@ -350,10 +352,10 @@ PT_DEV bool bounce_step(const SceneLds &sc, int ns, int nc, const EnvRef &env, v
         rad = V(f_fma(h.m.emissiv.x, throughput.x, rad.x), f_fma(h.m.emissiv.y, throughput.y, rad.y),
                 f_fma(h.m.emissiv.z, throughput.z, rad.z));
         if (!isRefractive) throughput = v_mul(throughput, h.m.albedo);
-        throughput = V(throughput.x / prob, throughput.y / prob, throughput.z / prob);
+        throughput = v_scale(throughput, f_rcp(prob));
         float p = f_max(throughput.x, f_max(throughput.y, throughput.z)); // Russian roulette, :167-173
         if (rand01(seed) > p) return false;
-        throughput = V(throughput.x / p, throughput.y / p, throughput.z / p);
+        throughput = v_scale(throughput, f_rcp(p));
         return true;
     }
     v3 e = sample_env(env, rd); // compute.glsl:177
@@ -383,8 +385,8 @@ PT_DEV void primary_ray(const FrameArgs &a, int px, int py, uint32_t &seed, v3 &
 {
     v3 viewPos = V(a.viewPos[0], a.viewPos[1], a.viewPos[2]);
     float u0 = rand01(seed), u1 = rand01(seed); // :113
-    float ndcx = f_fma(((float)px + u0) / (float)a.width, 2.0f, -1.0f);
-    float ndcy = f_fma(((float)py + u1) / (float)a.height, 2.0f, -1.0f);
+    float ndcx = f_fma(((float)px + u0) * f_div_ieee(1.0f, (float)a.width), 2.0f, -1.0f); // uniform 1/W, 1/H
+    float ndcy = f_fma(((float)py + u1) * f_div_ieee(1.0f, (float)a.height), 2.0f, -1.0f);
     float eye[4], wd[4];
     mat_vec(a.invProj, ndcx, ndcy, -1.0f, 0.0f, eye);
     mat_vec(a.invView, eye[0], eye[1], -1.0f, 0.0f, wd);
@@ -410,9 +412,8 @@ PT_DEV uint32_t pixel_seed(int px, int py, int frame)
 // compute.glsl:125-129: irradiance /= SPP; running mean with the previous accumulation value; alpha = 1
 PT_DEV float4 resolve_pixel(const FrameArgs &a, v3 irr, float4 last)
 {
-    float fspp = (float)a.spp;
-    irr = V(irr.x / fspp, irr.y / fspp, irr.z / fspp);
-    float w = 1.0f / (float)(a.frame + 1);
+    irr = v_scale(irr, f_div_ieee(1.0f, (float)a.spp)); // uniform reciprocal
+    float w = f_div_ieee(1.0f, (float)(a.frame + 1));
     return make_float4(f_mix(last.x, irr.x, w), f_mix(last.y, irr.y, w), f_mix(last.z, irr.z, w), 1.0f);
 }
 

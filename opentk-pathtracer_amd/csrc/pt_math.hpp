@@ -1,13 +1,17 @@
 // pt_math.hpp — the "pt-f32" arithmetic contract on the device side (gfx950).
 //
-// Every routine here is a fixed sequence of IEEE-754 binary32 operations (correctly rounded +,-,*,/,sqrt and
-// explicitly written fma), so the HIP integrator reproduces the CPU oracle bit for bit.  The translation unit
+// Every routine here is a fixed sequence of IEEE-754 binary32 operations (correctly rounded +,-,*,sqrt and
+// explicitly written fma), so the HIP integrator reproduces the CPU oracle bit for bit.  Reciprocals and inverse
+// square roots on the per-bounce path are the contract's Newton sequences f_rcp / f_rsqrt (the correctly rounded
+// IEEE divide / sqrt cost 43 / 52 issue cycles on gfx950, tools/ubench.hip; the hardware approximations cannot be
+// reproduced on a CPU); per-frame uniform quotients use the IEEE operator `/` via f_div_ieee.  The translation unit
 // that includes this header must be compiled with  -ffp-contract=off -fno-fast-math  and WITHOUT
 // -fgpu-flush-denormals-to-zero (hipcc's default keeps denormals and uses correctly rounded fp32 divide/sqrt).
 // No hardware approximations (v_rcp/v_rsq/v_sin/v_exp) are used on the parity path.
 //
 // GLSL built-ins of the reference shader (res/shaders/PathTracing/compute.glsl) map as follows:
-//   dot -> v_dot (fma chain), normalize -> v * (1/sqrt(dot)), mix -> fma(y,a,x*(1-a)), min/max -> minNum/maxNum,
+//   dot -> v_dot (fma chain), normalize -> v * f_rsqrt(dot), a/b -> a * f_rcp(b), mix -> fma(y,a,x*(1-a)),
+//   min/max -> minNum/maxNum,
 //   sin/cos -> pt_sincos, exp -> pt_exp, pow(x,5.0) -> pt_pow5, reflect/refract -> GLSL 4.50 section 8.5 formulas.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -29,7 +33,28 @@ struct v3 {
 PT_DEV float f_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 PT_DEV float f_min(float a, float b) { return __builtin_fminf(a, b); }
 PT_DEV float f_max(float a, float b) { return __builtin_fmaxf(a, b); }
-PT_DEV float f_rcp(float a) { return 1.0f / a; }
+PT_DEV float f_div_ieee(float a, float b) { return a / b; } // correctly rounded; uniform / once-per-object uses only
+// pt-f32 reciprocal: seed by exponent negation, three Newton steps (<= 0.51 ulp); zero and denormals give +-inf
+PT_DEV float f_rcp(float x)
+{
+    float y = __uint_as_float(0x7EF311C7u - __float_as_uint(x));
+    float e = f_fma(-x, y, 1.0f); y = f_fma(y, e, y);
+    e = f_fma(-x, y, 1.0f); y = f_fma(y, e, y);
+    e = f_fma(-x, y, 1.0f); y = f_fma(y, e, y);
+    if (__builtin_fabsf(x) < 1.17549435e-38f) y = __builtin_copysignf(__builtin_inff(), x);
+    return y;
+}
+// pt-f32 inverse square root: classic seed, three Newton steps (<= 1.7 ulp); zero/denormal -> +inf, negative -> NaN
+PT_DEV float f_rsqrt(float x)
+{
+    float y = __uint_as_float(0x5F3759DFu - (__float_as_uint(x) >> 1));
+    float h = 0.5f * x, t;
+    t = y * y; t = f_fma(-h, t, 1.5f); y = y * t;
+    t = y * y; t = f_fma(-h, t, 1.5f); y = y * t;
+    t = y * y; t = f_fma(-h, t, 1.5f); y = y * t;
+    if (x < 1.17549435e-38f) y = x < 0.0f ? __builtin_nanf("") : __builtin_inff();
+    return y;
+}
 PT_DEV float f_sqrt(float a) { return __builtin_sqrtf(a); }
 PT_DEV float f_abs(float a) { return __builtin_fabsf(a); }
 PT_DEV float f_mix(float x, float y, float a) { return f_fma(y, a, x * (1.0f - a)); }
@@ -42,7 +67,7 @@ PT_DEV v3 v_scale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
 PT_DEV v3 v_neg(v3 a) { return V(-a.x, -a.y, -a.z); }
 PT_DEV v3 v_fma(v3 b, float s, v3 a) { return V(f_fma(b.x, s, a.x), f_fma(b.y, s, a.y), f_fma(b.z, s, a.z)); }
 PT_DEV float v_dot(v3 a, v3 b) { return f_fma(a.z, b.z, f_fma(a.y, b.y, a.x * b.x)); }
-PT_DEV v3 v_normalize(v3 a) { return v_scale(a, f_rcp(f_sqrt(v_dot(a, a)))); }
+PT_DEV v3 v_normalize(v3 a) { return v_scale(a, f_rsqrt(v_dot(a, a))); }
 PT_DEV v3 v_mix(v3 x, v3 y, float a)
 {
     float ia = 1.0f - a;

@@ -15,18 +15,27 @@
  * tests/golden/ (generator: tests/golden/make_golden.py) and checked by tests/test_oracle_vs_reference.py.
  *
  * ARITHMETIC CONTRACT ("pt-f32", shared with the HIP kernel so that HIP == oracle BIT-FOR-BIT):
- *   - every value is IEEE-754 binary32; +,-,*,/ and sqrt are correctly rounded; denormals are kept;
+ *   - every value is IEEE-754 binary32; +,-,* and sqrt are correctly rounded; denormals are kept;
  *   - a*b+c is fused ONLY where this file writes fmaf() — compile with -ffp-contract=off;
  *   - dot(a,b)      = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
- *   - normalize(v)  = v * (1.0f / sqrtf(dot(v,v)))
+ *   - 1/x           = f_rcp(x): bit-trick seed 0x7EF311C7 - bits(x), three Newton steps y += y*fma(-x,y,1)
+ *                     (measured <= 0.51 ulp over 6e6 samples); |x| < FLT_MIN -> +-inf.  a/b is evaluated as a * f_rcp(b)
+ *                     everywhere on the per-bounce path (GLSL 4.50 section 4.7.1 allows 2.5 ulp for a/b), and a
+ *                     vector divided by a scalar uses ONE reciprocal.  Per-frame uniform reciprocals (1/W, 1/H, 1/SPP,
+ *                     1/(frame+1)) and 1/radius (computed once per sphere) use the correctly rounded IEEE quotient.
+ *   - inversesqrt(x)= f_rsqrt(x): seed 0x5F3759DF - (bits(x)>>1), three Newton steps (<= 1.7 ulp; GLSL allows 2);
+ *                     x < FLT_MIN -> +inf (x >= 0) or NaN (x < 0), so normalize(vec3(0)) is still NaN
+ *   - normalize(v)  = v * f_rsqrt(dot(v,v))
  *   - mix(x,y,a)    = fma(y, a, x*(1-a))                       (GLSL 4.50 section 8.3 definition)
  *   - min/max       = IEEE minNum/maxNum (fminf/fmaxf); GLSL leaves NaN handling undefined
  *   - sin/cos/exp   = the fixed polynomial algorithms below (<= ~1.5 ulp), pow(x,5) = x*(x^2)^2,
  *                     pow(x,1.5) = x*sqrt(x)
- *   - cuboid slabs  : (Min-O)/D is evaluated as (Min-O) * (1.0f/D)  (GLSL 4.50 section 4.7.1 allows 2.5 ulp
- *                     for a/b; one correctly-rounded reciprocal per ray component instead of six divisions per
- *                     cuboid).  Define PT_SLAB_TRUE_DIVISION to get the literal a/b form (kept for the
- *                     fidelity study in DESIGN.md; the HIP kernel implements the reciprocal form).
+ *   - cuboid slabs  : (Min-O)/D is evaluated as (Min-O) * f_rcp(D) (one reciprocal per ray component instead of six
+ *                     divisions per cuboid).  Define PT_SLAB_TRUE_DIVISION to get the literal IEEE a/b form (kept for
+ *                     the fidelity study in DESIGN.md; the HIP kernel implements the reciprocal form).
+ *   Why software reciprocals: the correctly rounded IEEE divide / sqrt expand to 43 / 52 issue cycles on gfx950
+ *   (tools/ubench.hip) and were 22 % of the integrator's vector work; hardware v_rcp/v_rsq cannot be reproduced on a
+ *   CPU, these sequences can — so the GPU result stays bit-identical to this file.
  *   GLSL itself leaves precision of all of these implementation-defined; llvmpipe is one realisation, this
  *   contract is another.  The stated tolerance against llvmpipe lives in tests/test_oracle_vs_reference.py.
  *
@@ -50,7 +59,29 @@ typedef struct { float x, y, z; } v3;
 /* ------------------------------------------------------------------ pt-f32 primitives */
 static inline float f_min(float a, float b) { return fminf(a, b); }
 static inline float f_max(float a, float b) { return fmaxf(a, b); }
-static inline float f_rcp(float a) { return 1.0f / a; }
+static inline uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float f_unbits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+/* pt-f32 reciprocal: seed by exponent negation, three Newton steps; zero and denormals give +-inf */
+static inline float f_rcp(float x)
+{
+    float y = f_unbits(0x7EF311C7u - f_bits(x));
+    float e = fmaf(-x, y, 1.0f); y = fmaf(y, e, y);
+    e = fmaf(-x, y, 1.0f); y = fmaf(y, e, y);
+    e = fmaf(-x, y, 1.0f); y = fmaf(y, e, y);
+    if (fabsf(x) < 1.17549435e-38f) y = copysignf(INFINITY, x);
+    return y;
+}
+/* pt-f32 inverse square root: classic seed, three Newton steps; zero/denormal -> +inf, negative -> NaN */
+static inline float f_rsqrt(float x)
+{
+    float y = f_unbits(0x5F3759DFu - (f_bits(x) >> 1));
+    float h = 0.5f * x, t;
+    t = y * y; t = fmaf(-h, t, 1.5f); y = y * t;
+    t = y * y; t = fmaf(-h, t, 1.5f); y = y * t;
+    t = y * y; t = fmaf(-h, t, 1.5f); y = y * t;
+    if (x < 1.17549435e-38f) y = x < 0.0f ? NAN : INFINITY;
+    return y;
+}
 static inline float f_mix(float x, float y, float a) { return fmaf(y, a, x * (1.0f - a)); }
 
 static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
@@ -62,7 +93,7 @@ static inline v3 v_neg(v3 a) { return V(-a.x, -a.y, -a.z); }
 /* a + b*s, fused */
 static inline v3 v_fma(v3 b, float s, v3 a) { return V(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z)); }
 static inline float v_dot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
-static inline v3 v_normalize(v3 a) { return v_scale(a, f_rcp(sqrtf(v_dot(a, a)))); }
+static inline v3 v_normalize(v3 a) { return v_scale(a, f_rsqrt(v_dot(a, a))); }
 static inline v3 v_mix(v3 x, v3 y, float a)
 {
     float ia = 1.0f - a;
@@ -214,15 +245,17 @@ static rgb env_texel_wrapped(const Ctx *c, int face, int ix, int iy)
     if (ix >= 0 && ix < S && iy >= 0 && iy < S) return env_texel(c, face, ix, iy);
     /* texel centre in face coordinates, then re-project through 3D onto the neighbour face */
     float fs = (float)S;
-    float sc = ((float)ix + 0.5f) / fs * 2.0f - 1.0f;
-    float tc = ((float)iy + 0.5f) / fs * 2.0f - 1.0f;
+    float rfs = 1.0f / fs; /* uniform */
+    float sc = ((float)ix + 0.5f) * rfs * 2.0f - 1.0f;
+    float tc = ((float)iy + 0.5f) * rfs * 2.0f - 1.0f;
     float x, y, z, ma, nsc, ntc;
     int nface;
     face_to_dir(face, sc, tc, &x, &y, &z);
     /* push the major axis below the overflowing one so the neighbour wins the selection */
     dir_to_face(x, y, z, &nface, &nsc, &ntc, &ma);
-    float u = (nsc / ma * 0.5f + 0.5f) * fs;
-    float v = (ntc / ma * 0.5f + 0.5f) * fs;
+    float rma = f_rcp(ma);
+    float u = (nsc * rma * 0.5f + 0.5f) * fs;
+    float v = (ntc * rma * 0.5f + 0.5f) * fs;
     int nx = (int)floorf(u), ny = (int)floorf(v);
     if (nx < 0) nx = 0; if (nx > S - 1) nx = S - 1;
     if (ny < 0) ny = 0; if (ny > S - 1) ny = S - 1;
@@ -234,7 +267,7 @@ static rgb sample_env(const Ctx *c, v3 d)
     int S = c->envSize, face;
     float sc, tc, ma;
     dir_to_face(d.x, d.y, d.z, &face, &sc, &tc, &ma);
-    float ima = 0.5f / ma;
+    float ima = 0.5f * f_rcp(ma);
     float fs = (float)S;
     float u = fmaf(sc, ima, 0.5f) * fs - 0.5f;
     float v = fmaf(tc, ima, 0.5f) * fs - 0.5f;
@@ -357,7 +390,7 @@ static int ray_trace(const Ctx *c, v3 o, v3 d, HitInfo *h, Stats *st)
         const float *s = ob + (size_t)winner * SPHERE_STRIDE;
         h->m = load_material(s + 4);
         v3 pc = v_sub(h->nearHitPos, V(s[0], s[1], s[2])); /* compute.glsl:316-319 GetNormal(Sphere) */
-        h->normal = V(pc.x / s[3], pc.y / s[3], pc.z / s[3]);
+        h->normal = v_scale(pc, 1.0f / s[3]); /* 1/radius: IEEE quotient, computed once per sphere */
     } else {
         const float *q = ob + CUBOIDS_OFFSET + (size_t)(winner - 256) * CUBOID_STRIDE;
         h->m = load_material(q + 8);
@@ -381,7 +414,7 @@ static v3 cosine_sample_hemisphere(v3 n, uint32_t *seed)
 /* compute.glsl:359-364 */
 static float fresnel_schlick(float cosTheta, float n1, float n2)
 {
-    float r0 = (n1 - n2) / (n1 + n2);
+    float r0 = (n1 - n2) * f_rcp(n1 + n2);
     r0 *= r0;
     return fmaf(1.0f - r0, f_pow5(1.0f - cosTheta), r0);
 }
@@ -416,7 +449,7 @@ static float bsdf(v3 *ro, v3 *rd, const HitInfo *h, int *isRefractive, uint32_t 
         *rd = v_normalize(v_mix(refl, diffuseRay, h->m.specularRoughness * h->m.specularRoughness));
         prob = spec;
     } else if (spec + refr > roll) {
-        v3 rf = f_refract(*rd, h->normal, h->fromInside ? (h->m.ior / 1.0f) : (1.0f / h->m.ior));
+        v3 rf = f_refract(*rd, h->normal, h->fromInside ? h->m.ior : f_rcp(h->m.ior));
         v3 rough = cosine_sample_hemisphere(v_neg(h->normal), seed);
         *rd = v_normalize(v_mix(rf, rough, h->m.refractionRoughness * h->m.refractionRoughness));
         prob = refr;
@@ -448,10 +481,10 @@ static v3 radiance(const Ctx *c, v3 ro, v3 rd, uint32_t *seed, Stats *st)
             rad = V(fmaf(h.m.emissiv.x, throughput.x, rad.x), fmaf(h.m.emissiv.y, throughput.y, rad.y),
                     fmaf(h.m.emissiv.z, throughput.z, rad.z));
             if (!isRefractive) throughput = v_mul(throughput, h.m.albedo);
-            throughput = V(throughput.x / prob, throughput.y / prob, throughput.z / prob);
+            throughput = v_scale(throughput, f_rcp(prob));
             float p = f_max(throughput.x, f_max(throughput.y, throughput.z));
             if (rand01(seed) > p) break;
-            throughput = V(throughput.x / p, throughput.y / p, throughput.z / p);
+            throughput = v_scale(throughput, f_rcp(p));
         } else {
             rgb e = sample_env(c, rd);
             if (st) st->envLookups++;
@@ -476,8 +509,8 @@ static void shade_pixel(const Ctx *c, int px, int py, int frame, const float *la
     v3 irr = V(0.0f, 0.0f, 0.0f);
     for (int s = 0; s < c->spp; s++) {
         float u0 = rand01(&seed), u1 = rand01(&seed); /* :113, x first */
-        float ndcx = fmaf(((float)px + u0) / (float)c->width, 2.0f, -1.0f);
-        float ndcy = fmaf(((float)py + u1) / (float)c->height, 2.0f, -1.0f);
+        float ndcx = fmaf(((float)px + u0) * (1.0f / (float)c->width), 2.0f, -1.0f);  /* uniform 1/W, 1/H */
+        float ndcy = fmaf(((float)py + u1) * (1.0f / (float)c->height), 2.0f, -1.0f);
         /* GetWorldSpaceRay :352-357 */
         float eye[4], wd[4];
         mat_vec(c->invProj, ndcx, ndcy, -1.0f, 0.0f, eye);
@@ -498,8 +531,7 @@ static void shade_pixel(const Ctx *c, int px, int py, int frame, const float *la
         if (st) st->samples++;
         irr = v_add(irr, radiance(c, ro, rd, &seed, st));
     }
-    float fspp = (float)c->spp;
-    irr = V(irr.x / fspp, irr.y / fspp, irr.z / fspp); /* :125 */
+    irr = v_scale(irr, 1.0f / (float)c->spp); /* :125, uniform reciprocal */
     float w = 1.0f / (float)(frame + 1);                  /* :128 */
     out[0] = f_mix(last[0], irr.x, w);
     out[1] = f_mix(last[1], irr.y, w);
