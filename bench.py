@@ -187,10 +187,14 @@ def main():
                        "kernel_variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(wl_key),
-                         "kernel": "pt_integrate_kernel", "kernel_ms": round(kernel_ms, 5),
+                         "kernel": "pt_integrate_persistent_kernel", "kernel_ms": round(kernel_ms, 5),
+                         "launches_per_step": 2 if args.variant == 0 else (args.variant // 10 if 20 <= args.variant < 50 else 1),
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "32 B/pixel/frame (float4 load + store of the accumulation image); the path is fp32-VALU "
-                                 "bound, see `valu`"},
+                         "note": "32 B/pixel/frame (float4 load + store of the accumulation image), summed over the step's "
+                                 "launches; kernel_ms = GPU time per step from HIP events on the library's streams. The "
+                                 "default variant renders a step as 2 row-stripe launches on 2 streams whose executions "
+                                 "overlap (rocprofv3's per-launch average is therefore longer than kernel_ms/2; run "
+                                 "--variant 14 for one launch per step). The path is fp32-VALU bound, see `valu`"},
             "present_ms": round(present_ms, 3),
             "checks": checks,
         }

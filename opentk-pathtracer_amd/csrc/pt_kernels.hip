@@ -638,9 +638,34 @@ PT_DEV int queue_pop_tile(BlockQueue *q, const FrameArgs &a, int numTiles)
     }
 }
 
-__global__ __launch_bounds__(256) void pt_integrate_persistent_kernel(const FrameArgs a)
+// ---- drain compaction.  When the frame's tiles are all handed out, every wavefront still holds up to 64 paths
+// of very different remaining length, and would spend ~5 more iterations mostly empty.  Instead, a draining
+// wavefront that is at most half full DONATES its live paths to a per-workgroup LDS pool and exits, and the
+// draining wavefronts that stay pull from that pool into their idle lanes — four thin wavefronts collapse into one
+// or two full ones.  A path is a self-contained record (pixel, RNG state, ray, throughput, radiance, sample /
+// bounce counters), so moving it to another lane changes nothing in its arithmetic: still bit-identical.
+struct PathState { // 80 bytes
+    int pix, pxy, counters; // counters = sample | bounce << 12 | needRay << 24
+    uint32_t seed;
+    float ro[3], rd[3], thr[3], rad[3], irr[3];
+    int pad;
+};
+constexpr int POOL_SLOTS = 96;  // <= 3 donors x DONATE_MAX paths per workgroup and launch
+constexpr int DONATE_MAX = 32;
+
+struct DrainControl {        // static LDS, one per workgroup
+    unsigned int pushed;     // pool entries [0, pushed) are published
+    unsigned int taken;      // pool entries [0, taken) are consumed
+    unsigned int alive;      // wavefronts that have neither exited nor committed to donate-and-exit
+    unsigned int pushing;    // donors between commit and publication
+    unsigned int lock;       // serialises donors
+    unsigned int pad[3];
+};
+
+__global__ __launch_bounds__(256, 5) void pt_integrate_persistent_kernel(const FrameArgs a)
 {
     __shared__ __attribute__((aligned(16))) BlockQueue queue; // 16 B: keeps the dynamic-LDS base 16-byte aligned
+    __shared__ __attribute__((aligned(16))) DrainControl drain; // 32 B
     const int numTiles = a.tilesX * a.tilesY;
     if (threadIdx.x == 0) { // the workgroup's first chunk is static: chunk index = workgroup index
         long long first = (long long)blockIdx.x * a.queueChunk;
@@ -649,15 +674,26 @@ __global__ __launch_bounds__(256) void pt_integrate_persistent_kernel(const Fram
         queue.pair = ((unsigned long long)last << 32) | (unsigned long long)first;
         queue.lock = 0u;
         queue.done = 0u;
+        drain.pushed = 0u;
+        drain.taken = 0u;
+        drain.alive = 4u;
+        drain.pushing = 0u;
+        drain.lock = 0u;
     }
     SceneLds sc = stage_scene(a); // ends with __syncthreads()
     EnvRef env{a.env, sc.lut, a.envSize, a.envFormat};
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // the ring lives behind the staged scene in dynamic LDS
-    RingEntry *ring = (RingEntry *)((char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat)) + wave * 64;
+    RingEntry *ringBase = (RingEntry *)((char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat));
+    RingEntry *ring = ringBase + wave * 64;
+    PathState *pool = (PathState *)(ringBase + 4 * 64);
+    volatile DrainControl *dc = &drain;
+    const bool compaction = a.drainCompaction != 0;
+    const bool leader = lane == 0;
 
     int avail = 0;           // wave-uniform: ring entries [0, avail) are unconsumed
     bool exhausted = false;
+    bool lastAlive = false;  // this wavefront found itself the last one of its workgroup: it can neither donate nor leave early
     unsigned long long tStart = 0, tExhausted = 0, nIter = 0;
     if (a.timeline) tStart = wall_clock64();
 
@@ -719,12 +755,106 @@ __global__ __launch_bounds__(256) void pt_integrate_persistent_kernel(const Fram
                 }
                 int n = __builtin_popcountll(m);
                 avail = n < avail ? avail - n : 0;
+            } else if (exhausted && compaction) {
+                // ---- drain: idle lanes adopt donated paths from the workgroup's pool
+                unsigned int pushed = dc->pushed, taken = dc->taken;
+                pushed = (unsigned int)__builtin_amdgcn_readfirstlane((int)pushed);
+                taken = (unsigned int)__builtin_amdgcn_readfirstlane((int)taken);
+                if (pushed > taken) {
+                    unsigned int want = (unsigned int)__builtin_popcountll(m), have = pushed - taken;
+                    unsigned int k = want < have ? want : have;
+                    unsigned int got = ~0u;
+                    if (leader) got = atomicCAS(&drain.taken, taken, taken + k);
+                    got = (unsigned int)__builtin_amdgcn_readfirstlane((int)got);
+                    if (got == taken) { // claimed entries [taken, taken + k)
+                        int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if (idle && (unsigned int)rank < k) {
+                            PathState st = pool[taken + rank];
+                            pix = st.pix;
+                            px = st.pxy & 0xffff;
+                            py = st.pxy >> 16;
+                            sample = st.counters & 0xfff;
+                            bounce = (st.counters >> 12) & 0xfff;
+                            needRay = (st.counters >> 24) & 1;
+                            seed = st.seed;
+                            ro = V(st.ro[0], st.ro[1], st.ro[2]);
+                            rd = V(st.rd[0], st.rd[1], st.rd[2]);
+                            throughput = V(st.thr[0], st.thr[1], st.thr[2]);
+                            rad = V(st.rad[0], st.rad[1], st.rad[2]);
+                            irr = V(st.irr[0], st.irr[1], st.irr[2]);
+                        }
+                    }
+                }
             }
         }
         bool active = pix >= 0;
-        if (!__any(active)) {
-            if (exhausted && avail == 0) break;
+        const unsigned long long am = __ballot(active);
+        if (am == 0ull) {
+            if (!(exhausted && avail == 0)) continue;
+            if (!compaction) break;
+            // ---- leaving: the last wavefront of the workgroup must outlive every donor and empty the pool
+            unsigned int old = 0;
+            if (leader) old = atomicSub(&drain.alive, 1u);
+            old = (unsigned int)__builtin_amdgcn_readfirstlane((int)old);
+            if (old > 1u) break;
+            lastAlive = true;
+            unsigned int pushing = dc->pushing, pushed = dc->pushed, taken = dc->taken;
+            bool pending = __builtin_amdgcn_readfirstlane((int)(pushing != 0u || pushed != taken)) != 0;
+            if (!pending) break;
+            if (leader) atomicAdd(&drain.alive, 1u);
+            __builtin_amdgcn_s_sleep(1);
             continue;
+        }
+        if (compaction && exhausted && avail == 0 && !lastAlive && __builtin_popcountll(am) <= DONATE_MAX) {
+            // ---- donate: commit (pushing++, alive--), publish the live paths under the donor lock, exit
+            unsigned int old = 0, base = 0;
+            if (leader) {
+                atomicAdd(&drain.pushing, 1u);
+                old = atomicSub(&drain.alive, 1u);
+            }
+            old = (unsigned int)__builtin_amdgcn_readfirstlane((int)old);
+            bool committed = old > 1u;
+            if (committed) {
+                if (leader) {
+                    while (atomicCAS(&drain.lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+                    base = dc->pushed;
+                }
+                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                unsigned int n = (unsigned int)__builtin_popcountll(am);
+                if (base + n <= (unsigned int)POOL_SLOTS) {
+                    int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
+                    if (active) {
+                        PathState st;
+                        st.pix = pix;
+                        st.pxy = px | (py << 16);
+                        st.counters = sample | (bounce << 12) | ((needRay ? 1 : 0) << 24);
+                        st.seed = seed;
+                        st.ro[0] = ro.x; st.ro[1] = ro.y; st.ro[2] = ro.z;
+                        st.rd[0] = rd.x; st.rd[1] = rd.y; st.rd[2] = rd.z;
+                        st.thr[0] = throughput.x; st.thr[1] = throughput.y; st.thr[2] = throughput.z;
+                        st.rad[0] = rad.x; st.rad[1] = rad.y; st.rad[2] = rad.z;
+                        st.irr[0] = irr.x; st.irr[1] = irr.y; st.irr[2] = irr.z;
+                        st.pad = 0;
+                        pool[base + rank] = st;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (leader) {
+                        dc->pushed = base + n;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        atomicExch(&drain.lock, 0u);
+                        atomicSub(&drain.pushing, 1u);
+                    }
+                    break; // this wavefront is done; its paths live on in the pool
+                }
+                // pool full (cannot happen with <= 3 donors x DONATE_MAX, kept for safety): withdraw the commit
+                if (leader) atomicExch(&drain.lock, 0u);
+            } else {
+                lastAlive = true;
+            }
+            if (leader) {
+                atomicAdd(&drain.alive, 1u);
+                atomicSub(&drain.pushing, 1u);
+            }
         }
         nIter++;
         if (active && needRay) { // only for spp > 1: the next sample continues the pixel's RNG stream (compute.glsl:110)
@@ -788,7 +918,7 @@ hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int
         int numChunks = (tiles + a.queueChunk - 1) / a.queueChunk;
         if (nwg > numChunks) nwg = numChunks;
         if (nwg < 1) nwg = 1;
-        size_t ldsTotal = lds + 4 * 64 * sizeof(RingEntry);
+        size_t ldsTotal = lds + 4 * 64 * sizeof(RingEntry) + POOL_SLOTS * sizeof(PathState);
         hipLaunchKernelGGL(pt_integrate_persistent_kernel, dim3(nwg), dim3(256), ldsTotal, stream, a);
         // every workgroup draws tickets until its first failing one: (numChunks - nwg) successful + nwg failing
         *ticketsConsumed = (unsigned int)(numChunks > nwg ? numChunks : nwg);
