@@ -12,8 +12,8 @@ exactly as in the reference (src/Render/PathTracer.cs:114-123).
 N = 1 runs BASELINE.json configs[1]: default scene (48 spheres + 7 cuboids), 1920x1080, 8 bounces, 1 spp, the
 reference's default environment (256^2 RGBA32F atmosphere cube, computed by the atmosphere kernel).
 N > 1 is WEAK scaling: the 16:9 image grows to ~N x 2.07 Mpixel (N=4 is BASELINE configs[3]'s 3840x2160) and is
-tiled in contiguous row blocks, one per rank, no data-path collective; the RCCL gather happens only at present
-time and is timed separately (`present_ms`).  value = all pixels x spp x steps / max-over-ranks wall time.
+tiled across ranks in block-cyclic 16-row bands (balanced: floor rows cost ~2x sky rows), no data-path collective; the
+RCCL gather happens only at present time and is timed separately (`present_ms`).  value = all pixels x spp x steps / max-over-ranks wall time.
 
 The JSON line also carries
   roofline     : the integrator kernel against the HBM roof, from ALGORITHMIC bytes (32 B per pixel per frame: one
@@ -132,8 +132,9 @@ def main():
         pt.EnvironmentMap = pkg.envmap.synthetic_sky_rgba32f(64)
     pt.UploadScene(scene)
     pt.UploadBasicData(basic)
-    tile = D.attach_tile(pt, H, rank, world, device=torch.device("cuda", local))
-    y0, rows = D.row_block(H, rank, world)
+    BAND = 16  # block-cyclic 16-row bands across ranks: row cost varies ~2x between sky and floor rows
+    tile = D.attach_tile(pt, H, rank, world, device=torch.device("cuda", local), band_rows=BAND)
+    rows = pt.rows
 
     def sync_all():
         pt.Synchronize()
@@ -144,7 +145,7 @@ def main():
     for _ in range(args.warmup):
         pt.Render()
     if world > 1:  # first RCCL call (communicator setup) outside the timed region; also validates the gather
-        D.present(tile, H, rank, world)
+        D.present(tile, H, rank, world, band_rows=BAND)
     sync_all()
 
     t0 = time.perf_counter()
@@ -156,7 +157,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     t1 = time.perf_counter()
-    full = D.present(tile, H, rank, world)
+    full = D.present(tile, H, rank, world, band_rows=BAND)
     torch.cuda.synchronize()
     present_ms = (time.perf_counter() - t1) * 1e3
 
@@ -182,8 +183,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} scene ({scene.num_spheres} spheres + {scene.num_cuboids} cuboids), {W}x{H}, "
                                    f"{args.depth} bounces, {args.spp} spp, progressive accumulate, env {args.env}, "
-                                   f"row blocks of {rows} rows per GPU" + ("" if world > 1 else " (BASELINE configs[1])"),
-                       "image": [W, H], "ray_depth": args.depth, "spp": args.spp, "parallelism": f"rowtile{world}",
+                                   + (f"{rows} rows per GPU in block-cyclic {BAND}-row bands" if world > 1
+                                      else "one GPU (BASELINE configs[1])"),
+                       "image": [W, H], "ray_depth": args.depth, "spp": args.spp, "parallelism": f"rowbands{world}",
                        "kernel_variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(wl_key),

@@ -75,6 +75,11 @@ PT_API int pt_set_size(pt_handle h, int width, int height);
  * coordinates, so tiled and untiled renders are bit-identical.  Resets the frame counter and zeroes. */
 PT_API int pt_set_tile(pt_handle h, int y0, int rows);
 
+/* Block-cyclic variant of pt_set_tile for load balance across GPUs (rows near the floor cost ~2x sky rows): this handle
+ * owns the bands rank, rank + world, rank + 2*world, ... of band_rows image rows each (band_rows a multiple of 8) and
+ * stores them compactly, band after band.  Same bit-identical pixels; resets the frame counter and zeroes. */
+PT_API int pt_set_interleaved_tile(pt_handle h, int rank, int world, int band_rows);
+
 /* PathTracer.ResetRenderer — PathTracer.cs:137-140: frame counter = 0 (image contents are irrelevant then). */
 PT_API int pt_reset(pt_handle h);
 

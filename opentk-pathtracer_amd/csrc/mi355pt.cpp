@@ -33,6 +33,7 @@ struct pt_renderer {
     int device = 0;
     int width = 0, height = 0;
     int y0 = 0, rows = 0;
+    int bandRows = 0, bandWorld = 1, bandRank = 0; // block-cyclic row ownership (pt_set_interleaved_tile)
     int numSpheres = 0, numCuboids = 0, rayDepth = 1, spp = 1;
     float focalLength = 0.0f, apertureDiameter = 0.0f;
     int frame = 0; // thisRenderNumFrame, PathTracer.cs:113
@@ -270,6 +271,7 @@ PT_API int pt_set_size(pt_handle h, int width, int height)
     h->height = height;
     h->y0 = 0;
     h->rows = height;
+    h->bandRows = 0;
     h->frame = 0; // PathTracer.cs:133
     if (int rc = ensure_accum(h)) return rc;
     return clear_accum(h);
@@ -282,6 +284,30 @@ PT_API int pt_set_tile(pt_handle h, int y0, int rows)
     if (int rc = bind_device(h)) return rc;
     h->y0 = y0;
     h->rows = rows;
+    h->bandRows = 0;
+    h->frame = 0;
+    if (int rc = ensure_accum(h)) return rc;
+    return clear_accum(h);
+}
+
+PT_API int pt_set_interleaved_tile(pt_handle h, int rank, int world, int band_rows)
+{
+    PT_CHECK_HANDLE(h);
+    if (world < 1 || rank < 0 || rank >= world || band_rows < 8 || (band_rows & 7))
+        return fail(h, PT_E_BAD_ARGUMENT, "need 0 <= rank < world and band_rows a positive multiple of 8");
+    if (int rc = bind_device(h)) return rc;
+    // rows owned: bands rank, rank + world, ... of band_rows rows (the last band of the image may be partial)
+    long long rows = 0;
+    for (long long b = rank; b * band_rows < h->height; b += world) {
+        long long top = (b + 1) * band_rows;
+        rows += (top < h->height ? top : h->height) - b * band_rows;
+    }
+    if (rows <= 0) return fail(h, PT_E_BAD_ARGUMENT, "this rank owns no rows (image too small for world * band_rows)");
+    h->y0 = 0;
+    h->rows = (int)rows;
+    h->bandRows = band_rows;
+    h->bandWorld = world;
+    h->bandRank = rank;
     h->frame = 0;
     if (int rc = ensure_accum(h)) return rc;
     return clear_accum(h);
@@ -387,6 +413,10 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     a.env = h->dEnv;
     a.srgbLut = h->dLut;
     a.tilesX = (h->width + 7) / 8;
+    a.bandRows = h->bandRows;
+    a.bandWorld = h->bandWorld;
+    a.bandRank = h->bandRank;
+    a.localRow0 = 0;
     a.numCUs = h->numCUs;
     a.queueChunk = h->queueChunk;
     a.drainCompaction = h->drainCompaction;
@@ -421,6 +451,7 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
             if (j + 1 < stripes) r1 &= ~7;
             if (r1 <= r0) continue;
             a.y0 = h->y0 + r0;
+            a.localRow0 = r0;
             a.rows = r1 - r0;
             a.accum = h->accum() + (size_t)r0 * h->width;
             a.tilesY = (a.rows + 7) / 8;

@@ -404,6 +404,15 @@ PT_DEV void primary_ray(const FrameArgs &a, int px, int py, uint32_t &seed, v3 &
     rd = v_normalize(v_sub(focal, ro));
 }
 
+// image row of local row `ly` of this launch (contiguous row block, or block-cyclic bands across GPUs)
+PT_DEV int global_row(const FrameArgs &a, int ly)
+{
+    if (a.bandRows == 0) return a.y0 + ly;
+    int l = a.localRow0 + ly;
+    int band = l / a.bandRows;
+    return (band * a.bandWorld + a.bandRank) * a.bandRows + (l - band * a.bandRows);
+}
+
 PT_DEV uint32_t pixel_seed(int px, int py, int frame)
 {
     return ((uint32_t)px * 1973u + (uint32_t)py * 9277u + (uint32_t)frame * 2699u) | 1u; // compute.glsl:106
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(256) void pt_integrate_kernel(const FrameArgs a)
     if (px >= a.width || ly >= a.rows) return;
     const size_t idx = (size_t)ly * a.width + px;
     float4 last = a.accum[idx];                                  // imageLoad  (compute.glsl:126)
-    a.accum[idx] = shade_pixel(a, sc, env, px, a.y0 + ly, last); // imageStore (compute.glsl:129)
+    a.accum[idx] = shade_pixel(a, sc, env, px, global_row(a, ly), last); // imageStore (compute.glsl:129)
 }
 
 // ---- variants 2..6: wave-level pixel pool with path regeneration.
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(256) void pt_integrate_pool_kernel(const FrameArgs 
                 int x = tx * 8 + (q & 7), ly = ty * 8 + (q >> 3);
                 if (x < a.width && ly < a.rows) { // ragged right/bottom tiles: skip the pixel, stay idle
                     px = x;
-                    py = a.y0 + ly;
+                    py = global_row(a, ly);
                     pix = ly * a.width + x;
                     seed = pixel_seed(px, py, a.frame);
                     sample = 0;
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_persistent_kernel(const F
                     e.pix = -1;
                     e.pxy = 0; e.seed = 0; e.ox = e.oy = e.oz = e.dx = e.dy = e.dz = 0.0f; e.pad = 0;
                     if (x < a.width && ly < a.rows) {
-                        int gy = a.y0 + ly;
+                        int gy = global_row(a, ly);
                         uint32_t sd = pixel_seed(x, gy, a.frame);
                         v3 o, d;
                         primary_ray(a, x, gy, sd, o, d);

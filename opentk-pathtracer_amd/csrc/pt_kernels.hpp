@@ -15,6 +15,11 @@ struct FrameArgs {
     float focalLength, apertureDiameter; // compute.glsl:93-94
     int width, height; // full image size: imageSize(ImgResult) (compute.glsl:103)
     int y0, rows;      // row block owned by this GPU (multi-GPU tiling); y0=0, rows=height on one GPU
+    // interleaved (block-cyclic) ownership for load balance across GPUs: when bandRows > 0 this GPU owns the bands
+    // b = bandRank, bandRank + bandWorld, ... of bandRows image rows each, stored compactly; local row l (counted from
+    // the start of the GPU's storage, localRow0 = first local row of this launch) is image row
+    // ((l / bandRows) * bandWorld + bandRank) * bandRows + l % bandRows.  bandRows == 0: image row = y0 + local row.
+    int bandRows, bandWorld, bandRank, localRow0;
     int numSpheres, numCuboids; // uboGameObjectsSize (compute.glsl:88)
     int rayDepth, spp; // compute.glsl:90-91
     int frame;         // thisRendererFrame (compute.glsl:96)

@@ -26,6 +26,22 @@ def max_rows(height: int, world: int) -> int:
     return max(row_block(height, r, world)[1] for r in range(world))
 
 
+def interleaved_rows(height: int, rank: int, world: int, band_rows: int) -> list[int]:
+    """Image rows owned by `rank` under block-cyclic ownership (pt_set_interleaved_tile), in storage order: bands
+    rank, rank + world, ... of `band_rows` rows each.  Row cost varies ~2x between sky and floor rows, so contiguous
+    blocks leave the GPU with the floor rows as the straggler; interleaving 16-row bands balances the ranks."""
+    rows = []
+    b = rank
+    while b * band_rows < height:
+        rows.extend(range(b * band_rows, min((b + 1) * band_rows, height)))
+        b += world
+    return rows
+
+
+def max_interleaved_rows(height: int, world: int, band_rows: int) -> int:
+    return max(len(interleaved_rows(height, r, world, band_rows)) for r in range(world))
+
+
 def init_from_env(backend: str | None = None):
     """Initialise torch.distributed from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
     backend 'nccl' is RCCL on ROCm; falls back to 'gloo' only when there is no GPU (CPU tests)."""
@@ -49,21 +65,26 @@ def init_from_env(backend: str | None = None):
     return rank, world, local
 
 
-def attach_tile(tracer, height: int, rank: int, world: int, device=None):
-    """Give `tracer` (a PathTracer) its row block and a torch-owned accumulation buffer padded to the largest
-    block, so that all ranks gather equal-sized tensors.  Returns the (max_rows, W, 4) float32 tensor."""
+def attach_tile(tracer, height: int, rank: int, world: int, device=None, band_rows: int = 0):
+    """Give `tracer` (a PathTracer) its rows (a contiguous block, or block-cyclic bands when band_rows > 0) and a
+    torch-owned accumulation buffer padded to the largest share, so that all ranks gather equal-sized tensors.
+    Returns the (max_rows, W, 4) float32 tensor."""
     import torch
 
-    y0, rows = row_block(height, rank, world)
-    tracer.SetTile(y0, rows)
-    pad = max_rows(height, world)
+    if band_rows and world > 1:
+        tracer.SetInterleavedTile(rank, world, band_rows)
+        pad = max_interleaved_rows(height, world, band_rows)
+    else:
+        y0, rows = row_block(height, rank, world)
+        tracer.SetTile(y0, rows)
+        pad = max_rows(height, world)
     buf = torch.zeros((pad, tracer.Width, 4), dtype=torch.float32, device=device if device is not None else "cuda")
     tracer.BindResultBuffer(buf.data_ptr(), buf.numel() * 4)
     return buf
 
 
-def present(tile, height: int, rank: int, world: int, dst: int = 0):
-    """Gather the row blocks on rank `dst` and return the assembled (height, W, 4) tensor there (None elsewhere).
+def present(tile, height: int, rank: int, world: int, dst: int = 0, band_rows: int = 0):
+    """Gather the ranks' rows on rank `dst` and return the assembled (height, W, 4) tensor there (None elsewhere).
     `tile` is this rank's (max_rows, W, 4) tensor (CPU tensor with gloo, CUDA tensor with nccl/RCCL)."""
     import torch
     import torch.distributed as dist
@@ -75,8 +96,13 @@ def present(tile, height: int, rank: int, world: int, dst: int = 0):
         dist.gather(tile, gather_list=parts, dst=dst)
         out = torch.empty((height,) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
         for r in range(world):
-            y0, rows = row_block(height, r, world)
-            out[y0:y0 + rows] = parts[r][:rows]
+            if band_rows:
+                rows = interleaved_rows(height, r, world, band_rows)
+                idx = torch.as_tensor(rows, dtype=torch.long, device=tile.device)
+                out.index_copy_(0, idx, parts[r][:len(rows)])
+            else:
+                y0, n = row_block(height, r, world)
+                out[y0:y0 + n] = parts[r][:n]
         return out
     dist.gather(tile, gather_list=None, dst=dst)
     return None

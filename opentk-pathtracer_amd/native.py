@@ -100,6 +100,7 @@ def load() -> C.CDLL:
         "pt_destroy": [vp],
         "pt_set_size": [vp, C.c_int, C.c_int],
         "pt_set_tile": [vp, C.c_int, C.c_int],
+        "pt_set_interleaved_tile": [vp, C.c_int, C.c_int, C.c_int],
         "pt_reset": [vp],
         "pt_set_params": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float],
         "pt_upload_basic_data": [vp, C.c_int, C.c_int, vp],

@@ -135,6 +135,11 @@ class PathTracer:
         check(self._lib.pt_set_tile(self._h, y0, rows), self._h)
         self.y0, self.rows = y0, rows
 
+    def SetInterleavedTile(self, rank: int, world: int, band_rows: int) -> None:
+        check(self._lib.pt_set_interleaved_tile(self._h, rank, world, band_rows), self._h)
+        from .distributed import interleaved_rows
+        self.y0, self.rows = 0, len(interleaved_rows(self.Height, rank, world, band_rows))
+
     @property
     def Result(self) -> np.ndarray:
         """The RGBA32F `Result` image of this tile, read back to the host: (rows, Width, 4), row 0 = image row y0."""
@@ -233,6 +238,11 @@ class AtmosphericScatterer:
         lp = np.ascontiguousarray(self.LightPos, dtype=np.float32)
         check(t._lib.pt_atmosphere_render(t._h, self.Size, self.ISteps, self.JSteps,
                                           lp.ctypes.data_as(C.POINTER(C.c_float)), max(self.LightIntensity, 0.0)), t._h)
+
+    def SetInterleavedTile(self, rank: int, world: int, band_rows: int) -> None:
+        check(self._lib.pt_set_interleaved_tile(self._h, rank, world, band_rows), self._h)
+        from .distributed import interleaved_rows
+        self.y0, self.rows = 0, len(interleaved_rows(self.Height, rank, world, band_rows))
 
     @property
     def Result(self) -> np.ndarray:

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, height, out_path):
+def _worker(rank, world, port, height, out_path, band=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch as t
@@ -41,11 +41,22 @@ def _worker(rank, world, port, height, out_path):
     wl = cfg.Workload("t", "default", 64, height, 5, "sky_f32_32")
     sc, basic, objs, env, kw = cfg.inputs(wl)
     oracle = graft.load_oracle().Oracle()
-    y0, rows = D.row_block(height, rank, world)
-    tile = t.zeros((D.max_rows(height, world), wl.width, 4), dtype=t.float32)
-    img = oracle.render(wl.width, wl.height, basic, objs, env, num_frames=2, y0=y0, rows=rows, threads=2, **kw)
-    tile[:rows] = t.from_numpy(img)
-    full = D.present(tile, height, rank, world, dst=0)
+    if band:
+        mine = D.interleaved_rows(height, rank, world, band)
+        tile = t.zeros((D.max_interleaved_rows(height, world, band), wl.width, 4), dtype=t.float32)
+        off = 0
+        for b0 in range(rank * band, height, world * band):  # one oracle call per owned band
+            n = min(band, height - b0)
+            img = oracle.render(wl.width, wl.height, basic, objs, env, num_frames=2, y0=b0, rows=n, threads=2, **kw)
+            tile[off:off + n] = t.from_numpy(img)
+            off += n
+        assert off == len(mine)
+    else:
+        y0, rows = D.row_block(height, rank, world)
+        tile = t.zeros((D.max_rows(height, world), wl.width, 4), dtype=t.float32)
+        img = oracle.render(wl.width, wl.height, basic, objs, env, num_frames=2, y0=y0, rows=rows, threads=2, **kw)
+        tile[:rows] = t.from_numpy(img)
+    full = D.present(tile, height, rank, world, dst=0, band_rows=band)
     if rank == 0:
         np.save(out_path, full.numpy())
     else:
@@ -54,11 +65,11 @@ def _worker(rank, world, port, height, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height", [(2, 36), (3, 37)])
-def test_tiled_present_over_gloo(tmp_path, oracle, world, height):
+@pytest.mark.parametrize("world,height,band", [(2, 36, 0), (3, 37, 0), (2, 43, 8)])
+def test_tiled_present_over_gloo(tmp_path, oracle, world, height, band):
     out = str(tmp_path / "full.npy")
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, height, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, height, out, band), nprocs=world, join=True)
     got = np.load(out)
     wl = configs.Workload("t", "default", 64, height, 5, "sky_f32_32")
     sc, basic, objs, env, kw = configs.inputs(wl)

@@ -345,3 +345,27 @@ def test_many_consecutive_frames_queue_accounting(pkg, native_lib, oracle):
     tickets the host accounts for): 48 consecutive frames, then bit-compare the accumulation with the oracle."""
     w = configs.Workload("queue", "default", 416, 234, 8, "sky_f32_32")
     assert_bit_exact(hip_render(pkg, w, frames=48), oracle_render(oracle, w, frames=48), "48 frames")
+
+
+@pytest.mark.parametrize("w,world,band", [(configs.C2, 8, 16), (configs.Workload("odd", "default", 333, 211, 8, "sky_f32_32"), 3, 8)],
+                         ids=["1080p/8x16", "odd/3x8"])
+def test_interleaved_tiling_is_bit_identical(pkg, native_lib, w, world, band):
+    """Block-cyclic ownership (pt_set_interleaved_tile), emulated on one GPU: each rank's compact band storage, scattered
+    back to image rows, reproduces the untiled render bit for bit."""
+    from opentk_pathtracer_amd import distributed as D
+    sc, basic, objs, env, kw = configs.inputs(w)
+    full = hip_render(pkg, w, frames=2)
+    out = np.zeros_like(full)
+    for r in range(world):
+        pt = pkg.PathTracer(env, w.width, w.height, w.ray_depth, w.spp, w.focal_length, w.aperture)
+        pt.UploadScene(sc)
+        pt.UploadBasicData(basic)
+        pt.SetInterleavedTile(r, world, band)
+        pt.Render()
+        pt.Render()
+        rows = D.interleaved_rows(w.height, r, world, band)
+        part = pt.Result
+        assert part.shape[0] == len(rows)
+        out[rows] = part
+        pt.Dispose()
+    assert np.array_equal(bits(out), bits(full))

@@ -101,6 +101,14 @@ def test_row_blocks_cover_image(pkg):
         assert max(b[1] for b in blocks) - min(b[1] for b in blocks) <= 1
         assert D.max_rows(h, g) == max(b[1] for b in blocks)
     assert D.row_block(2160, 3, 8) == (810, 270)
+    # block-cyclic ownership (pt_set_interleaved_tile): every row exactly once, shares differ by at most one band
+    for h, g, band in [(1080, 8, 16), (3060, 8, 16), (1530, 2, 8), (75, 4, 8), (2160, 3, 24)]:
+        shares = [D.interleaved_rows(h, r, g, band) for r in range(g)]
+        allrows = sorted(y for sh in shares for y in sh)
+        assert allrows == list(range(h))
+        assert max(len(sh) for sh in shares) - min(len(sh) for sh in shares) <= band
+        assert D.max_interleaved_rows(h, g, band) == max(len(sh) for sh in shares)
+        assert shares[1][:band] == list(range(band, min(2 * band, h)))
 
 
 # ------------------------------------------------------------------------------------------------ C ABI (no GPU here)
