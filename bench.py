@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--env", default="atmosphere256", choices=["atmosphere256", "sky2048", "sky64"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="debug: all ranks use cuda:0 and rendezvous over gloo (validates the N>1 logic on a 1-GPU box; "
+                         "RCCL cannot put two ranks on one device)")
     args = ap.parse_args()
 
     pkg = graft.load_package()
@@ -110,7 +113,10 @@ def main():
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != args.gpus and world_env > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
-    rank, world, local = D.init_from_env() if args.gpus > 1 else (0, 1, int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, local = (D.init_from_env(backend="gloo" if args.share_gpu else None) if args.gpus > 1
+                          else (0, 1, int(os.environ.get("LOCAL_RANK", "0"))))
+    if args.share_gpu:
+        local = 0
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -136,6 +142,12 @@ def main():
     tile = D.attach_tile(pt, H, rank, world, device=torch.device("cuda", local), band_rows=BAND)
     rows = pt.rows
 
+    def gather_image():
+        if args.share_gpu and world > 1:  # gloo cannot gather CUDA tensors: stage through the host
+            out = D.present(tile.cpu(), H, rank, world, band_rows=BAND)
+            return out.cuda() if out is not None else None
+        return D.present(tile, H, rank, world, band_rows=BAND)
+
     def sync_all():
         pt.Synchronize()
         torch.cuda.synchronize()
@@ -145,7 +157,7 @@ def main():
     for _ in range(args.warmup):
         pt.Render()
     if world > 1:  # first RCCL call (communicator setup) outside the timed region; also validates the gather
-        D.present(tile, H, rank, world, band_rows=BAND)
+        gather_image()
     sync_all()
 
     t0 = time.perf_counter()
@@ -157,11 +169,11 @@ def main():
     elapsed = time.perf_counter() - t0
 
     t1 = time.perf_counter()
-    full = D.present(tile, H, rank, world, band_rows=BAND)
+    full = gather_image()
     torch.cuda.synchronize()
     present_ms = (time.perf_counter() - t1) * 1e3
 
-    times = torch.tensor([elapsed, kernel_ms_total / 1e3], dtype=torch.float64, device="cuda")
+    times = torch.tensor([elapsed, kernel_ms_total / 1e3], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     elapsed_max, kernel_s_max = (float(v) for v in times.cpu())
