@@ -39,16 +39,21 @@ kstats = [r for r in csv.DictReader(open(os.path.join(src, "stats", "stats_kerne
 bench = json.load(open(os.path.join(src, "bench.json"))) if os.path.exists(os.path.join(src, "bench.json")) else {}
 W, H = bench.get("config", {}).get("image", [1920, 1080])
 pixels = W * H
+# a step (frame) may be several launches (row stripes on separate streams): counters are averaged per launch above,
+# so scale them to per-step values before comparing with per-frame byte counts
+L = int(bench.get("roofline", {}).get("launches_per_step", 1))
+pmc = {k: v * L for k, v in pmc.items()}
+cal = {k: (v * L if v else v) for k, v in cal.items()}
 # calibration: the depth-0 launch reads 16 B and writes 16 B per pixel, nothing else of size
 known = 16.0 * pixels
 fetch_factor = known / (cal["FETCH_SIZE"] * 1024.0) if cal["FETCH_SIZE"] else None
 write_factor = known / (cal["WRITE_SIZE"] * 1024.0) if cal["WRITE_SIZE"] else None
 summary = {
-    "tag": tag, "workload": key,
+    "tag": tag, "workload": key, "launches_per_step": L,
     "kernel_avg_ns_rocprof": float(kstats[0]["AverageNs"]) if kstats else None,
     "kernel_calls": int(kstats[0]["Calls"]) if kstats else None,
     "bench_kernel_ms_hip_events": bench.get("roofline", {}).get("kernel_ms"),
-    "pmc_mean_per_launch": pmc,
+    "pmc_mean_per_step": pmc,
     "calibration_depth0": {"known_bytes_each_way": known, "FETCH_SIZE_KiB": cal["FETCH_SIZE"], "WRITE_SIZE_KiB": cal["WRITE_SIZE"],
                            "fetch_bytes_per_counted_byte": fetch_factor, "write_bytes_per_counted_byte": write_factor},
 }
@@ -57,7 +62,7 @@ if pmc.get("FETCH_SIZE") and pmc.get("WRITE_SIZE") and fetch_factor and write_fa
     # our own access pattern (calibration above) is applied instead of assuming it.
     rd = pmc["FETCH_SIZE"] * 1024.0 * fetch_factor
     wr = pmc["WRITE_SIZE"] * 1024.0 * write_factor
-    summary["hbm_traffic_bytes_per_launch"] = {"read": rd, "write": wr, "total": rd + wr,
+    summary["hbm_traffic_bytes_per_step"] = {"read": rd, "write": wr, "total": rd + wr,
                                                "algorithmic": 32.0 * pixels, "ratio_to_algorithmic": (rd + wr) / (32.0 * pixels)}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     t = json.load(open(tpath)) if os.path.exists(tpath) else {}
