@@ -47,12 +47,13 @@ struct SceneLds {
     const float4 *cmin; // [numCuboids]
     const float4 *cmax; // [numCuboids]
     const float4 *mat;  // [(numSpheres + numCuboids) * 4]
+    const float *invr;  // [numSpheres rounded up to 4] 1 / radius (IEEE quotient, computed once per workgroup)
     const float *lut;   // [256] sRGB8 -> linear (only staged for SRGB8_A8 environments)
 };
 
 __host__ __device__ inline size_t scene_lds_bytes(int ns, int nc, int envFormat)
 {
-    return (size_t)(ns + 2 * nc + 4 * (ns + nc)) * 16 + (envFormat == 1 ? 1024 : 0);
+    return (size_t)(ns + 2 * nc + 4 * (ns + nc)) * 16 + (size_t)((ns + 3) & ~3) * 4 + (envFormat == 1 ? 1024 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------- environment
@@ -261,7 +262,7 @@ PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h)
         float4 s = sc.sph[winner];
         h.m = load_material(sc.mat + 4 * winner);
         v3 pc = V(h.nearHitPos.x - s.x, h.nearHitPos.y - s.y, h.nearHitPos.z - s.z);
-        h.normal = v_scale(pc, f_div_ieee(1.0f, s.w)); // compute.glsl:316-319; 1/radius = IEEE quotient
+        h.normal = v_scale(pc, sc.invr[winner]); // compute.glsl:316-319; 1/radius = IEEE quotient staged in LDS
     } else {
         int ci = winner - 256;
         float4 mn = sc.cmin[ci], mx = sc.cmax[ci];
@@ -316,20 +317,26 @@ PT_DEV float bsdf(v3 &ro, v3 &rd, const Hit &h, bool &isRefractive, uint32_t &se
     v3 diffuseRay = cosine_sample_hemisphere(h.normal, seed);
     float prob;
     float roll = rand01(seed);
+    // the specular and the refractive lobe both end in normalize(mix(...)); the mix is evaluated per lobe and the
+    // normalisation once for whichever lobe the lane took (same arithmetic per lane, one code instance per wave)
+    v3 raw = diffuseRay;
+    bool lobe = false;
     if (spec > roll) {
         v3 refl = f_reflect(rd, h.normal);
-        rd = v_normalize(v_mix(refl, diffuseRay, h.m.specularRoughness * h.m.specularRoughness));
+        raw = v_mix(refl, diffuseRay, h.m.specularRoughness * h.m.specularRoughness);
         prob = spec;
+        lobe = true;
     } else if (spec + refr > roll) {
         v3 rf = f_refract(rd, h.normal, h.fromInside ? h.m.ior : f_rcp(h.m.ior));
         v3 rough = cosine_sample_hemisphere(v_neg(h.normal), seed);
-        rd = v_normalize(v_mix(rf, rough, h.m.refractionRoughness * h.m.refractionRoughness));
+        raw = v_mix(rf, rough, h.m.refractionRoughness * h.m.refractionRoughness);
         prob = refr;
         isRefractive = true;
+        lobe = true;
     } else {
-        rd = diffuseRay;
         prob = 1.0f - spec - refr;
     }
+    rd = lobe ? v_normalize(raw) : raw;
     ro = v_fma(rd, EPSILON, h.nearHitPos);
     return f_max(prob, EPSILON);
 }
@@ -451,14 +458,19 @@ PT_DEV SceneLds stage_scene(const FrameArgs &a)
     float4 *cmin = sph + ns;
     float4 *cmax = cmin + nc;
     float4 *mat = cmax + nc;
-    float *lut = (float *)(mat + 4 * (ns + nc));
+    float *invr = (float *)(mat + 4 * (ns + nc));
+    float *lut = invr + ((ns + 3) & ~3);
     const int tid = threadIdx.x;
     const float4 *obj = (const float4 *)a.objects;
     for (int i = tid; i < ns * 5; i += 256) {
         int s = i / 5, part = i - s * 5;
         float4 v = obj[i];
-        if (part == 0) sph[s] = v;
-        else mat[4 * s + part - 1] = v;
+        if (part == 0) {
+            sph[s] = v;
+            invr[s] = f_div_ieee(1.0f, v.w);
+        } else {
+            mat[4 * s + part - 1] = v;
+        }
     }
     for (int i = tid; i < nc * 6; i += 256) {
         int c = i / 6, part = i - c * 6;
@@ -469,7 +481,7 @@ PT_DEV SceneLds stage_scene(const FrameArgs &a)
     }
     if (a.envFormat == 1) lut[tid] = a.srgbLut[tid];
     __syncthreads();
-    return SceneLds{sph, cmin, cmax, mat, lut};
+    return SceneLds{sph, cmin, cmax, mat, invr, lut};
 }
 
 // XCD-aware workgroup id: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, so id b is

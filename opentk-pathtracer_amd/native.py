@@ -14,7 +14,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(HERE, "libmi355pt.so")
+LIB_PATH = os.environ.get("MI355PT_LIB") or os.path.join(HERE, "libmi355pt.so")  # MI355PT_LIB: A/B tuning builds
 HEADER = os.path.join(REPO, "include", "mi355pt.h")
 SOURCES = ["pt_kernels.hip", "mi355pt.cpp"]
 # -ffp-contract=off / -fno-fast-math are part of the pt-f32 arithmetic contract (csrc/pt_math.hpp)
