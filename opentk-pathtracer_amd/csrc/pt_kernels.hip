@@ -65,6 +65,16 @@ struct EnvRef {
     int size, format;
 };
 
+// Rarely needed launch parameters are re-read from the kernarg segment where they are used (scalar loads, always
+// cached) instead of being kept live in SGPRs for the whole kernel: the bounce loop needs its SGPRs for exec-mask
+// nesting, and every spilled SGPR costs v_writelane / v_readlane VALU slots.  FrameArgs is the kernel's first argument.
+PT_DEV const FrameArgs *cold_args()
+{
+    const FrameArgs *p = (const FrameArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 PT_DEV v3 env_texel(const EnvRef &e, int face, int x, int y)
 {
     size_t idx = ((size_t)face * e.size + (size_t)y) * e.size + (size_t)x;
@@ -365,7 +375,14 @@ PT_DEV bool bounce_step(const SceneLds &sc, int ns, int nc, const EnvRef &env, v
         throughput = v_scale(throughput, f_rcp(p));
         return true;
     }
-    v3 e = sample_env(env, rd); // compute.glsl:177
+    v3 e;
+    if (env.data == nullptr) { // persistent kernel: fetch the environment descriptor where it is needed (see cold_args)
+        const FrameArgs *ca = cold_args();
+        EnvRef cold{ca->env, env.lut, ca->envSize, ca->envFormat};
+        e = sample_env(cold, rd); // compute.glsl:177
+    } else {
+        e = sample_env(env, rd);
+    }
     rad = V(f_fma(e.x, throughput.x, rad.x), f_fma(e.y, throughput.y, rad.y), f_fma(e.z, throughput.z, rad.z));
     return false;
 }
@@ -388,27 +405,37 @@ PT_DEV void mat_vec(const float *m, float x, float y, float z, float w, float *o
 
 // compute.glsl:113-121: sub-pixel jitter, GetWorldSpaceRay (:352-357), thin lens (UniformSampleUnitCircle :309-314).
 // Consumes 4 RNG draws.
-PT_DEV void primary_ray(const FrameArgs &a, int px, int py, uint32_t &seed, v3 &ro, v3 &rd)
+// The camera block (invProj[16], invView[16], viewPos[3], focalLength, apertureDiameter = the first 37 floats of
+// FrameArgs) is read through `cam`.  The persistent kernel passes a pointer into its kernarg segment that is made
+// opaque once per ring refill, so these 37 scalars are s_load-ed where they are used instead of being kept live in
+// SGPRs across the whole bounce loop (which spilled SGPRs into VGPR lanes).
+PT_DEV void primary_ray_cam(const float *cam, float invW, float invH, int px, int py, uint32_t &seed, v3 &ro, v3 &rd)
 {
-    v3 viewPos = V(a.viewPos[0], a.viewPos[1], a.viewPos[2]);
+    const float *invProj = cam, *invView = cam + 16;
+    v3 viewPos = V(cam[32], cam[33], cam[34]);
     float u0 = rand01(seed), u1 = rand01(seed); // :113
-    float ndcx = f_fma(((float)px + u0) * f_div_ieee(1.0f, (float)a.width), 2.0f, -1.0f); // uniform 1/W, 1/H
-    float ndcy = f_fma(((float)py + u1) * f_div_ieee(1.0f, (float)a.height), 2.0f, -1.0f);
+    float ndcx = f_fma(((float)px + u0) * invW, 2.0f, -1.0f); // uniform 1/W, 1/H (IEEE quotients)
+    float ndcy = f_fma(((float)py + u1) * invH, 2.0f, -1.0f);
     float eye[4], wd[4];
-    mat_vec(a.invProj, ndcx, ndcy, -1.0f, 0.0f, eye);
-    mat_vec(a.invView, eye[0], eye[1], -1.0f, 0.0f, wd);
+    mat_vec(invProj, ndcx, ndcy, -1.0f, 0.0f, eye);
+    mat_vec(invView, eye[0], eye[1], -1.0f, 0.0f, wd);
     v3 dir = v_normalize(V(wd[0], wd[1], wd[2]));
-    v3 focal = v_fma(dir, a.focalLength, viewPos); // :117
+    v3 focal = v_fma(dir, cam[35], viewPos); // :117
     float angle = rand01(seed) * 2.0f * PI;
     float rr = f_sqrt(rand01(seed));
     float sn, cs;
     pt_sincos(angle, sn, cs);
-    float half_ap = a.apertureDiameter * 0.5f;
+    float half_ap = cam[36] * 0.5f;
     float ox = half_ap * (cs * rr), oy = half_ap * (sn * rr);
     float org[4];
-    mat_vec(a.invView, ox, oy, 0.0f, 1.0f, org); // :120
+    mat_vec(invView, ox, oy, 0.0f, 1.0f, org); // :120
     ro = V(org[0], org[1], org[2]);
     rd = v_normalize(v_sub(focal, ro));
+}
+
+PT_DEV void primary_ray(const FrameArgs &a, int px, int py, uint32_t &seed, v3 &ro, v3 &rd)
+{
+    primary_ray_cam(a.invProj, f_div_ieee(1.0f, (float)a.width), f_div_ieee(1.0f, (float)a.height), px, py, seed, ro, rd);
 }
 
 // image row of local row `ly` of this launch (contiguous row block, or block-cyclic bands across GPUs)
@@ -462,7 +489,8 @@ PT_DEV SceneLds stage_scene(const FrameArgs &a)
     float *lut = invr + ((ns + 3) & ~3);
     const int tid = threadIdx.x;
     const float4 *obj = (const float4 *)a.objects;
-    for (int i = tid; i < ns * 5; i += 256) {
+    const int nthreads = blockDim.x;
+    for (int i = tid; i < ns * 5; i += nthreads) {
         int s = i / 5, part = i - s * 5;
         float4 v = obj[i];
         if (part == 0) {
@@ -472,14 +500,14 @@ PT_DEV SceneLds stage_scene(const FrameArgs &a)
             mat[4 * s + part - 1] = v;
         }
     }
-    for (int i = tid; i < nc * 6; i += 256) {
+    for (int i = tid; i < nc * 6; i += nthreads) {
         int c = i / 6, part = i - c * 6;
         float4 v = obj[1280 + i]; // Cuboids[] start at byte 20480 = float4 index 1280
         if (part == 0) cmin[c] = v;
         else if (part == 1) cmax[c] = v;
         else mat[4 * (ns + c) + part - 2] = v;
     }
-    if (a.envFormat == 1) lut[tid] = a.srgbLut[tid];
+    if (a.envFormat == 1 && tid < 256) lut[tid] = a.srgbLut[tid];
     __syncthreads();
     return SceneLds{sph, cmin, cmax, mat, invr, lut};
 }
@@ -621,8 +649,9 @@ struct BlockQueue {            // one per workgroup, in static LDS
     unsigned int done;         // global queue exhausted
 };
 
+
 // Next tile for this wavefront, or -1 when the frame's tiles are all handed out.  Wave-uniform result.
-PT_DEV int queue_pop_tile(BlockQueue *q, const FrameArgs &a, int numTiles)
+PT_DEV int queue_pop_tile(BlockQueue *q)
 {
     const bool leader = (threadIdx.x & 63) == 0;
     for (;;) {
@@ -641,13 +670,15 @@ PT_DEV int queue_pop_tile(BlockQueue *q, const FrameArgs &a, int numTiles)
             unsigned int isDone = ((volatile BlockQueue *)q)->done;
             if (!isDone && (unsigned int)cur >= (unsigned int)(cur >> 32)) {
                 unsigned int ticket = 0;
-                if (leader) ticket = atomicAdd(a.queue, 1u) - a.queueBase;
+                const FrameArgs *ca = cold_args();
+                const int numTiles = ca->tilesX * ca->tilesY, chunk = ca->queueChunk;
+                if (leader) ticket = atomicAdd(ca->queue, 1u) - ca->queueBase;
                 ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
-                long long first = ((long long)gridDim.x + ticket) * a.queueChunk;
+                long long first = ((long long)gridDim.x + ticket) * chunk;
                 if (first >= numTiles) {
                     if (leader) ((volatile BlockQueue *)q)->done = 1u;
                 } else {
-                    long long last = first + a.queueChunk < numTiles ? first + a.queueChunk : numTiles;
+                    long long last = first + chunk < numTiles ? first + chunk : numTiles;
                     if (leader) atomicExch(&q->pair, ((unsigned long long)last << 32) | (unsigned long long)first);
                 }
             }
@@ -671,8 +702,9 @@ struct PathState { // 80 bytes
     float ro[3], rd[3], thr[3], rad[3], irr[3];
     int pad;
 };
-constexpr int POOL_SLOTS = 96;  // <= 3 donors x DONATE_MAX paths per workgroup and launch
 constexpr int DONATE_MAX = 32;
+
+__host__ __device__ constexpr int pool_slots(int waves) { return (waves - 1) * DONATE_MAX; } // <= (waves-1) donors x DONATE_MAX
 
 struct DrainControl {        // static LDS, one per workgroup
     unsigned int pushed;     // pool entries [0, pushed) are published
@@ -683,7 +715,8 @@ struct DrainControl {        // static LDS, one per workgroup
     unsigned int pad[3];
 };
 
-__global__ __launch_bounds__(256, 5) void pt_integrate_persistent_kernel(const FrameArgs a)
+template <int NWAVES, int MIN_WAVES_PER_SIMD, bool TIMELINE>
+__global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_persistent_kernel(const FrameArgs a)
 {
     __shared__ __attribute__((aligned(16))) BlockQueue queue; // 16 B: keeps the dynamic-LDS base 16-byte aligned
     __shared__ __attribute__((aligned(16))) DrainControl drain; // 32 B
@@ -697,17 +730,17 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_persistent_kernel(const F
         queue.done = 0u;
         drain.pushed = 0u;
         drain.taken = 0u;
-        drain.alive = 4u;
+        drain.alive = (unsigned int)NWAVES;
         drain.pushing = 0u;
         drain.lock = 0u;
     }
     SceneLds sc = stage_scene(a); // ends with __syncthreads()
-    EnvRef env{a.env, sc.lut, a.envSize, a.envFormat};
+    EnvRef env{nullptr, sc.lut, 0, 0}; // descriptor is cold-loaded at the miss-shading site (bounce_step)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // the ring lives behind the staged scene in dynamic LDS
     RingEntry *ringBase = (RingEntry *)((char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat));
     RingEntry *ring = ringBase + wave * 64;
-    PathState *pool = (PathState *)(ringBase + 4 * 64);
+    PathState *pool = (PathState *)(ringBase + NWAVES * 64);
     volatile DrainControl *dc = &drain;
     const bool compaction = a.drainCompaction != 0;
     const bool leader = lane == 0;
@@ -716,7 +749,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_persistent_kernel(const F
     bool exhausted = false;
     bool lastAlive = false;  // this wavefront found itself the last one of its workgroup: it can neither donate nor leave early
     unsigned long long tStart = 0, tExhausted = 0, nIter = 0;
-    if (a.timeline) tStart = wall_clock64();
+    if (TIMELINE) tStart = wall_clock64();
 
     int pix = -1, px = 0, py = 0, sample = 0, bounce = 0;
     bool needRay = false;
@@ -729,22 +762,28 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_persistent_kernel(const F
         if (m != 0ull) {
             if (avail == 0 && !exhausted) {
                 // ---- refill the ring: one tile, every lane generates one primary ray
-                int tile = queue_pop_tile(&queue, a, numTiles);
+                int tile = queue_pop_tile(&queue);
                 if (tile < 0) {
                     exhausted = true;
-                    if (a.timeline) tExhausted = wall_clock64();
+                    if (TIMELINE) tExhausted = wall_clock64();
                 } else {
-                    int tx = (int)(tile % a.tilesX), ty = (int)(tile / a.tilesX);
+                    // camera block: FrameArgs is the kernel's first argument, so it starts the kernarg segment
+                    const float *cam = (const float *)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(cam)); // opaque: load the camera here, do not keep it live across the loop
+                    const FrameArgs *ca = (const FrameArgs *)cam;
+                    const int width = ca->width, tilesX = ca->tilesX;
+                    const float invW = f_div_ieee(1.0f, (float)width), invH = f_div_ieee(1.0f, (float)ca->height);
+                    int tx = (int)(tile % tilesX), ty = (int)(tile / tilesX);
                     int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
                     RingEntry e;
                     e.pix = -1;
                     e.pxy = 0; e.seed = 0; e.ox = e.oy = e.oz = e.dx = e.dy = e.dz = 0.0f; e.pad = 0;
-                    if (x < a.width && ly < a.rows) {
-                        int gy = global_row(a, ly);
-                        uint32_t sd = pixel_seed(x, gy, a.frame);
+                    if (x < width && ly < ca->rows) {
+                        int gy = global_row(*ca, ly);
+                        uint32_t sd = pixel_seed(x, gy, ca->frame);
                         v3 o, d;
-                        primary_ray(a, x, gy, sd, o, d);
-                        e.pix = ly * a.width + x;
+                        primary_ray_cam(cam, invW, invH, x, gy, sd, o, d);
+                        e.pix = ly * width + x;
                         e.pxy = x | (gy << 16);
                         e.seed = sd;
                         e.ox = o.x; e.oy = o.y; e.oz = o.z; e.dx = d.x; e.dy = d.y; e.dz = d.z;
@@ -842,7 +881,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_persistent_kernel(const F
                 }
                 base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
                 unsigned int n = (unsigned int)__builtin_popcountll(am);
-                if (base + n <= (unsigned int)POOL_SLOTS) {
+                if (base + n <= (unsigned int)pool_slots(NWAVES)) {
                     int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
                     if (active) {
                         PathState st;
@@ -877,7 +916,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_persistent_kernel(const F
                 atomicSub(&drain.pushing, 1u);
             }
         }
-        nIter++;
+        if (TIMELINE) nIter++;
         if (active && needRay) { // only for spp > 1: the next sample continues the pixel's RNG stream (compute.glsl:110)
             primary_ray(a, px, py, seed, ro, rd);
             throughput = V(1.0f, 1.0f, 1.0f);
@@ -902,8 +941,8 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_persistent_kernel(const F
             }
         }
     }
-    if (a.timeline && lane == 0) {
-        unsigned long long *t = a.timeline + ((size_t)blockIdx.x * 4 + wave) * 4;
+    if (TIMELINE && lane == 0) {
+        unsigned long long *t = a.timeline + ((size_t)blockIdx.x * NWAVES + wave) * 4;
         t[0] = tStart; t[1] = tExhausted; t[2] = wall_clock64(); t[3] = nIter;
     }
 }
@@ -934,13 +973,20 @@ hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int
         int nwg = (tiles + 3) / 4;
         hipLaunchKernelGGL(pt_integrate_kernel, dim3(nwg), dim3(256), lds, stream, a);
     } else if (a.variant == 0 || a.variant >= 10) {
-        int blocksPerCU = a.variant == 0 ? 4 : a.variant - 9;
+        // 10+k: 256-thread workgroups, k+1 per CU; 50+k: 512-thread workgroups; 60+k: 1024-thread workgroups
+        int waves = 4, k = a.variant == 0 ? 4 : a.variant - 10;
+        if (a.variant >= 60) { waves = 16; k = a.variant - 60; }
+        else if (a.variant >= 50) { waves = 8; k = a.variant - 50; }
+        int blocksPerCU = k + 1;
         int nwg = a.numCUs * blocksPerCU;
         int numChunks = (tiles + a.queueChunk - 1) / a.queueChunk;
         if (nwg > numChunks) nwg = numChunks;
         if (nwg < 1) nwg = 1;
-        size_t ldsTotal = lds + 4 * 64 * sizeof(RingEntry) + POOL_SLOTS * sizeof(PathState);
-        hipLaunchKernelGGL(pt_integrate_persistent_kernel, dim3(nwg), dim3(256), ldsTotal, stream, a);
+        size_t ldsTotal = lds + (size_t)waves * 64 * sizeof(RingEntry) + (size_t)pool_slots(waves) * sizeof(PathState);
+        if (waves == 4 && a.timeline) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, 5, true>), dim3(nwg), dim3(256), ldsTotal, stream, a);
+        else if (waves == 4) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, 5, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
+        else if (waves == 8) hipLaunchKernelGGL((pt_integrate_persistent_kernel<8, 5, false>), dim3(nwg), dim3(512), ldsTotal, stream, a);
+        else hipLaunchKernelGGL((pt_integrate_persistent_kernel<16, 4, false>), dim3(nwg), dim3(1024), ldsTotal, stream, a);
         // every workgroup draws tickets until its first failing one: (numChunks - nwg) successful + nwg failing
         *ticketsConsumed = (unsigned int)(numChunks > nwg ? numChunks : nwg);
     } else {

@@ -1,6 +1,7 @@
 // pt_kernels.hpp — host-visible launch interface of the HIP kernels (implemented in pt_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace pt {
@@ -37,6 +38,11 @@ struct FrameArgs {
     int drainCompaction;    // 1 = donate/adopt paths through the per-workgroup LDS pool while draining
     unsigned long long *timeline; // optional (tuning): per wavefront {start, queue exhausted, end, iterations} timestamps
 };
+
+// the persistent kernel reads the camera block straight from its kernarg segment (see primary_ray_cam)
+static_assert(offsetof(FrameArgs, invProj) == 0 && offsetof(FrameArgs, invView) == 64 && offsetof(FrameArgs, viewPos) == 128 &&
+                  offsetof(FrameArgs, focalLength) == 140 && offsetof(FrameArgs, apertureDiameter) == 144,
+              "camera block layout");
 
 struct AtmoArgs {
     float invProj[16];
