@@ -47,7 +47,7 @@ struct pt_renderer {
     unsigned int *dQueue = nullptr; // global chunk-ticket counter of the persistent kernel (never reset: epoch scheme)
     int queueChunk = 8;             // tiles per global ticket (PT_QUEUE_CHUNK overrides, for tuning runs)
     unsigned long long *dTimeline = nullptr; // tuning only (pt_debug_timeline)
-    int drainCompaction = 1;        // PT_DRAIN_COMPACTION=0 disables (A/B runs)
+    int drainCompaction = 32;       // donate threshold in live paths (<= 48); PT_DRAIN_COMPACTION=0 disables (A/B runs)
     int numCUs = 256;
     void *dEnv = nullptr;      // current environment cube
     size_t envBytes = 0;
@@ -183,7 +183,7 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     pt_renderer *h = new (std::nothrow) pt_renderer();
     if (!h) return fail(nullptr, PT_E_OUT_OF_MEMORY, "host allocation failed");
     h->device = device_id;
-    if (const char *dcv = std::getenv("PT_DRAIN_COMPACTION")) h->drainCompaction = std::atoi(dcv) != 0;
+    if (const char *dcv = std::getenv("PT_DRAIN_COMPACTION")) h->drainCompaction = std::atoi(dcv);
     if (const char *qc = std::getenv("PT_QUEUE_CHUNK")) {
         int v = std::atoi(qc);
         if (v >= 1 && v <= 1024) h->queueChunk = v;

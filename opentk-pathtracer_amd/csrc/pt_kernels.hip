@@ -743,6 +743,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     PathState *pool = (PathState *)(ringBase + NWAVES * 64);
     volatile DrainControl *dc = &drain;
     const bool compaction = a.drainCompaction != 0;
+    const int donateMax = a.drainCompaction < DONATE_MAX ? a.drainCompaction : DONATE_MAX; // a wavefront this thin donates
     const bool leader = lane == 0;
 
     int avail = 0;           // wave-uniform: ring entries [0, avail) are unconsumed
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             __builtin_amdgcn_s_sleep(1);
             continue;
         }
-        if (compaction && exhausted && avail == 0 && !lastAlive && __builtin_popcountll(am) <= DONATE_MAX) {
+        if (compaction && exhausted && avail == 0 && !lastAlive && __builtin_popcountll(am) <= donateMax) {
             // ---- donate: commit (pushing++, alive--), publish the live paths under the donor lock, exit
             unsigned int old = 0, base = 0;
             if (leader) {

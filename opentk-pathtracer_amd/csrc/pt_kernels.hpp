@@ -35,7 +35,7 @@ struct FrameArgs {
     unsigned int queueBase; // value of *queue when this launch starts (every launch consumes exactly numChunks tickets)
     int numCUs;             // compute units of the device (grid sizing of persistent variants)
     int queueChunk;         // tiles per global ticket of the persistent kernel's queue
-    int drainCompaction;    // 1 = donate/adopt paths through the per-workgroup LDS pool while draining
+    int drainCompaction;    // 0 = off; else a draining wavefront with at most this many live paths donates them (<= 48)
     unsigned long long *timeline; // optional (tuning): per wavefront {start, queue exhausted, end, iterations} timestamps
 };
 
