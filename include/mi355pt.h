@@ -115,6 +115,14 @@ PT_API int pt_render(pt_handle h, int *out_total_samples);
  * handle's rows [y0, y0+rows) into dst (row_pitch_bytes >= width*16; 0 means tightly packed). */
 PT_API int pt_read_result(pt_handle h, float *dst_rgba32f, size_t row_pitch_bytes);
 
+/* The step right after the path ("next" row 1): ScreenEffect.Render(PathTracer.Result) —
+ * src/Render/ScreenEffect.cs:29-37 with res/shaders/PostProcessing/fragment.glsl:17-44 — ACES tone map + gamma 2.4 into
+ * an RGBA8 image (alpha 255), fused with the read-back: 4 B/pixel cross PCIe instead of 16.  Blocks like pt_read_result;
+ * row_pitch_bytes >= width*4 (0 = tight).  pt_postprocess_device runs the same pass and returns the device copy (stream-
+ * ordered, no host copy) so that a multi-GPU harness can gather RGBA8 rows instead of RGBA32F. */
+PT_API int pt_present_rgba8(pt_handle h, uint8_t *dst_rgba8, size_t row_pitch_bytes);
+PT_API int pt_postprocess_device(pt_handle h, void **out_device_ptr, size_t *out_bytes);
+
 /* Resume support (no reference counterpart; the reference discards accumulation on every event): replace the
  * accumulation image of this tile and set the frame counter. */
 PT_API int pt_write_result(pt_handle h, const float *src_rgba32f, size_t row_pitch_bytes, int frame_index);

@@ -56,6 +56,8 @@ struct pt_renderer {
     float4 *dAccum = nullptr;  // internal accumulation image (rows x width)
     size_t accumCapacity = 0;  // in pixels
     float4 *boundAccum = nullptr; // caller-owned target (pt_bind_result_buffer)
+    void *dRgba8 = nullptr;    // post-processed RGBA8 image of the tile (pt_present_rgba8)
+    size_t rgba8Capacity = 0;  // in pixels
     size_t boundBytes = 0;
 
     hipStream_t ownStream = nullptr, stream = nullptr;
@@ -254,6 +256,7 @@ PT_API int pt_destroy(pt_handle h)
     if (h->dQueue) (void)hipFree(h->dQueue);
     if (h->dEnv) (void)hipFree(h->dEnv);
     if (h->dAccum) (void)hipFree(h->dAccum);
+    if (h->dRgba8) (void)hipFree(h->dRgba8);
     if (h->evBegin) (void)hipEventDestroy(h->evBegin);
     if (h->evEnd) (void)hipEventDestroy(h->evEnd);
     if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
@@ -499,6 +502,48 @@ PT_API int pt_write_result(pt_handle h, const float *src, size_t row_pitch_bytes
                                hipMemcpyHostToDevice, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     h->frame = frame_index;
+    return PT_OK;
+}
+
+namespace {
+int run_postprocess(pt_handle h)
+{
+    size_t need = h->tilePixels();
+    if (need > h->rgba8Capacity) {
+        if (h->dRgba8) PT_HIP(h, hipFree(h->dRgba8));
+        h->dRgba8 = nullptr;
+        h->rgba8Capacity = 0;
+        PT_HIP(h, hipMalloc(&h->dRgba8, need * 4));
+        h->rgba8Capacity = need;
+    }
+    if (int rc = join_stripes(h)) return rc;
+    PT_HIP(h, pt::launch_postprocess(h->accum(), h->dRgba8, need, h->stream));
+    return PT_OK;
+}
+} // namespace
+
+PT_API int pt_present_rgba8(pt_handle h, uint8_t *dst, size_t row_pitch_bytes)
+{
+    PT_CHECK_HANDLE(h);
+    if (!dst) return fail(h, PT_E_BAD_ARGUMENT, "dst == NULL");
+    size_t rowBytes = (size_t)h->width * 4;
+    if (row_pitch_bytes == 0) row_pitch_bytes = rowBytes;
+    if (row_pitch_bytes < rowBytes) return fail(h, PT_E_BAD_ARGUMENT, "row pitch smaller than a row");
+    if (int rc = bind_device(h)) return rc;
+    if (int rc = run_postprocess(h)) return rc;
+    PT_HIP(h, hipMemcpy2DAsync(dst, row_pitch_bytes, h->dRgba8, rowBytes, rowBytes, (size_t)h->rows, hipMemcpyDeviceToHost,
+                               h->stream));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return PT_OK;
+}
+
+PT_API int pt_postprocess_device(pt_handle h, void **out_device_ptr, size_t *out_bytes)
+{
+    PT_CHECK_HANDLE(h);
+    if (int rc = bind_device(h)) return rc;
+    if (int rc = run_postprocess(h)) return rc;
+    if (out_device_ptr) *out_device_ptr = h->dRgba8;
+    if (out_bytes) *out_bytes = h->tilePixels() * 4;
     return PT_OK;
 }
 

@@ -1038,6 +1038,34 @@ hipError_t launch_env_to_float(const void *env, int envSize, int envFormat, cons
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------- post-process
+// /root/reference/OpenTK-PathTracer/res/shaders/PostProcessing/fragment.glsl:17-26 (ScreenEffect.Render,
+// src/Render/ScreenEffect.cs:29-37, into an RGBA8 target): ACES tone map + gamma 2.4, alpha = 1.  HBM-bound
+// elementwise pass: 16 B read + 4 B written per pixel.
+__global__ __launch_bounds__(256) void pt_postprocess_kernel(const float4 *accum, uchar4 *out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        float4 c = accum[i];
+        uchar4 o;
+        o.x = to_unorm8(linear_to_inverse_gamma(aces_film(c.x), 2.4f));
+        o.y = to_unorm8(linear_to_inverse_gamma(aces_film(c.y), 2.4f));
+        o.z = to_unorm8(linear_to_inverse_gamma(aces_film(c.z), 2.4f));
+        o.w = 255;
+        out[i] = o;
+    }
+}
+
+hipError_t launch_postprocess(const float4 *accum, void *outRgba8, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pt_postprocess_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, accum, (uchar4 *)outRgba8, n);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------- atmosphere
 // /root/reference/OpenTK-PathTracer/res/shaders/AtmosphericScattering/compute.glsl:30-171
 // (algorithm credited there to github.com/wwwtyro/glsl-atmosphere); one thread per cube texel.

@@ -57,6 +57,8 @@ struct AtmoArgs {
 hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int *ticketsConsumed);
 hipError_t launch_atmosphere(const AtmoArgs &a, hipStream_t stream);
 hipError_t launch_clear(float4 *p, size_t n, hipStream_t stream);
+// ACES + gamma of PostProcessing/fragment.glsl: n RGBA32F pixels -> n RGBA8 pixels
+hipError_t launch_postprocess(const float4 *accum, void *outRgba8, size_t n, hipStream_t stream);
 // linearise any environment into RGBA32F for read-back
 hipError_t launch_env_to_float(const void *env, int envSize, int envFormat, const float *srgbLut, float4 *out,
                                hipStream_t stream);

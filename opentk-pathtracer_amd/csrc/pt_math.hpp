@@ -122,6 +122,48 @@ PT_DEV float pt_pow5(float x)
     return x * (x2 * x2);
 }
 
+// log(x), x > 0 normal: exponent split + degree-9 polynomial in (m - 1), m in [sqrt(1/2), sqrt(2))  (~1 ulp)
+PT_DEV float pt_log(float x)
+{
+    uint32_t u = __float_as_uint(x);
+    int e = (int)(u >> 23) - 127;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237f) { m *= 0.5f; e += 1; }
+    float t = m - 1.0f, z = t * t;
+    float y = f_fma(7.0376836292e-2f, t, -1.1514610310e-1f);
+    y = f_fma(y, t, 1.1676998740e-1f);
+    y = f_fma(y, t, -1.2420140846e-1f);
+    y = f_fma(y, t, 1.4249322787e-1f);
+    y = f_fma(y, t, -1.6668057665e-1f);
+    y = f_fma(y, t, 2.0000714765e-1f);
+    y = f_fma(y, t, -2.4999993993e-1f);
+    y = f_fma(y, t, 3.3333331174e-1f);
+    y = y * t * z;
+    float fe = (float)e;
+    y = f_fma(-2.12194440e-4f, fe, y);
+    y = f_fma(-0.5f, z, y);
+    return f_fma(0.693359375f, fe, t + y);
+}
+
+PT_DEV float f_clamp01(float x) { return f_min(f_max(x, 0.0f), 1.0f); }
+
+// PostProcessing/fragment.glsl:35-43 ACESFilm, per channel
+PT_DEV float aces_film(float x)
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    float num = x * f_fma(a, x, b), den = f_fma(x, f_fma(c, x, d), e);
+    return f_clamp01(num * f_rcp(den));
+}
+
+// PostProcessing/fragment.glsl:28-32 LinearToInverseGamma, per channel; pow(x,y) = exp(y * log(x))
+PT_DEV float linear_to_inverse_gamma(float v, float gamma)
+{
+    if (v < 0.0031308f) return v * 12.92f;
+    return f_fma(pt_exp(f_rcp(gamma) * pt_log(v)), 1.055f, -0.055f);
+}
+
+PT_DEV unsigned char to_unorm8(float v) { return (unsigned char)(int)(f_clamp01(v) * 255.0f + 0.5f); }
+
 // compute.glsl:334-344 — PCG hash RNG; uint -> float conversion is round-to-nearest-even, /2^32 is exact.
 PT_DEV uint32_t pcg_hash(uint32_t &seed)
 {

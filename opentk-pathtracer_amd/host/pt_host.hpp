@@ -273,6 +273,13 @@ public:
         Check(pt_read_result(h_, img.data(), 0), h_);
         return img;
     }
+    // ScreenEffect.Render(PathTracer.Result) — src/Render/ScreenEffect.cs:29-37 — tone-mapped RGBA8 image
+    std::vector<uint8_t> Present() const
+    {
+        std::vector<uint8_t> img((size_t)width_ * height_ * 4);
+        Check(pt_present_rgba8(h_, img.data(), 0), h_);
+        return img;
+    }
     int Width() const { return width_; }
     int Height() const { return height_; }
     pt_handle Handle() const { return h_; }

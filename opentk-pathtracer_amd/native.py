@@ -109,6 +109,8 @@ def load() -> C.CDLL:
         "pt_render": [vp, ip],
         "pt_read_result": [vp, fp, C.c_size_t],
         "pt_write_result": [vp, fp, C.c_size_t, C.c_int],
+        "pt_present_rgba8": [vp, C.POINTER(C.c_uint8), C.c_size_t],
+        "pt_postprocess_device": [vp, C.POINTER(vp), C.POINTER(C.c_size_t)],
         "pt_get_frame_index": [vp, ip],
         "pt_synchronize": [vp],
         "pt_atmosphere_upload_data": [vp, C.c_int, C.c_int, vp],

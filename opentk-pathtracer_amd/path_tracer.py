@@ -147,6 +147,18 @@ class PathTracer:
         check(self._lib.pt_read_result(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), 0), self._h)
         return out
 
+    def Present(self) -> np.ndarray:
+        """ScreenEffect.Render(PathTracer.Result) (ScreenEffect.cs:29-37, PostProcessing/fragment.glsl): the tone-mapped
+        RGBA8 image of this tile, (rows, Width, 4) uint8, row 0 = image row y0."""
+        out = np.empty((self.rows, self.Width, 4), dtype=np.uint8)
+        check(self._lib.pt_present_rgba8(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), 0), self._h)
+        return out
+
+    def PostProcessDevice(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(self._lib.pt_postprocess_device(self._h, C.byref(p), C.byref(n)), self._h)
+        return p.value, n.value
+
     def WriteResult(self, image: np.ndarray, frame_index: int) -> None:
         img = np.ascontiguousarray(image, dtype=np.float32)
         assert img.shape == (self.rows, self.Width, 4)

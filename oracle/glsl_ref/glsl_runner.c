@@ -24,6 +24,9 @@
  *           output: (dumpEach ? numFrames : 1) * W*H*4 float32
  *   mode 1: int32 size,iSteps,jSteps ; float lightPos[3], lightIntensity ; 464 B AtmosphericDataUBO
  *           output: 6 * size*size*4 float32
+ *   mode 2: int32 W,H ; W*H*4 float32 image.  Runs a compute shader (local size 8x8) that transforms the RGBA32F image
+ *           bound at image unit 0 in place — used to drive the reference's post-process FUNCTIONS
+ *           (PostProcessing/fragment.glsl:28-43) through a test main; output: W*H*4 float32
  *
  * Build: gcc -O2 -D_GNU_SOURCE glsl_runner.c -o ../_ref/glsl_runner -ldl -lm   (see oracle/Makefile)
  */
@@ -315,6 +318,38 @@ static void run_atmosphere(const char *shader_path, struct reader *r, FILE *out)
     fprintf(stderr, "glsl_runner: atmosphere %d^2 x6, %d x %d steps: %.3f ms\n", size, iSteps, jSteps, 1e3 * dt);
 }
 
+static void run_image_transform(const char *shader_path, struct reader *r, FILE *out)
+{
+    int W = take_i32(r), H = take_i32(r);
+    const void *pixels = take(r, (size_t)W * H * 16);
+    char *src = slurp(shader_path, NULL);
+    GLuint prog = build_program(src);
+    GLFN(PFNGLUSEPROGRAMPROC, glUseProgram);
+    GLFN(PFNGLCREATETEXTURESPROC, glCreateTextures);
+    GLFN(PFNGLTEXTURESTORAGE2DPROC, glTextureStorage2D);
+    GLFN(PFNGLTEXTURESUBIMAGE2DPROC, glTextureSubImage2D);
+    GLFN(PFNGLBINDIMAGETEXTUREPROC, glBindImageTexture);
+    GLFN(PFNGLDISPATCHCOMPUTEPROC, glDispatchCompute);
+    GLFN(PFNGLMEMORYBARRIERPROC, glMemoryBarrier);
+    GLFN(PFNGLGETTEXTUREIMAGEPROC, glGetTextureImage);
+    GLenum (*p_glGetError)(void) = (GLenum (*)(void))g_getproc("glGetError");
+    void (*p_glFinish)(void) = (void (*)(void))g_getproc("glFinish");
+    GLuint img;
+    glCreateTextures(GL_TEXTURE_2D, 1, &img);
+    glTextureStorage2D(img, 1, GL_RGBA32F, W, H);
+    glTextureSubImage2D(img, 0, 0, 0, W, H, GL_RGBA, GL_FLOAT, pixels);
+    glUseProgram(prog);
+    glBindImageTexture(0, img, 0, GL_FALSE, 0, GL_READ_WRITE, GL_RGBA32F);
+    glDispatchCompute((W + 7) / 8, (H + 7) / 8, 1);
+    glMemoryBarrier(GL_ALL_BARRIER_BITS);
+    p_glFinish();
+    float *pix = malloc((size_t)W * H * 16);
+    glGetTextureImage(img, 0, GL_RGBA, GL_FLOAT, (GLsizei)((size_t)W * H * 16), pix);
+    GLenum e = p_glGetError();
+    if (e) DIE("glGetError = 0x%x", e);
+    fwrite(pix, 16, (size_t)W * H, out);
+}
+
 int main(int argc, char **argv)
 {
     if (argc != 4) DIE("usage: glsl_runner <shader.glsl> <job.bin> <out.bin>");
@@ -328,6 +363,7 @@ int main(int argc, char **argv)
     if (!out) DIE("cannot write %s", argv[3]);
     if (mode == 0) run_pathtracer(argv[1], &r, out);
     else if (mode == 1) run_atmosphere(argv[1], &r, out);
+    else if (mode == 2) run_image_transform(argv[1], &r, out);
     else DIE("unknown mode %d", mode);
     fclose(out);
     return 0;

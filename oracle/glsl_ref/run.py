@@ -18,6 +18,7 @@ RUNNER = os.path.join(HERE, "..", "_ref", "glsl_runner")
 REF_ROOT = os.environ.get("PT_REFERENCE_ROOT", "/root/reference")
 PT_SHADER = os.path.join(REF_ROOT, "OpenTK-PathTracer/res/shaders/PathTracing/compute.glsl")
 ATMO_SHADER = os.path.join(REF_ROOT, "OpenTK-PathTracer/res/shaders/AtmosphericScattering/compute.glsl")
+POST_SHADER = os.path.join(REF_ROOT, "OpenTK-PathTracer/res/shaders/PostProcessing/fragment.glsl")
 SWRAST = "/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so"
 
 
@@ -70,3 +71,37 @@ def run_atmosphere(size, atmo_ubo: bytes, light_pos, light_intensity=15.0, i_ste
     job += atmo_ubo
     out, _ = _run(ATMO_SHADER, job, 6 * size * size * 4, threads)
     return out.reshape(6, size, size, 4)
+
+
+def run_image_transform(shader_path: str, image: np.ndarray) -> np.ndarray:
+    """Run a compute shader (8x8 groups) that transforms the RGBA32F image at image unit 0 in place."""
+    image = np.ascontiguousarray(image, dtype=np.float32)
+    h, w, c = image.shape
+    assert c == 4
+    job = struct.pack("<ii", 0x4A4C5347, 2) + struct.pack("<2i", w, h) + image.tobytes()
+    out, _ = _run(shader_path, job, w * h * 4)
+    return out.reshape(h, w, 4)
+
+
+def run_postprocess(image: np.ndarray) -> np.ndarray:
+    """The reference's post-process FUNCTIONS (ACESFilm, LinearToInverseGamma; PostProcessing/fragment.glsl:28-43) applied
+    to `image` exactly as fragment.glsl's main does (:17-26), driven from a compute-stage test main: the function
+    definitions are cut from the reference text at run time (nothing is stored in the repo)."""
+    src = open(POST_SHADER, "rb").read().decode("utf-8-sig")
+    start = src.index("vec3 LinearToInverseGamma(vec3 rgb, float gamma)\n{") if "vec3 LinearToInverseGamma(vec3 rgb, float gamma)\n{" in src \
+        else src.index("vec3 LinearToInverseGamma(vec3 rgb, float gamma)\r\n{")
+    funcs = src[start:]
+    derived = ("#version 450 core\nlayout(local_size_x = 8, local_size_y = 8, local_size_z = 1) in;\n"
+               "layout(binding = 0, rgba32f) restrict uniform image2D ImgResult;\n"
+               "vec3 LinearToInverseGamma(vec3 rgb, float gamma);\nvec3 ACESFilm(vec3 x);\n"
+               "void main() {\n  ivec2 c = ivec2(gl_GlobalInvocationID.xy);\n"
+               "  if (c.x >= imageSize(ImgResult).x || c.y >= imageSize(ImgResult).y) return;\n"
+               "  vec3 color = imageLoad(ImgResult, c).rgb;\n  color = ACESFilm(color);\n"
+               "  color = LinearToInverseGamma(color, 2.4);\n  imageStore(ImgResult, c, vec4(color, 1.0));\n}\n" + funcs)
+    with tempfile.NamedTemporaryFile("w", suffix=".glsl", delete=False) as f:
+        f.write(derived)
+        path = f.name
+    try:
+        return run_image_transform(path, image)
+    finally:
+        os.unlink(path)

@@ -7,6 +7,7 @@
  * What it restates, function by function (all paths relative to /root/reference/OpenTK-PathTracer/):
  *   res/shaders/PathTracing/compute.glsl:101-369          the integrator (cited per function below)
  *   res/shaders/AtmosphericScattering/compute.glsl:30-171 the atmosphere env-map precompute
+ *   res/shaders/PostProcessing/fragment.glsl:17-44        ACES tone map + gamma -> RGBA8 (the step after the path)
  *   src/Render/PathTracer.cs:114-129                      frame counter / dispatch semantics
  *
  * PINNING: the reference has no tests or golden vectors of its own.  This oracle is
@@ -697,6 +698,70 @@ PTO_API void pto_cosine_sample_hemisphere(const float *n, uint32_t *seed, float 
 { v3 r = cosine_sample_hemisphere(V(n[0], n[1], n[2]), seed); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
 PTO_API void pto_normalize(const float *v, float *out)
 { v3 r = v_normalize(V(v[0], v[1], v[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+
+/* ------------------------------------------------------------------ post-process ("next" row 1)
+ * res/shaders/PostProcessing/fragment.glsl:17-44, run by src/Render/ScreenEffect.cs:29-37 into an RGBA8 target:
+ *   color = texture(Sampler0, uv).rgb (+ an unbound sampler = 0); ACESFilm; LinearToInverseGamma(color, 2.4); alpha 1.
+ * pt-f32 contract additions: log(x) = the cephes-style degree-9 polynomial below (~1 ulp), pow(x,y) = exp(y*log(x)),
+ * a/b = a * f_rcp(b); float -> unorm8 = round-half-up of clamp(x,0,1)*255 (GL 4.5 section 2.3.5.1 leaves ties open). */
+static float f_log(float x)
+{
+    uint32_t u = f_bits(x);
+    int e = (int)(u >> 23) - 127;
+    float m = f_unbits((u & 0x007fffffu) | 0x3f800000u); /* [1,2) */
+    if (m > 1.41421356237f) { m *= 0.5f; e += 1; }
+    float t = m - 1.0f, z = t * t;
+    float y = fmaf(7.0376836292e-2f, t, -1.1514610310e-1f);
+    y = fmaf(y, t, 1.1676998740e-1f);
+    y = fmaf(y, t, -1.2420140846e-1f);
+    y = fmaf(y, t, 1.4249322787e-1f);
+    y = fmaf(y, t, -1.6668057665e-1f);
+    y = fmaf(y, t, 2.0000714765e-1f);
+    y = fmaf(y, t, -2.4999993993e-1f);
+    y = fmaf(y, t, 3.3333331174e-1f);
+    y = y * t * z;
+    float fe = (float)e;
+    y = fmaf(-2.12194440e-4f, fe, y);
+    y = fmaf(-0.5f, z, y);
+    return fmaf(0.693359375f, fe, t + y);
+}
+
+static inline float f_clamp01(float x) { return f_min(f_max(x, 0.0f), 1.0f); }
+
+static float aces_film(float x) /* fragment.glsl:35-43 */
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    float num = x * fmaf(a, x, b), den = fmaf(x, fmaf(c, x, d), e);
+    return f_clamp01(num * f_rcp(den));
+}
+
+static float linear_to_inverse_gamma(float v, float gamma) /* fragment.glsl:28-32 */
+{
+    if (v < 0.0031308f) return v * 12.92f;
+    return fmaf(f_exp(f_rcp(gamma) * f_log(v)), 1.055f, -0.055f);
+}
+
+static inline uint8_t to_unorm8(float v)
+{
+    float c = f_clamp01(v) * 255.0f + 0.5f;
+    return (uint8_t)(int)c;
+}
+
+/* out_f (optional): the shader's float colour per pixel (n x 3); out_u8 (optional): the RGBA8 target (n x 4) */
+PTO_API int pto_postprocess(const float *rgba, int n, float *out_f, uint8_t *out_u8)
+{
+    for (int i = 0; i < n; i++) {
+        float c[3];
+        for (int k = 0; k < 3; k++) c[k] = linear_to_inverse_gamma(aces_film(rgba[4 * i + k]), 2.4f);
+        if (out_f) { out_f[3 * i] = c[0]; out_f[3 * i + 1] = c[1]; out_f[3 * i + 2] = c[2]; }
+        if (out_u8) {
+            out_u8[4 * i] = to_unorm8(c[0]); out_u8[4 * i + 1] = to_unorm8(c[1]); out_u8[4 * i + 2] = to_unorm8(c[2]);
+            out_u8[4 * i + 3] = 255;
+        }
+    }
+    return 0;
+}
+PTO_API float pto_log(float x) { return f_log(x); }
 
 /* ------------------------------------------------------------------ atmosphere precompute
  * res/shaders/AtmosphericScattering/compute.glsl:30-171 (algorithm credited there to

@@ -74,6 +74,10 @@ class Oracle:
         L.pto_cosine_sample_hemisphere.argtypes = [_fp, C.POINTER(C.c_uint32), _fp]
         L.pto_normalize.argtypes = [_fp, _fp]
         L.pto_set_srgb_lut.argtypes = [_fp]
+        L.pto_postprocess.restype = C.c_int
+        L.pto_postprocess.argtypes = [_fp, C.c_int, _fp, C.POINTER(C.c_uint8)]
+        L.pto_log.restype = C.c_float
+        L.pto_log.argtypes = [C.c_float]
         L.pto_atmosphere.restype = C.c_int
         L.pto_atmosphere.argtypes = [_fp, _fp, C.c_float, C.c_int, C.c_int, C.c_int, _fp, C.c_int]
 
@@ -138,6 +142,18 @@ class Oracle:
         self.lib.pto_atmosphere(_ptr(ubo), _ptr(lp), light_intensity, size, i_steps, j_steps, _ptr(out),
                                 threads or os.cpu_count() or 1)
         return out
+
+    def postprocess(self, image):
+        """ACES + gamma of PostProcessing/fragment.glsl on an (..., 4) float32 image -> (float (..., 3), uint8 (..., 4))."""
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        n = img.size // 4
+        of = np.zeros(img.shape[:-1] + (3,), np.float32)
+        ou = np.zeros(img.shape[:-1] + (4,), np.uint8)
+        self.lib.pto_postprocess(_ptr(img), n, _ptr(of), ou.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return of, ou
+
+    def log(self, x):
+        return self.lib.pto_log(float(x))
 
     # ---------------------------------------------------------------- micro helpers
     def rand_stream(self, seed: int, n: int):

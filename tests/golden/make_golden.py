@@ -210,7 +210,26 @@ def gen_micro():
     save("micro", **arrays)
 
 
-GROUPS = {"envs": gen_envs, "micro": gen_micro, "frames": gen_frames, "envonly": gen_envonly, "sparse": gen_sparse,
+def gen_post():
+    print("post-process (reference PostProcessing/fragment.glsl functions on llvmpipe):")
+    rng = np.random.RandomState(11)
+    img = np.ones((96, 64, 4), dtype=np.float32)
+    img[..., :3] = np.exp(rng.uniform(np.log(1e-6), np.log(80.0), (96, 64, 3))).astype(np.float32)
+    ramp = np.linspace(0.0, 4.0, 64, dtype=np.float32)
+    img[0, :, :3] = ramp[:, None]                       # grey ramp through the knee
+    img[1, :, :3] = (ramp * np.float32(0.002))[:, None]  # around the 0.0031308 linear/power switch
+    img[2, :8, :3] = [[0, 0, 0], [1, 1, 1], [0.0031308, 0.0031307, 0.0031309], [-0.5, -1e-3, 2.0], [1e-8, 1e-7, 1e-6],
+                      [0.18, 0.18, 0.18], [100, 1000, 1e6], [0.5, 0.25, 0.75]]
+    # plus a real HDR frame of the integrator (default scene) so the fixture covers the value distribution that matters
+    w = configs.SMALL_FRAMES[1]
+    sc, basic, objs, env, kw = configs.inputs(w)
+    hdr = ref.run_pathtracer(w.width, w.height, basic, objs, env, num_frames=4, **kw)[0]
+    img[24:96, :, :] = hdr[:, 32:96, :]
+    out = ref.run_postprocess(img)
+    save("post_aces_gamma", image=img, expected=out[..., :3].copy())
+
+
+GROUPS = {"post": gen_post, "envs": gen_envs, "micro": gen_micro, "frames": gen_frames, "envonly": gen_envonly, "sparse": gen_sparse,
           "atmo": gen_atmo}
 
 if __name__ == "__main__":

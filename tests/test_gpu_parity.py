@@ -369,3 +369,43 @@ def test_interleaved_tiling_is_bit_identical(pkg, native_lib, w, world, band):
         out[rows] = part
         pt.Dispose()
     assert np.array_equal(bits(out), bits(full))
+
+
+def test_present_rgba8_equals_oracle_and_reference(pkg, native_lib, oracle):
+    """pt_present_rgba8 (ScreenEffect.Render + PostProcessing/fragment.glsl fused with the read-back): the HIP pass on a
+    rendered HDR image equals the oracle's RGBA8 byte for byte; and on the reference fixture's input image it is within
+    1 LSB of the reference's own functions."""
+    w = configs.Workload("present", "default", 320, 180, 8, "sky_f32_32")
+    sc, basic, objs, env, kw = configs.inputs(w)
+    pt = pkg.PathTracer(env, w.width, w.height, w.ray_depth, 1, w.focal_length, w.aperture)
+    pt.UploadScene(sc)
+    pt.UploadBasicData(basic)
+    for _ in range(6):
+        pt.Render()
+    hdr, ldr = pt.Result, pt.Present()
+    _, want = oracle.postprocess(hdr)
+    assert ldr.shape == (w.height, w.width, 4) and np.array_equal(ldr, want)
+    # fixture: load its input image as the accumulation image, then present
+    fx = fixtures.load("post_aces_gamma")
+    img = fx["image"]
+    pt2 = pkg.PathTracer(env, img.shape[1], img.shape[0], 1, 1, 1.0, 0.0)
+    pt2.WriteResult(img, 1)
+    got = pt2.Present()
+    _, want2 = oracle.postprocess(img)
+    assert np.array_equal(got, want2)
+    ref_u8 = (np.clip(fx["expected"], 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    diff = np.abs(ref_u8.astype(int) - got[..., :3].astype(int))
+    assert diff.max() <= 1 and (diff == 0).mean() >= 0.999
+    # tiled present: row blocks concatenate to the full presented image
+    parts = []
+    for r in range(3):
+        from opentk_pathtracer_amd import distributed as D
+        p3 = pkg.PathTracer(env, w.width, w.height, w.ray_depth, 1, w.focal_length, w.aperture)
+        p3.UploadScene(sc)
+        p3.UploadBasicData(basic)
+        p3.SetTile(*D.row_block(w.height, r, 3))
+        for _ in range(6):
+            p3.Render()
+        parts.append(p3.Present())
+        p3.Dispose()
+    assert np.array_equal(np.concatenate(parts), ldr)

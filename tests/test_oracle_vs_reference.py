@@ -245,3 +245,28 @@ def test_atmosphere_matches_reference(oracle, name):
     err = np.abs(got - ref) / scale
     assert err.max() < 2e-3, f"{name}: max rel err {err.max():.3g}"
     assert np.median(err) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ post-process ("next" row)
+def test_postprocess_matches_reference(oracle):
+    """ACESFilm + LinearToInverseGamma(2.4) of PostProcessing/fragment.glsl (the reference's own functions executed on
+    llvmpipe through a compute-stage test main) vs the oracle: float colour within 1e-6, RGBA8 within 1 LSB and >= 99.9 %
+    identical (llvmpipe's pow is ~20 ulp; the quantisation step amplifies that only at rounding boundaries)."""
+    fx = fixtures.load("post_aces_gamma")
+    f, u8 = oracle.postprocess(fx["image"])
+    ref = fx["expected"]
+    assert np.abs(f - ref).max() <= 1e-6
+    ref_u8 = (np.clip(ref, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    diff = np.abs(ref_u8.astype(int) - u8[..., :3].astype(int))
+    assert diff.max() <= 1 and (diff == 0).mean() >= 0.999
+    assert (u8[..., 3] == 255).all()
+    # exact anchors of the curve
+    g, q = oracle.postprocess(np.array([[0.0, 1.0, 0.0031307, 1.0]], np.float32))
+    assert q[0, 0] == 0 and abs(g[0, 1] - 0.908230) < 2e-6 and q[0, 1] == 232
+
+
+def test_log_accuracy(oracle):
+    xs = np.exp(np.random.RandomState(0).uniform(np.log(1e-6), np.log(1e4), 3000)).astype(np.float32)
+    for x in xs:
+        t = np.log(np.float64(x))
+        assert abs(oracle.log(x) - t) <= 2e-7 * max(1.0, abs(t))
