@@ -758,43 +758,49 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     v3 ro = V(0, 0, 0), rd = V(0, 0, 1), throughput = V(1, 1, 1), rad = V(0, 0, 0), irr = V(0, 0, 0);
 
     for (;;) {
+        // ---- feed idle lanes: pop from the ring; if the ring runs dry while lanes are still idle, refill it with the next
+        // tile and pop again in the SAME iteration (a lane never idles through a bounce iteration because the ring happened
+        // to hold fewer rays than there were idle lanes)
         bool idle = pix < 0;
         unsigned long long m = __ballot(idle);
-        if (m != 0ull) {
-            if (avail == 0 && !exhausted) {
-                // ---- refill the ring: one tile, every lane generates one primary ray
-                int tile = queue_pop_tile(&queue);
-                if (tile < 0) {
-                    exhausted = true;
-                    if (TIMELINE) tExhausted = wall_clock64();
-                } else {
-                    // camera block: FrameArgs is the kernel's first argument, so it starts the kernarg segment
-                    const float *cam = (const float *)__builtin_amdgcn_kernarg_segment_ptr();
-                    asm volatile("" : "+s"(cam)); // opaque: load the camera here, do not keep it live across the loop
-                    const FrameArgs *ca = (const FrameArgs *)cam;
-                    const int width = ca->width, tilesX = ca->tilesX;
-                    const float invW = f_div_ieee(1.0f, (float)width), invH = f_div_ieee(1.0f, (float)ca->height);
-                    int tx = (int)(tile % tilesX), ty = (int)(tile / tilesX);
-                    int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
-                    RingEntry e;
-                    e.pix = -1;
-                    e.pxy = 0; e.seed = 0; e.ox = e.oy = e.oz = e.dx = e.dy = e.dz = 0.0f; e.pad = 0;
-                    if (x < width && ly < ca->rows) {
-                        int gy = global_row(*ca, ly);
-                        uint32_t sd = pixel_seed(x, gy, ca->frame);
-                        v3 o, d;
-                        primary_ray_cam(cam, invW, invH, x, gy, sd, o, d);
-                        e.pix = ly * width + x;
-                        e.pxy = x | (gy << 16);
-                        e.seed = sd;
-                        e.ox = o.x; e.oy = o.y; e.oz = o.z; e.dx = d.x; e.dy = d.y; e.dz = d.z;
+        for (int pass = 0; pass < 2 && m != 0ull; pass++) {
+            if (avail == 0) {
+                if (exhausted) break;
+                    // ---- refill the ring: one tile, every lane generates one primary ray
+                    int tile = queue_pop_tile(&queue);
+                    if (tile < 0) {
+                        exhausted = true;
+                        if (TIMELINE) tExhausted = wall_clock64();
+                    } else {
+                        // camera block: FrameArgs is the kernel's first argument, so it starts the kernarg segment
+                        const float *cam = (const float *)__builtin_amdgcn_kernarg_segment_ptr();
+                        asm volatile("" : "+s"(cam)); // opaque: load the camera here, do not keep it live across the loop
+                        const FrameArgs *ca = (const FrameArgs *)cam;
+                        const int width = ca->width, tilesX = ca->tilesX;
+                        const float invW = f_div_ieee(1.0f, (float)width), invH = f_div_ieee(1.0f, (float)ca->height);
+                        int tx = (int)(tile % tilesX), ty = (int)(tile / tilesX);
+                        int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+                        RingEntry e;
+                        e.pix = -1;
+                        e.pxy = 0; e.seed = 0; e.ox = e.oy = e.oz = e.dx = e.dy = e.dz = 0.0f; e.pad = 0;
+                        if (x < width && ly < ca->rows) {
+                            int gy = global_row(*ca, ly);
+                            uint32_t sd = pixel_seed(x, gy, ca->frame);
+                            v3 o, d;
+                            primary_ray_cam(cam, invW, invH, x, gy, sd, o, d);
+                            e.pix = ly * width + x;
+                            e.pxy = x | (gy << 16);
+                            e.seed = sd;
+                            e.ox = o.x; e.oy = o.y; e.oz = o.z; e.dx = d.x; e.dy = d.y; e.dz = d.z;
+                        }
+                        ring[lane] = e;
+                        __builtin_amdgcn_wave_barrier(); // ring entries are read by other lanes of this wave below
+                        avail = 64;
                     }
-                    ring[lane] = e;
-                    __builtin_amdgcn_wave_barrier(); // ring entries are read by other lanes of this wave below
-                    avail = 64;
-                }
+
+                if (exhausted) break;
             }
-            if (avail > 0) {
+            {
                 // ---- idle lanes pop ring entries (top down); a popped out-of-image entry leaves the lane idle
                 int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 if (idle && rank < avail) {
@@ -816,6 +822,13 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                 }
                 int n = __builtin_popcountll(m);
                 avail = n < avail ? avail - n : 0;
+            }
+            idle = pix < 0;
+            m = __ballot(idle);
+        }
+        if (m != 0ull) {
+            if (avail > 0) {
+                // (ring entries left: the remaining idle lanes popped out-of-image entries of a ragged tile)
             } else if (exhausted && compaction) {
                 // ---- drain: idle lanes adopt donated paths from the workgroup's pool
                 unsigned int pushed = dc->pushed, taken = dc->taken;
