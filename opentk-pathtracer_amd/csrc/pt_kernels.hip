@@ -59,18 +59,23 @@ __host__ __device__ inline size_t scene_lds_bytes(int ns, int nc, int envFormat)
 // ---------------------------------------------------------------------------------------------- environment
 // texture(SamplerEnvironment, dir) (compute.glsl:177): LOD 0, LINEAR magnification, seamless cube edges
 // (src/MainWindow.cs:168,178).  Face selection per OpenGL 4.5 table 8.19 (ties: Z, then X, then Y).
+typedef const __attribute__((address_space(3))) float *LdsFloats; // keeps LUT reads as ds_read (a generic pointer would make them flat loads)
 struct EnvRef {
     const void *data;
-    const float *lut;
+    LdsFloats lut;
     int size, format;
 };
 
 // Rarely needed launch parameters are re-read from the kernarg segment where they are used (scalar loads, always
 // cached) instead of being kept live in SGPRs for the whole kernel: the bounce loop needs its SGPRs for exec-mask
 // nesting, and every spilled SGPR costs v_writelane / v_readlane VALU slots.  FrameArgs is the kernel's first argument.
-PT_DEV const FrameArgs *cold_args()
+// The pointer stays in the CONSTANT address space (4), so every access is a scalar s_load (uniform, cached), not a
+// per-lane flat load.
+typedef const __attribute__((address_space(4))) FrameArgs *ColdArgs;
+typedef const __attribute__((address_space(4))) float *ColdFloats;
+PT_DEV ColdArgs cold_args()
 {
-    const FrameArgs *p = (const FrameArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    ColdArgs p = (ColdArgs)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
     return p;
 }
@@ -377,7 +382,7 @@ PT_DEV bool bounce_step(const SceneLds &sc, int ns, int nc, const EnvRef &env, v
     }
     v3 e;
     if (env.data == nullptr) { // persistent kernel: fetch the environment descriptor where it is needed (see cold_args)
-        const FrameArgs *ca = cold_args();
+        ColdArgs ca = cold_args();
         EnvRef cold{ca->env, env.lut, ca->envSize, ca->envFormat};
         e = sample_env(cold, rd); // compute.glsl:177
     } else {
@@ -397,7 +402,8 @@ PT_DEV v3 radiance(const FrameArgs &a, const SceneLds &sc, const EnvRef &env, v3
 }
 
 // GLSL mat4 * vec4 on the column-major view of the UBO bytes: m[4c + r]
-PT_DEV void mat_vec(const float *m, float x, float y, float z, float w, float *out)
+template <typename FP>
+PT_DEV void mat_vec(FP m, float x, float y, float z, float w, float *out)
 {
 #pragma unroll
     for (int r = 0; r < 4; r++) out[r] = f_fma(m[12 + r], w, f_fma(m[8 + r], z, f_fma(m[4 + r], y, m[r] * x)));
@@ -409,9 +415,10 @@ PT_DEV void mat_vec(const float *m, float x, float y, float z, float w, float *o
 // FrameArgs) is read through `cam`.  The persistent kernel passes a pointer into its kernarg segment that is made
 // opaque once per ring refill, so these 37 scalars are s_load-ed where they are used instead of being kept live in
 // SGPRs across the whole bounce loop (which spilled SGPRs into VGPR lanes).
-PT_DEV void primary_ray_cam(const float *cam, float invW, float invH, int px, int py, uint32_t &seed, v3 &ro, v3 &rd)
+template <typename FP>
+PT_DEV void primary_ray_cam(FP cam, float invW, float invH, int px, int py, uint32_t &seed, v3 &ro, v3 &rd)
 {
-    const float *invProj = cam, *invView = cam + 16;
+    FP invProj = cam, invView = cam + 16;
     v3 viewPos = V(cam[32], cam[33], cam[34]);
     float u0 = rand01(seed), u1 = rand01(seed); // :113
     float ndcx = f_fma(((float)px + u0) * invW, 2.0f, -1.0f); // uniform 1/W, 1/H (IEEE quotients)
@@ -435,17 +442,18 @@ PT_DEV void primary_ray_cam(const float *cam, float invW, float invH, int px, in
 
 PT_DEV void primary_ray(const FrameArgs &a, int px, int py, uint32_t &seed, v3 &ro, v3 &rd)
 {
-    primary_ray_cam(a.invProj, f_div_ieee(1.0f, (float)a.width), f_div_ieee(1.0f, (float)a.height), px, py, seed, ro, rd);
+    primary_ray_cam<const float *>(a.invProj, f_div_ieee(1.0f, (float)a.width), f_div_ieee(1.0f, (float)a.height), px, py, seed, ro, rd);
 }
 
 // image row of local row `ly` of this launch (contiguous row block, or block-cyclic bands across GPUs)
-PT_DEV int global_row(const FrameArgs &a, int ly)
+PT_DEV int global_row_v(int bandRows, int bandWorld, int bandRank, int localRow0, int y0, int ly)
 {
-    if (a.bandRows == 0) return a.y0 + ly;
-    int l = a.localRow0 + ly;
-    int band = l / a.bandRows;
-    return (band * a.bandWorld + a.bandRank) * a.bandRows + (l - band * a.bandRows);
+    if (bandRows == 0) return y0 + ly;
+    int l = localRow0 + ly;
+    int band = l / bandRows;
+    return (band * bandWorld + bandRank) * bandRows + (l - band * bandRows);
 }
+PT_DEV int global_row(const FrameArgs &a, int ly) { return global_row_v(a.bandRows, a.bandWorld, a.bandRank, a.localRow0, a.y0, ly); }
 
 PT_DEV uint32_t pixel_seed(int px, int py, int frame)
 {
@@ -524,7 +532,7 @@ PT_DEV int xcd_band_id(int b, int nwg)
 __global__ __launch_bounds__(256) void pt_integrate_kernel(const FrameArgs a)
 {
     SceneLds sc = stage_scene(a);
-    EnvRef env{a.env, sc.lut, a.envSize, a.envFormat};
+    EnvRef env{a.env, (LdsFloats)sc.lut, a.envSize, a.envFormat};
     const int tid = threadIdx.x;
     const int b = xcd_band_id(blockIdx.x, gridDim.x);
     const int wave = tid >> 6, lane = tid & 63;
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(256) void pt_integrate_kernel(const FrameArgs a)
 __global__ __launch_bounds__(256) void pt_integrate_pool_kernel(const FrameArgs a, const int poolTiles)
 {
     SceneLds sc = stage_scene(a);
-    EnvRef env{a.env, sc.lut, a.envSize, a.envFormat};
+    EnvRef env{a.env, (LdsFloats)sc.lut, a.envSize, a.envFormat};
     const int tid = threadIdx.x;
     const int b = xcd_band_id(blockIdx.x, gridDim.x);
     const int wave = tid >> 6;
@@ -650,6 +658,11 @@ struct BlockQueue {            // one per workgroup, in static LDS
 };
 
 
+// relaxed workgroup-scope loads/stores of LDS control words (compile to ds_read / ds_write, never cached in registers)
+PT_DEV unsigned int lds_load(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+PT_DEV unsigned long long lds_load64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+PT_DEV void lds_store(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 // Next tile for this wavefront, or -1 when the frame's tiles are all handed out.  Wave-uniform result.
 PT_DEV int queue_pop_tile(BlockQueue *q)
 {
@@ -660,23 +673,23 @@ PT_DEV int queue_pop_tile(BlockQueue *q)
         unsigned int cursor = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)old);
         unsigned int end = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(old >> 32));
         if (cursor < end) return (int)cursor;
-        if (__builtin_amdgcn_readfirstlane((int)((volatile BlockQueue *)q)->done)) return -1;
+        if (__builtin_amdgcn_readfirstlane((int)lds_load(&q->done))) return -1;
         unsigned int got = 1;
         if (leader) got = atomicCAS(&q->lock, 0u, 1u);
         if (__builtin_amdgcn_readfirstlane((int)got) == 0) { // this wavefront refills
             // re-check under the lock: another wavefront may have refilled or hit the end meanwhile (a workgroup
             // must draw exactly ONE failing ticket per launch — the host's queueBase accounting relies on it)
-            unsigned long long cur = ((volatile BlockQueue *)q)->pair;
-            unsigned int isDone = ((volatile BlockQueue *)q)->done;
+            unsigned long long cur = lds_load64(&q->pair);
+            unsigned int isDone = lds_load(&q->done);
             if (!isDone && (unsigned int)cur >= (unsigned int)(cur >> 32)) {
                 unsigned int ticket = 0;
-                const FrameArgs *ca = cold_args();
+                ColdArgs ca = cold_args();
                 const int numTiles = ca->tilesX * ca->tilesY, chunk = ca->queueChunk;
                 if (leader) ticket = atomicAdd(ca->queue, 1u) - ca->queueBase;
                 ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
                 long long first = ((long long)gridDim.x + ticket) * chunk;
                 if (first >= numTiles) {
-                    if (leader) ((volatile BlockQueue *)q)->done = 1u;
+                    if (leader) lds_store(&q->done, 1u);
                 } else {
                     long long last = first + chunk < numTiles ? first + chunk : numTiles;
                     if (leader) atomicExch(&q->pair, ((unsigned long long)last << 32) | (unsigned long long)first);
@@ -735,13 +748,12 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         drain.lock = 0u;
     }
     SceneLds sc = stage_scene(a); // ends with __syncthreads()
-    EnvRef env{nullptr, sc.lut, 0, 0}; // descriptor is cold-loaded at the miss-shading site (bounce_step)
+    EnvRef env{nullptr, (LdsFloats)sc.lut, 0, 0}; // descriptor is cold-loaded at the miss-shading site (bounce_step)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // the ring lives behind the staged scene in dynamic LDS
     RingEntry *ringBase = (RingEntry *)((char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat));
     RingEntry *ring = ringBase + wave * 64;
     PathState *pool = (PathState *)(ringBase + NWAVES * 64);
-    volatile DrainControl *dc = &drain;
     const bool compaction = a.drainCompaction != 0;
     const int donateMax = a.drainCompaction < DONATE_MAX ? a.drainCompaction : DONATE_MAX; // a wavefront this thin donates
     const bool leader = lane == 0;
@@ -773,9 +785,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         if (TIMELINE) tExhausted = wall_clock64();
                     } else {
                         // camera block: FrameArgs is the kernel's first argument, so it starts the kernarg segment
-                        const float *cam = (const float *)__builtin_amdgcn_kernarg_segment_ptr();
-                        asm volatile("" : "+s"(cam)); // opaque: load the camera here, do not keep it live across the loop
-                        const FrameArgs *ca = (const FrameArgs *)cam;
+                        ColdArgs ca = cold_args(); // opaque: load the camera here, do not keep it live across the loop
+                        ColdFloats cam = (ColdFloats)ca;
                         const int width = ca->width, tilesX = ca->tilesX;
                         const float invW = f_div_ieee(1.0f, (float)width), invH = f_div_ieee(1.0f, (float)ca->height);
                         int tx = (int)(tile % tilesX), ty = (int)(tile / tilesX);
@@ -784,7 +795,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         e.pix = -1;
                         e.pxy = 0; e.seed = 0; e.ox = e.oy = e.oz = e.dx = e.dy = e.dz = 0.0f; e.pad = 0;
                         if (x < width && ly < ca->rows) {
-                            int gy = global_row(*ca, ly);
+                            int gy = global_row_v(ca->bandRows, ca->bandWorld, ca->bandRank, ca->localRow0, ca->y0, ly);
                             uint32_t sd = pixel_seed(x, gy, ca->frame);
                             v3 o, d;
                             primary_ray_cam(cam, invW, invH, x, gy, sd, o, d);
@@ -831,7 +842,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                 // (ring entries left: the remaining idle lanes popped out-of-image entries of a ragged tile)
             } else if (exhausted && compaction) {
                 // ---- drain: idle lanes adopt donated paths from the workgroup's pool
-                unsigned int pushed = dc->pushed, taken = dc->taken;
+                unsigned int pushed = lds_load(&drain.pushed), taken = lds_load(&drain.taken);
                 pushed = (unsigned int)__builtin_amdgcn_readfirstlane((int)pushed);
                 taken = (unsigned int)__builtin_amdgcn_readfirstlane((int)taken);
                 if (pushed > taken) {
@@ -872,7 +883,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             old = (unsigned int)__builtin_amdgcn_readfirstlane((int)old);
             if (old > 1u) break;
             lastAlive = true;
-            unsigned int pushing = dc->pushing, pushed = dc->pushed, taken = dc->taken;
+            unsigned int pushing = lds_load(&drain.pushing), pushed = lds_load(&drain.pushed), taken = lds_load(&drain.taken);
             bool pending = __builtin_amdgcn_readfirstlane((int)(pushing != 0u || pushed != taken)) != 0;
             if (!pending) break;
             if (leader) atomicAdd(&drain.alive, 1u);
@@ -891,7 +902,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             if (committed) {
                 if (leader) {
                     while (atomicCAS(&drain.lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
-                    base = dc->pushed;
+                    base = lds_load(&drain.pushed);
                 }
                 base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
                 unsigned int n = (unsigned int)__builtin_popcountll(am);
@@ -913,7 +924,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (leader) {
-                        dc->pushed = base + n;
+                        lds_store(&drain.pushed, base + n);
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         atomicExch(&drain.lock, 0u);
                         atomicSub(&drain.pushing, 1u);
