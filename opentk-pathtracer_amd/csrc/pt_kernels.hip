@@ -155,10 +155,18 @@ PT_DEV v3 sample_env(const EnvRef &e, v3 d)
     float w00 = (1.0f - wu) * (1.0f - wv), w10 = wu * (1.0f - wv), w01 = (1.0f - wu) * wv, w11 = wu * wv;
     v3 t00, t10, t01, t11;
     if (!(offx0 || offx1 || offy0 || offy1)) { // interior: the overwhelmingly common case
-        t00 = env_texel(e, face, x0, y0);
-        t10 = env_texel(e, face, x1, y0);
-        t01 = env_texel(e, face, x0, y1);
-        t11 = env_texel(e, face, x1, y1);
+        // one base index, the other three taps at +1, +S, +S+1 (32-bit index math, a single 64-bit address)
+        const unsigned base = ((unsigned)face * (unsigned)S + (unsigned)y0) * (unsigned)S + (unsigned)x0;
+        if (e.format == 0) {
+            const float4 *p = (const float4 *)e.data + base;
+            float4 a = p[0], b = p[1], c = p[S], d = p[S + 1];
+            t00 = V(a.x, a.y, a.z); t10 = V(b.x, b.y, b.z); t01 = V(c.x, c.y, c.z); t11 = V(d.x, d.y, d.z);
+        } else {
+            const uchar4 *p = (const uchar4 *)e.data + base;
+            uchar4 a = p[0], b = p[1], c = p[S], d = p[S + 1];
+            t00 = V(e.lut[a.x], e.lut[a.y], e.lut[a.z]); t10 = V(e.lut[b.x], e.lut[b.y], e.lut[b.z]);
+            t01 = V(e.lut[c.x], e.lut[c.y], e.lut[c.z]); t11 = V(e.lut[d.x], e.lut[d.y], e.lut[d.z]);
+        }
     } else {
         bool miss00 = offx0 && offy0, miss10 = offx1 && offy0, miss01 = offx0 && offy1, miss11 = offx1 && offy1;
         v3 zero = V(0.0f, 0.0f, 0.0f);
