@@ -229,7 +229,17 @@ def gen_post():
     save("post_aces_gamma", image=img, expected=out[..., :3].copy())
 
 
-GROUPS = {"post": gen_post, "envs": gen_envs, "micro": gen_micro, "frames": gen_frames, "envonly": gen_envonly, "sparse": gen_sparse,
+def gen_converged():
+    print("converged accumulation (statistical parity: the branch-flip pixels average out):")
+    w = configs.Workload("default_96x54_d8_acc96", "default", 96, 54, 8, "sky_f32_32", frames=96)
+    sc, basic, objs, env, kw = configs.inputs(w)
+    out = ref.run_pathtracer(w.width, w.height, basic, objs, env, num_frames=w.frames, **kw)
+    ip, fp = params_array(w, kw)
+    save("converged_" + w.name, basic=np.frombuffer(basic, np.uint8), objects=np.frombuffer(objs, np.uint8),
+         env_key=np.array(w.env), iparams=ip, fparams=fp, expected=out[0, ..., :3].copy())
+
+
+GROUPS = {"converged": gen_converged, "post": gen_post, "envs": gen_envs, "micro": gen_micro, "frames": gen_frames, "envonly": gen_envonly, "sparse": gen_sparse,
           "atmo": gen_atmo}
 
 if __name__ == "__main__":

@@ -1,0 +1,18 @@
+#!/bin/bash
+# BASELINE.json's other configs through bench.py (one JSON line each) -> gpurun_out/bench_configs.jsonl
+R=/root/repo
+O=$R/gpurun_out/bench_configs.jsonl
+: > $O
+python $R/bench.py --no-cpu-baseline >> $O                                       # C2: default scene, 1080p, 8 bounces
+python $R/bench.py --no-cpu-baseline --scene stress256 >> $O                     # C3: 256-sphere scene (fills the UBO)
+python $R/bench.py --no-cpu-baseline --scene glass --depth 32 >> $O              # C5: glass-heavy, 32 bounces, atmosphere env
+python $R/bench.py --no-cpu-baseline --env sky2048 >> $O                         # default scene with a 2048^2 sRGB sky cube
+python $R/bench.py --no-cpu-baseline --depth 13 >> $O                            # the reference's shipped default depth
+python $R/bench.py --no-cpu-baseline --spp 4 --steps 100 >> $O                   # 4 samples per pixel per frame
+python $R/bench.py --no-cpu-baseline --variant 1 >> $O                           # tile-per-wave kernel (reference mapping)
+python $R/bench.py --no-cpu-baseline --variant 14 >> $O                          # persistent kernel, one launch per frame
+python - <<PY
+import json
+for l in open("$O"):
+    d = json.loads(l); print(d["value"], d["ms_per_step"], d["config"]["workload"][:90], "variant", d["config"]["kernel_variant"])
+PY
