@@ -108,6 +108,9 @@ def main():
     args = ap.parse_args()
 
     pkg = graft.load_package()
+    if not os.path.exists(pkg.native.LIB_PATH):  # fresh checkout without built artefacts: hipcc is part of the image
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            graft.build()
     from opentk_pathtracer_amd import distributed as D
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
