@@ -111,6 +111,11 @@ def main():
     if not os.path.exists(pkg.native.LIB_PATH):  # fresh checkout without built artefacts: hipcc is part of the image
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
             graft.build()
+        else:  # other ranks wait for rank 0's build instead of racing it
+            t_wait = time.time()
+            while not os.path.exists(pkg.native.LIB_PATH) and time.time() - t_wait < 300:
+                time.sleep(1.0)
+            time.sleep(2.0)
     from opentk_pathtracer_amd import distributed as D
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
