@@ -23,6 +23,22 @@
 #include "pt_kernels.hpp"
 #include "pt_math.hpp"
 
+// Section profiling (tuning builds only: hipcc -DPT_PROFILE): per-wavefront s_memtime deltas accumulated per section of
+// the bounce iteration and added to FrameArgs::timeline[0..7] at the end.  Compiled out of the product build.
+#ifdef PT_PROFILE
+#define PROF_PARAM , unsigned long long *prof
+#define PROF_PASS , prof
+#define PROF_DUMMY , prof_dummy
+#define PROF_BEGIN unsigned long long prof_t = __builtin_readcyclecounter();
+#define PROF_MARK(slot) { unsigned long long n_ = __builtin_readcyclecounter(); prof[slot] += n_ - prof_t; prof_t = n_; }
+#else
+#define PROF_PARAM
+#define PROF_PASS
+#define PROF_DUMMY
+#define PROF_BEGIN
+#define PROF_MARK(slot)
+#endif
+
 namespace pt {
 
 struct Material { // std140 Material, compute.glsl:13-26
@@ -220,8 +236,9 @@ PT_DEV Material load_material(const float4 *m)
 // compute.glsl:226-258 RayTrace (+ :261-294 intersections, :316-332 normals).
 // Acceptance uses the ENTRY distance t1 against the stored GetSmallestPositive (compute.glsl:234,247,347-350);
 // objects are visited in reference order; material + normal are evaluated once for the surviving candidate.
-PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h)
+PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h PROF_PARAM)
 {
+    PROF_BEGIN
     float T = FLOAT_MAX, wt2 = 0.0f;
     int winner = -1;
     // Sphere pass, 4 spheres per step: the four discriminants are computed branch-free from four broadcast LDS
@@ -231,7 +248,7 @@ PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h)
     // (sqrt(b*b - c) <= b when c > 0), so it is rejected before the square root — an exact shortcut.
     auto candidate = [&](int i, float b, float c, float disc) {
         if (!(disc < 0.0f) && !(c > 0.0f && b > 1e-10f)) {
-            float sq = f_sqrt(disc);
+            float sq = pt_sqrt(disc);
             float t1 = -b - sq, t2 = -b + sq;
             if (t1 <= t2 && t2 > 0.0f && t1 < T) {
                 T = t1 < 0.0f ? t2 : t1;
@@ -262,6 +279,7 @@ PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h)
         float c = f_fma(-s.w, s.w, v_dot(oc, oc));
         candidate(i, b, c, f_fma(b, b, -c));
     }
+    PROF_MARK(1) // sphere pass
     v3 invd = V(f_rcp(d.x), f_rcp(d.y), f_rcp(d.z)); // slab test by reciprocal (pt-f32 contract)
     for (int i = 0; i < nc; i++) {
         float4 mn = sc.cmin[i], mx = sc.cmax[i];
@@ -277,6 +295,7 @@ PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h)
             winner = 256 + i;
         }
     }
+    PROF_MARK(2) // cuboid pass
     if (winner < 0 || !(T != FLOAT_MAX)) return false; // compute.glsl:257
     h.T = T;
     h.fromInside = (T == wt2);
@@ -292,6 +311,7 @@ PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h)
         h.m = load_material(sc.mat + 4 * (ns + ci));
         h.normal = cuboid_normal(V(mn.x, mn.y, mn.z), V(mx.x, mx.y, mx.z), h.nearHitPos);
     }
+    PROF_MARK(3) // winner: material + normal
     return true;
 }
 
@@ -301,7 +321,7 @@ PT_DEV v3 cosine_sample_hemisphere(v3 n, uint32_t &seed)
 {
     float z = f_fma(rand01(seed), 2.0f, -1.0f);
     float a = rand01(seed) * 2.0f * PI;
-    float r = f_sqrt(f_fma(-z, z, 1.0f));
+    float r = pt_sqrt(f_fma(-z, z, 1.0f));
     float sn, cs;
     pt_sincos(a, sn, cs);
     return v_normalize(v_add(n, V(r * cs, r * sn, z)));
@@ -322,7 +342,7 @@ PT_DEV v3 f_refract(v3 i, v3 n, float eta)
     float ni = v_dot(n, i);
     float k = f_fma(-(eta * eta), f_fma(-ni, ni, 1.0f), 1.0f);
     if (k < 0.0f) return V(0.0f, 0.0f, 0.0f);
-    float f = f_fma(eta, ni, f_sqrt(k));
+    float f = f_fma(eta, ni, pt_sqrt(k));
     return V(f_fma(eta, i.x, -(f * n.x)), f_fma(eta, i.y, -(f * n.y)), f_fma(eta, i.z, -(f * n.z)));
 }
 
@@ -367,18 +387,21 @@ PT_DEV float bsdf(v3 &ro, v3 &rd, const Hit &h, bool &isRefractive, uint32_t &se
 // One iteration of Radiance's bounce loop (compute.glsl:140-180) for one path.  Returns true when the path
 // continues (hit, survived Russian roulette), false when it ended (miss -> environment, or roulette kill).
 PT_DEV bool bounce_step(const SceneLds &sc, int ns, int nc, const EnvRef &env, v3 &ro, v3 &rd, v3 &throughput, v3 &rad,
-                        uint32_t &seed)
+                        uint32_t &seed PROF_PARAM)
 {
     Hit h;
-    if (ray_trace(sc, ns, nc, ro, rd, h)) {
+    if (ray_trace(sc, ns, nc, ro, rd, h PROF_PASS)) {
+        PROF_BEGIN
         if (h.fromInside) { // Beer's law, compute.glsl:145-149
             h.normal = v_neg(h.normal);
             throughput.x *= pt_exp(-h.m.absorbance.x * h.T);
             throughput.y *= pt_exp(-h.m.absorbance.y * h.T);
             throughput.z *= pt_exp(-h.m.absorbance.z * h.T);
         }
+        PROF_MARK(4) // Beer
         bool isRefractive;
         float prob = bsdf(ro, rd, h, isRefractive, seed);
+        PROF_MARK(5) // BSDF
         rad = V(f_fma(h.m.emissiv.x, throughput.x, rad.x), f_fma(h.m.emissiv.y, throughput.y, rad.y),
                 f_fma(h.m.emissiv.z, throughput.z, rad.z));
         if (!isRefractive) throughput = v_mul(throughput, h.m.albedo);
@@ -388,6 +411,7 @@ PT_DEV bool bounce_step(const SceneLds &sc, int ns, int nc, const EnvRef &env, v
         throughput = v_scale(throughput, f_rcp(p));
         return true;
     }
+    PROF_BEGIN
     v3 e;
     if (env.data == nullptr) { // persistent kernel: fetch the environment descriptor where it is needed (see cold_args)
         ColdArgs ca = cold_args();
@@ -397,15 +421,19 @@ PT_DEV bool bounce_step(const SceneLds &sc, int ns, int nc, const EnvRef &env, v
         e = sample_env(env, rd);
     }
     rad = V(f_fma(e.x, throughput.x, rad.x), f_fma(e.y, throughput.y, rad.y), f_fma(e.z, throughput.z, rad.z));
+    PROF_MARK(6) // miss shading
     return false;
 }
 
 // compute.glsl:132-182 Radiance
 PT_DEV v3 radiance(const FrameArgs &a, const SceneLds &sc, const EnvRef &env, v3 ro, v3 rd, uint32_t &seed)
 {
+#ifdef PT_PROFILE
+    unsigned long long prof_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     v3 throughput = V(1.0f, 1.0f, 1.0f), rad = V(0.0f, 0.0f, 0.0f);
     for (int i = 0; i < a.rayDepth; i++)
-        if (!bounce_step(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed)) break;
+        if (!bounce_step(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed PROF_DUMMY)) break;
     return rad;
 }
 
@@ -437,7 +465,7 @@ PT_DEV void primary_ray_cam(FP cam, float invW, float invH, int px, int py, uint
     v3 dir = v_normalize(V(wd[0], wd[1], wd[2]));
     v3 focal = v_fma(dir, cam[35], viewPos); // :117
     float angle = rand01(seed) * 2.0f * PI;
-    float rr = f_sqrt(rand01(seed));
+    float rr = pt_sqrt(rand01(seed));
     float sn, cs;
     pt_sincos(angle, sn, cs);
     float half_ap = cam[36] * 0.5f;
@@ -576,6 +604,9 @@ __global__ __launch_bounds__(256) void pt_integrate_pool_kernel(const FrameArgs 
     const int poolEnd = (tileEnd < numTiles ? tileEnd : numTiles) * 64;
     if (next >= poolEnd) return;
 
+#ifdef PT_PROFILE
+    unsigned long long prof_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     // per-lane path state
     int pix = -1;           // linear index into accum, -1 = lane has no pixel
     int px = 0, py = 0, sample = 0, bounce = 0;
@@ -622,7 +653,7 @@ __global__ __launch_bounds__(256) void pt_integrate_pool_kernel(const FrameArgs 
         // ---- one bounce for every active lane
         if (active) {
             bool cont = false;
-            if (bounce < a.rayDepth) cont = bounce_step(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed);
+            if (bounce < a.rayDepth) cont = bounce_step(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed PROF_DUMMY);
             bounce++;
             if (!cont || bounce >= a.rayDepth) {
                 irr = v_add(irr, rad);
@@ -769,6 +800,10 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     int avail = 0;           // wave-uniform: ring entries [0, avail) are unconsumed
     bool exhausted = false;
     bool lastAlive = false;  // this wavefront found itself the last one of its workgroup: it can neither donate nor leave early
+#ifdef PT_PROFILE
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
     unsigned long long tStart = 0, tExhausted = 0, nIter = 0;
     if (TIMELINE) tStart = wall_clock64();
 
@@ -950,6 +985,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             }
         }
         if (TIMELINE) nIter++;
+        PROF_MARK(0) // feed: ring refill / pop / adopt / donate
         if (active && needRay) { // only for spp > 1: the next sample continues the pixel's RNG stream (compute.glsl:110)
             primary_ray(a, px, py, seed, ro, rd);
             throughput = V(1.0f, 1.0f, 1.0f);
@@ -959,8 +995,11 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         }
         if (active) {
             bool cont = false;
-            if (bounce < a.rayDepth) cont = bounce_step(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed);
+            if (bounce < a.rayDepth) cont = bounce_step(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed PROF_PASS);
             bounce++;
+#ifdef PT_PROFILE
+            prof_t = __builtin_readcyclecounter();
+#endif
             if (!cont || bounce >= a.rayDepth) {
                 irr = v_add(irr, rad);
                 sample++;
@@ -973,7 +1012,12 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                 }
             }
         }
+        PROF_MARK(7) // resolve
     }
+#ifdef PT_PROFILE
+    if (a.timeline && lane == 0)
+        for (int k = 0; k < 8; k++) atomicAdd(a.timeline + 200000 + k, prof[k]);
+#endif
     if (TIMELINE && lane == 0) {
         unsigned long long *t = a.timeline + ((size_t)blockIdx.x * NWAVES + wave) * 4;
         t[0] = tStart; t[1] = tExhausted; t[2] = wall_clock64(); t[3] = nIter;

@@ -55,7 +55,20 @@ PT_DEV float f_rsqrt(float x)
     if (x < 1.17549435e-38f) y = x < 0.0f ? __builtin_nanf("") : __builtin_inff();
     return y;
 }
-PT_DEV float f_sqrt(float a) { return __builtin_sqrtf(a); }
+PT_DEV float f_sqrt(float a) { return __builtin_sqrtf(a); } // correctly rounded (atmosphere precompute, uniform uses)
+// pt-f32 square root: two Newton steps y *= 1.5 - (x/2*y)*y on the classic inverse-square-root seed (4.7e-6), then one residual
+// correction s += (x - s*s) * y/2 (<= 0.501 ulp).  sqrt(0) = 0 exactly; negative, infinite and NaN inputs give a non-finite
+// value (every call site guards its argument)..
+PT_DEV float pt_sqrt(float x)
+{
+    float y = __uint_as_float(0x5F3759DFu - (__float_as_uint(x) >> 1));
+    float h = 0.5f * x, t;
+    t = h * y; t = f_fma(-t, y, 1.5f); y = y * t;
+    t = h * y; t = f_fma(-t, y, 1.5f); y = y * t;
+    float s = x * y;
+    float r = f_fma(-s, s, x);
+    return f_fma(r, 0.5f * y, s);
+}
 PT_DEV float f_abs(float a) { return __builtin_fabsf(a); }
 PT_DEV float f_mix(float x, float y, float a) { return f_fma(y, a, x * (1.0f - a)); }
 

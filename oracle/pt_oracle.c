@@ -16,7 +16,7 @@
  * tests/golden/ (generator: tests/golden/make_golden.py) and checked by tests/test_oracle_vs_reference.py.
  *
  * ARITHMETIC CONTRACT ("pt-f32", shared with the HIP kernel so that HIP == oracle BIT-FOR-BIT):
- *   - every value is IEEE-754 binary32; +,-,* and sqrt are correctly rounded; denormals are kept;
+ *   - every value is IEEE-754 binary32; +,-,* are correctly rounded; denormals are kept;
  *   - a*b+c is fused ONLY where this file writes fmaf() — compile with -ffp-contract=off;
  *   - dot(a,b)      = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
  *   - 1/x           = f_rcp(x): bit-trick seed 0x7EF311C7 - bits(x), three Newton steps y += y*fma(-x,y,1)
@@ -27,6 +27,9 @@
  *   - inversesqrt(x)= f_rsqrt(x): seed 0x5F3759DF - (bits(x)>>1), three Newton steps (<= 1.7 ulp; GLSL allows 2);
  *                     x < FLT_MIN -> +inf (x >= 0) or NaN (x < 0), so normalize(vec3(0)) is still NaN
  *   - normalize(v)  = v * f_rsqrt(dot(v,v))
+ *   - sqrt(x)       = pt_sqrt(x) on the per-bounce path (sphere roots, hemisphere / lens sampling, refract): the same
+ *                     seed, TWO Newton steps, then s = x*y; s += fma(-s,s,x) * (y/2)  (<= 0.501 ulp; GLSL inherits
+ *                     sqrt's precision from 1/inversesqrt = 2 ulp).  The atmosphere precompute keeps IEEE sqrtf.
  *   - mix(x,y,a)    = fma(y, a, x*(1-a))                       (GLSL 4.50 section 8.3 definition)
  *   - min/max       = IEEE minNum/maxNum (fminf/fmaxf); GLSL leaves NaN handling undefined
  *   - sin/cos/exp   = the fixed polynomial algorithms below (<= ~1.5 ulp), pow(x,5) = x*(x^2)^2,
@@ -82,6 +85,19 @@ static inline float f_rsqrt(float x)
     t = y * y; t = fmaf(-h, t, 1.5f); y = y * t;
     if (x < 1.17549435e-38f) y = x < 0.0f ? NAN : INFINITY;
     return y;
+}
+/* pt-f32 square root: two Newton steps y *= 1.5 - (x/2*y)*y on the same seed (4.7e-6), then one residual correction
+ * s += (x - s*s) * y/2  (<= 0.501 ulp); sqrt(0) = 0 exactly; negative, infinite and NaN inputs give a non-finite value
+ * (every call site guards its argument: discriminant >= 0, 1 - z*z >= 0, k >= 0, rand in [0,1]) */
+static inline float pt_sqrt(float x)
+{
+    float y = f_unbits(0x5F3759DFu - (f_bits(x) >> 1));
+    float h = 0.5f * x, t;
+    t = h * y; t = fmaf(-t, y, 1.5f); y = y * t;
+    t = h * y; t = fmaf(-t, y, 1.5f); y = y * t;
+    float s = x * y;
+    float r = fmaf(-s, s, x);
+    return fmaf(r, 0.5f * y, s);
 }
 static inline float f_mix(float x, float y, float a) { return fmaf(y, a, x * (1.0f - a)); }
 
@@ -312,7 +328,7 @@ static int ray_sphere(v3 o, v3 d, v3 pos, float radius, float *t1, float *t2)
     float c = fmaf(-radius, radius, v_dot(oc, oc));
     float disc = fmaf(b, b, -c);
     if (disc < 0.0f) return 0;
-    float s = sqrtf(disc);
+    float s = pt_sqrt(disc);
     *t1 = -b - s;
     *t2 = -b + s;
     return *t1 <= *t2;
@@ -406,7 +422,7 @@ static v3 cosine_sample_hemisphere(v3 n, uint32_t *seed)
 {
     float z = fmaf(rand01(seed), 2.0f, -1.0f);
     float a = rand01(seed) * 2.0f * PI;
-    float r = sqrtf(fmaf(-z, z, 1.0f));
+    float r = pt_sqrt(fmaf(-z, z, 1.0f));
     float sn, cs;
     f_sincos(a, &sn, &cs);
     return v_normalize(v_add(n, V(r * cs, r * sn, z)));
@@ -427,7 +443,7 @@ static v3 f_refract(v3 i, v3 n, float eta)
     float ni = v_dot(n, i);
     float k = fmaf(-(eta * eta), fmaf(-ni, ni, 1.0f), 1.0f);
     if (k < 0.0f) return V(0.0f, 0.0f, 0.0f);
-    float f = fmaf(eta, ni, sqrtf(k));
+    float f = fmaf(eta, ni, pt_sqrt(k));
     return V(fmaf(eta, i.x, -(f * n.x)), fmaf(eta, i.y, -(f * n.y)), fmaf(eta, i.z, -(f * n.z)));
 }
 
@@ -520,7 +536,7 @@ static void shade_pixel(const Ctx *c, int px, int py, int frame, const float *la
         v3 focal = v_fma(dir, c->focalLength, c->viewPos); /* :117 */
         /* UniformSampleUnitCircle :309-314 */
         float angle = rand01(&seed) * 2.0f * PI;
-        float rr = sqrtf(rand01(&seed));
+        float rr = pt_sqrt(rand01(&seed));
         float sn, cs;
         f_sincos(angle, &sn, &cs);
         float half_ap = c->apertureDiameter * 0.5f;
@@ -762,6 +778,10 @@ PTO_API int pto_postprocess(const float *rgba, int n, float *out_f, uint8_t *out
     return 0;
 }
 PTO_API float pto_log(float x) { return f_log(x); }
+/* the contract's software reciprocal / inverse square root / square root, array form (accuracy property tests) */
+PTO_API void pto_rcp_array(const float *x, float *y, int n) { for (int i = 0; i < n; i++) y[i] = f_rcp(x[i]); }
+PTO_API void pto_rsqrt_array(const float *x, float *y, int n) { for (int i = 0; i < n; i++) y[i] = f_rsqrt(x[i]); }
+PTO_API void pto_sqrt_array(const float *x, float *y, int n) { for (int i = 0; i < n; i++) y[i] = pt_sqrt(x[i]); }
 
 /* ------------------------------------------------------------------ atmosphere precompute
  * res/shaders/AtmosphericScattering/compute.glsl:30-171 (algorithm credited there to

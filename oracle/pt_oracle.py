@@ -155,6 +155,24 @@ class Oracle:
     def log(self, x):
         return self.lib.pto_log(float(x))
 
+    def _array_fn(self, name, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty_like(x)
+        fn = getattr(self.lib, name)
+        fn.restype = None
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        fn(x.ctypes.data, y.ctypes.data, x.size)
+        return y
+
+    def rcp(self, x):
+        return self._array_fn("pto_rcp_array", x)
+
+    def rsqrt(self, x):
+        return self._array_fn("pto_rsqrt_array", x)
+
+    def sqrt(self, x):
+        return self._array_fn("pto_sqrt_array", x)
+
     # ---------------------------------------------------------------- micro helpers
     def rand_stream(self, seed: int, n: int):
         s = C.c_uint32(seed)

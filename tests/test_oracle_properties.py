@@ -98,3 +98,28 @@ def test_spp_continues_the_rng_stream(oracle):
     one = oracle.render(w.width, w.height, basic, objs, env, **kw)
     assert np.isfinite(a).all() and not np.array_equal(a, one)
     assert abs(a[..., :3].mean() - one[..., :3].mean()) < 0.15 * one[..., :3].mean()
+
+
+def _ulp_error(got, exact64):
+    """|got - exact| in units of the float32 ulp at `exact`"""
+    exact32 = exact64.astype(np.float32)
+    ulp = np.spacing(np.abs(exact32)).astype(np.float64)
+    return np.abs(got.astype(np.float64) - exact64) / ulp
+
+
+def test_contract_reciprocal_root_accuracy(oracle):
+    """The pt-f32 software 1/x, 1/sqrt(x), sqrt(x) (oracle/pt_oracle.c header) stay inside the bounds the contract
+    states — far inside what GLSL 4.50 section 4.7.1 allows (2.5 ulp for a/b, 2 ulp for inversesqrt)."""
+    rng = np.random.RandomState(7)
+    x = np.exp(rng.uniform(np.log(1e-30), np.log(1e30), 2_000_000)).astype(np.float32)
+    x = np.concatenate([x, rng.uniform(0.0, 4.0, 1_000_000).astype(np.float32) + np.float32(1e-6)])
+    x64 = x.astype(np.float64)
+    assert _ulp_error(oracle.rcp(x), 1.0 / x64).max() <= 0.52
+    assert _ulp_error(oracle.rcp(-x), -1.0 / x64).max() <= 0.52
+    assert _ulp_error(oracle.rsqrt(x), 1.0 / np.sqrt(x64)).max() <= 1.75
+    assert _ulp_error(oracle.sqrt(x), np.sqrt(x64)).max() <= 0.502
+    # special values are part of the contract
+    sp = oracle.sqrt(np.array([0.0, 1.0, 4.0, np.inf, -1.0, np.nan], np.float32))
+    assert sp[0] == 0.0 and sp[1] == 1.0 and sp[2] == 2.0 and not np.isfinite(sp[3:]).any()
+    assert np.isinf(oracle.rcp(np.array([0.0], np.float32)))[0] and np.isinf(oracle.rsqrt(np.array([0.0], np.float32)))[0]
+    assert np.isnan(oracle.rsqrt(np.array([-1.0], np.float32)))[0]

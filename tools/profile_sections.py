@@ -1,0 +1,29 @@
+"""Per-section cycle breakdown of the persistent kernel's bounce iteration (needs the -DPT_PROFILE build:
+    hipcc ... -DPT_PROFILE csrc/pt_kernels.hip csrc/mi355pt.cpp -o tools/ab/libP.so ;  MI355PT_LIB=tools/ab/libP.so python tools/profile_sections.py)"""
+import os, sys, ctypes as C
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+pkg = g.load_package()
+lib = pkg.native.load()
+scene_name = sys.argv[1] if len(sys.argv) > 1 else "default"
+W, H = 1920, 1080
+sc = {"default": pkg.scene.default_scene, "stress": pkg.scene.stress_scene, "glass": pkg.scene.glass_scene}[scene_name]()
+cam = pkg.camera.Camera()
+pt = pkg.PathTracer(pkg.envmap.synthetic_sky_rgba32f(64), W, H, 8 if scene_name != "glass" else 32, 1, 20.0, 0.14)
+pt.SetVariant(14); pt.UploadScene(sc); pt.UploadBasicData(pkg.camera.basic_data_ubo(cam, W, H))
+for _ in range(5): pt.Render()
+lib.pt_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+lib.pt_debug_timeline(pt._h, None, 0)          # allocate + zero
+frames = 10
+for _ in range(frames): pt.Render()
+pt.Synchronize()
+buf = np.zeros((65536, 4), np.uint64)
+lib.pt_debug_timeline(pt._h, buf.ctypes.data_as(C.c_void_p), 65536)
+prof = buf.reshape(-1)[200000:200008].astype(np.float64) / frames
+names = ["feed (refill/pop/adopt/donate)", "sphere pass", "cuboid pass (+3 rcp)", "winner material+normal", "Beer absorption",
+         "BSDF", "miss shading (env)", "RR + resolve + bookkeeping"]
+tot = prof.sum()
+print(f"scene {scene_name}: wave-cycles per frame (s_memtime ticks, summed over wavefronts): {tot:.3e}")
+for n, v in zip(names, prof):
+    print(f"  {n:34s} {100 * v / tot:6.2f} %")
