@@ -430,7 +430,6 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     int stripes = 1, kernelVariant = h->variant;
     if (h->variant == 0) { stripes = 2; kernelVariant = 14; }
     else if (h->variant >= 20 && h->variant < 50) { stripes = h->variant / 10; kernelVariant = 10 + h->variant % 10; }
-    else if (h->variant >= 250 && h->variant < 270) { stripes = 2; kernelVariant = h->variant - 200; } // 2 stripes x 512/1024-thread WGs
     if (h->rows < 16 * stripes) stripes = 1; // tiny tiles: not worth splitting
     a.variant = kernelVariant;
 

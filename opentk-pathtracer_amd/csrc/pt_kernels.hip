@@ -65,11 +65,15 @@ struct SceneLds {
     const float4 *mat;  // [(numSpheres + numCuboids) * 4]
     const float *invr;  // [numSpheres rounded up to 4] 1 / radius (IEEE quotient, computed once per workgroup)
     const float *lut;   // [256] sRGB8 -> linear (only staged for SRGB8_A8 environments)
+    const float4 *objects; // the std140 GameObjectsUBO in device memory (materials of large scenes are read from here)
 };
 
-__host__ __device__ inline size_t scene_lds_bytes(int ns, int nc, int envFormat)
+// Geometry (16 B per sphere + 4 B 1/radius, 32 B per cuboid) is read by every ray and always lives in LDS.  The
+// 64-byte materials are read once per hit, by the winner only: they are staged too while the workgroup still fits
+// 5-per-CU, and stay in device memory (L2-resident, 26 KB) for large scenes, where they would cost a resident workgroup.
+__host__ __device__ inline size_t scene_lds_bytes(int ns, int nc, int envFormat, bool matInLds)
 {
-    return (size_t)(ns + 2 * nc + 4 * (ns + nc)) * 16 + (size_t)((ns + 3) & ~3) * 4 + (envFormat == 1 ? 1024 : 0);
+    return (size_t)(ns + 2 * nc + (matInLds ? 4 * (ns + nc) : 0)) * 16 + (size_t)((ns + 3) & ~3) * 4 + (envFormat == 1 ? 1024 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------- environment
@@ -236,7 +240,11 @@ PT_DEV Material load_material(const float4 *m)
 // compute.glsl:226-258 RayTrace (+ :261-294 intersections, :316-332 normals).
 // Acceptance uses the ENTRY distance t1 against the stored GetSmallestPositive (compute.glsl:234,247,347-350);
 // objects are visited in reference order; material + normal are evaluated once for the surviving candidate.
-PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h PROF_PARAM)
+// MASKED: only the spheres whose bit is set in the wave-uniform masks[0..3] are visited (still in index order).  The
+// masks come from cull_spheres(): a sphere outside them fails its own `t2 > 0` / discriminant test for EVERY ray of
+// the wavefront, and a sphere that fails its own test never changes T — skipping it cannot change the result.
+template <bool MASKED, bool MATLDS>
+PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, const unsigned long long *masks PROF_PARAM)
 {
     PROF_BEGIN
     float T = FLOAT_MAX, wt2 = 0.0f;
@@ -258,6 +266,23 @@ PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h PRO
         }
     };
     int i = 0;
+    if (MASKED) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w * 64 >= ns) break;
+            unsigned long long mk = masks[w];
+            while (mk != 0ull) {
+                int k = w * 64 + (int)__builtin_ctzll(mk);
+                mk &= mk - 1ull;
+                float4 s = sc.sph[k];
+                v3 oc = V(o.x - s.x, o.y - s.y, o.z - s.z);
+                float b = v_dot(d, oc);
+                float c = f_fma(-s.w, s.w, v_dot(oc, oc));
+                candidate(k, b, c, f_fma(b, b, -c));
+            }
+        }
+        i = ns;
+    }
     for (; i + 4 <= ns; i += 4) {
         float4 s0 = sc.sph[i], s1 = sc.sph[i + 1], s2 = sc.sph[i + 2], s3 = sc.sph[i + 3];
         float b[4], c[4], disc[4];
@@ -302,17 +327,91 @@ PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h PRO
     h.nearHitPos = v_fma(d, T, o);
     if (winner < 256) {
         float4 s = sc.sph[winner];
-        h.m = load_material(sc.mat + 4 * winner);
+        if (MATLDS) h.m = load_material(sc.mat + 4 * winner);
+        else h.m = load_material(sc.objects + 5 * winner + 1); // std140 Sphere = geometry + 4 x float4 material
         v3 pc = V(h.nearHitPos.x - s.x, h.nearHitPos.y - s.y, h.nearHitPos.z - s.z);
         h.normal = v_scale(pc, sc.invr[winner]); // compute.glsl:316-319; 1/radius = IEEE quotient staged in LDS
     } else {
         int ci = winner - 256;
         float4 mn = sc.cmin[ci], mx = sc.cmax[ci];
-        h.m = load_material(sc.mat + 4 * (ns + ci));
+        if (MATLDS) h.m = load_material(sc.mat + 4 * (ns + ci));
+        else h.m = load_material(sc.objects + 1280 + 6 * ci + 2); // Cuboids[] start at float4 index 1280: min, max, material
         h.normal = cuboid_normal(V(mn.x, mn.y, mn.z), V(mx.x, mx.y, mx.z), h.nearHitPos);
     }
     PROF_MARK(3) // winner: material + normal
     return true;
+}
+PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h PROF_PARAM)
+{
+    return ray_trace_t<false, true>(sc, ns, nc, o, d, h, nullptr PROF_PASS);
+}
+
+// ---- per-tile sphere culling for a wavefront of (nearly) coherent rays
+// Wavefront-wide maximum of a non-negative value.  row_shr:1/2/4/8 inside each row of 16 lanes (a lane shifted in
+// from outside the row contributes 0, the identity here), then row_bcast:15 / row_bcast:31 carry the row results
+// across the rows; lane 63 ends up with the maximum, which is broadcast.  Must be called with all 64 lanes active.
+PT_DEV float wave_max_nonneg(float x)
+{
+#define PT_DPP_MAX(ctrl, rowmask) \
+    x = __builtin_fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rowmask, 0xf, false)))
+    PT_DPP_MAX(0x111, 0xf);
+    PT_DPP_MAX(0x112, 0xf);
+    PT_DPP_MAX(0x114, 0xf);
+    PT_DPP_MAX(0x118, 0xf);
+    PT_DPP_MAX(0x142, 0xa);
+    PT_DPP_MAX(0x143, 0xc);
+#undef PT_DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+// The 64 primary rays of one 8x8 tile leave (almost) one point in (almost) one direction.  They are bounded by a cone:
+// apex region = ball of radius rho around one reference ray's origin O, axis A = that ray's direction, half-angle theta =
+// the largest angle any ray of the wavefront makes with A (both measured from the actual rays, so any camera matrix,
+// aperture or jitter is covered).  A ray (o, d) of the bundle can only reach sphere (c, r) with t > 0 if the ray (O, d)
+// reaches the sphere (c, R = r + rho), i.e. if |c - O| <= R or angle(A, c - O) <= theta + asin(R / |c - O|).  Lane j
+// tests sphere j (+64, +128, +192): masks[] = spheres that pass.  Every quantity is padded (0.1 % and absolute slack far
+// above float rounding), and the test only ever REMOVES spheres that no ray of the wavefront can hit — those would fail
+// `discriminant >= 0 && t2 > 0` (compute.glsl:261-277) for every lane and leave T untouched — so the traced result is
+// bit-identical to visiting all spheres.  Hardware sqrt/rcp approximations are fine here: they only move the padding.
+PT_DEV void cull_spheres(const SceneLds &sc, int ns, bool valid, v3 o, v3 d, unsigned long long masks[4])
+{
+    const int lane = threadIdx.x & 63;
+    masks[0] = masks[1] = masks[2] = masks[3] = 0ull;
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0ull) return;
+    const int ref = ((vm >> 36) & 1ull) ? 36 : (int)__builtin_ctzll(vm); // pixel (4,4) of the tile, else the first valid lane
+    const v3 O = V(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.x), ref)),
+                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.y), ref)),
+                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.z), ref)));
+    const v3 A = V(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.x), ref)),
+                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.y), ref)),
+                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.z), ref)));
+    const v3 dv = v_sub(o, O);
+    // a NaN ray hits nothing (every comparison of its intersection tests is false): fmax drops it from the bounds
+    float dev2 = wave_max_nonneg(__builtin_fmaxf(valid ? v_dot(dv, dv) : 0.0f, 0.0f));
+    float spread = wave_max_nonneg(__builtin_fmaxf(valid ? 1.0f - v_dot(A, d) : 0.0f, 0.0f)); // 1 - cos(angle to A)
+    const float rho = __builtin_amdgcn_sqrtf(dev2) * 1.001f;
+    const float ct = 1.0f - spread * 1.01f - 1e-5f;          // padded cos(theta)
+    const bool coneUsable = ct > 0.05f;                       // a bundle wider than ~87 degrees is not culled at all
+    const float st = __builtin_amdgcn_sqrtf(__builtin_fmaxf(f_fma(-ct, ct, 1.0f), 0.0f));
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w * 64 >= ns) break;
+        const int i = w * 64 + lane;
+        const bool in = i < ns;
+        const float4 s = sc.sph[in ? i : 0];
+        const v3 v = V(s.x - O.x, s.y - O.y, s.z - O.z);
+        const float L = __builtin_amdgcn_sqrtf(v_dot(v, v));
+        const float R = f_fma(f_abs(s.w) + rho, 1.001f, f_fma(L, 1e-4f, 1e-3f));
+        bool outside = false;
+        if (coneUsable && L > R) { // NaN / inf anywhere -> comparisons false -> the sphere is kept
+            const float sb = R * __builtin_amdgcn_rcpf(L);
+            const float cb = __builtin_amdgcn_sqrtf(__builtin_fmaxf(f_fma(-sb, sb, 1.0f), 0.0f));
+            const float cosSum = f_fma(ct, cb, -(st * sb)) - 1e-4f; // padded cos(theta + beta)
+            outside = v_dot(v, A) < L * cosSum;
+        }
+        masks[w] = __ballot(in && !outside);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- sampling / BSDF
@@ -386,11 +485,12 @@ PT_DEV float bsdf(v3 &ro, v3 &rd, const Hit &h, bool &isRefractive, uint32_t &se
 
 // One iteration of Radiance's bounce loop (compute.glsl:140-180) for one path.  Returns true when the path
 // continues (hit, survived Russian roulette), false when it ended (miss -> environment, or roulette kill).
-PT_DEV bool bounce_step(const SceneLds &sc, int ns, int nc, const EnvRef &env, v3 &ro, v3 &rd, v3 &throughput, v3 &rad,
-                        uint32_t &seed PROF_PARAM)
+template <bool MASKED, bool MATLDS>
+PT_DEV bool bounce_step_t(const SceneLds &sc, int ns, int nc, const EnvRef &env, v3 &ro, v3 &rd, v3 &throughput, v3 &rad,
+                          uint32_t &seed, const unsigned long long *masks PROF_PARAM)
 {
     Hit h;
-    if (ray_trace(sc, ns, nc, ro, rd, h PROF_PASS)) {
+    if (ray_trace_t<MASKED, MATLDS>(sc, ns, nc, ro, rd, h, masks PROF_PASS)) {
         PROF_BEGIN
         if (h.fromInside) { // Beer's law, compute.glsl:145-149
             h.normal = v_neg(h.normal);
@@ -423,6 +523,11 @@ PT_DEV bool bounce_step(const SceneLds &sc, int ns, int nc, const EnvRef &env, v
     rad = V(f_fma(e.x, throughput.x, rad.x), f_fma(e.y, throughput.y, rad.y), f_fma(e.z, throughput.z, rad.z));
     PROF_MARK(6) // miss shading
     return false;
+}
+PT_DEV bool bounce_step(const SceneLds &sc, int ns, int nc, const EnvRef &env, v3 &ro, v3 &rd, v3 &throughput, v3 &rad,
+                        uint32_t &seed PROF_PARAM)
+{
+    return bounce_step_t<false, true>(sc, ns, nc, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
 }
 
 // compute.glsl:132-182 Radiance
@@ -529,31 +634,46 @@ PT_DEV SceneLds stage_scene(const FrameArgs &a)
     float4 *cmin = sph + ns;
     float4 *cmax = cmin + nc;
     float4 *mat = cmax + nc;
-    float *invr = (float *)(mat + 4 * (ns + nc));
+    const bool matInLds = a.materialsInLds != 0;
+    float *invr = (float *)(mat + (matInLds ? 4 * (ns + nc) : 0));
     float *lut = invr + ((ns + 3) & ~3);
     const int tid = threadIdx.x;
     const float4 *obj = (const float4 *)a.objects;
     const int nthreads = blockDim.x;
-    for (int i = tid; i < ns * 5; i += nthreads) {
-        int s = i / 5, part = i - s * 5;
-        float4 v = obj[i];
-        if (part == 0) {
-            sph[s] = v;
-            invr[s] = f_div_ieee(1.0f, v.w);
-        } else {
-            mat[4 * s + part - 1] = v;
+    if (matInLds) {
+        for (int i = tid; i < ns * 5; i += nthreads) {
+            int s = i / 5, part = i - s * 5;
+            float4 v = obj[i];
+            if (part == 0) {
+                sph[s] = v;
+                invr[s] = f_div_ieee(1.0f, v.w);
+            } else {
+                mat[4 * s + part - 1] = v;
+            }
         }
-    }
-    for (int i = tid; i < nc * 6; i += nthreads) {
-        int c = i / 6, part = i - c * 6;
-        float4 v = obj[1280 + i]; // Cuboids[] start at byte 20480 = float4 index 1280
-        if (part == 0) cmin[c] = v;
-        else if (part == 1) cmax[c] = v;
-        else mat[4 * (ns + c) + part - 2] = v;
+        for (int i = tid; i < nc * 6; i += nthreads) {
+            int c = i / 6, part = i - c * 6;
+            float4 v = obj[1280 + i]; // Cuboids[] start at byte 20480 = float4 index 1280
+            if (part == 0) cmin[c] = v;
+            else if (part == 1) cmax[c] = v;
+            else mat[4 * (ns + c) + part - 2] = v;
+        }
+    } else { // geometry only
+        for (int i = tid; i < ns; i += nthreads) {
+            float4 v = obj[5 * i];
+            sph[i] = v;
+            invr[i] = f_div_ieee(1.0f, v.w);
+        }
+        for (int i = tid; i < nc * 2; i += nthreads) {
+            int c = i >> 1;
+            float4 v = obj[1280 + 6 * c + (i & 1)];
+            if (i & 1) cmax[c] = v;
+            else cmin[c] = v;
+        }
     }
     if (a.envFormat == 1 && tid < 256) lut[tid] = a.srgbLut[tid];
     __syncthreads();
-    return SceneLds{sph, cmin, cmax, mat, invr, lut};
+    return SceneLds{sph, cmin, cmax, mat, invr, lut, obj};
 }
 
 // XCD-aware workgroup id: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, so id b is
@@ -690,6 +810,14 @@ struct RingEntry { // 40 bytes
 };
 
 
+// spp == 1 kernels: the ring holds paths AFTER their first bounce (see the tile pass in the kernel), 60 bytes each
+struct PathEntry {
+    int pix;       // linear index into accum
+    int bounce;    // bounces done so far
+    uint32_t seed; // RNG state
+    float ro[3], rd[3], thr[3], rad[3];
+};
+
 struct BlockQueue {            // one per workgroup, in static LDS
     unsigned long long pair;   // (end << 32) | cursor : absolute tile indices of the current chunk
     unsigned int lock;         // refill lock
@@ -767,7 +895,15 @@ struct DrainControl {        // static LDS, one per workgroup
     unsigned int pad[3];
 };
 
-template <int NWAVES, int MIN_WAVES_PER_SIMD, bool TIMELINE>
+//
+// SPP1 (one sample per pixel per frame, the usual case) adds the TILE PASS: the wavefront that refills its ring runs the
+// whole first bounce of the tile's 64 primary rays right there, all lanes together.  Primary rays of one tile are
+// coherent, so the spheres are first culled against the tile's ray bundle (cull_spheres: typically 0-5 of them survive)
+// and the sphere pass of the first bounce — 37 % of all rays cast at 2.7 bounces per path — shrinks from numSpheres to
+// that handful; material / BSDF / environment code runs on coherent lanes too.  Paths that end at the first bounce are
+// resolved immediately, the survivors go to the ring as PathEntry records and are picked up by idle lanes of the
+// generic bounce loop.  Per path the arithmetic is unchanged (same tests in the same order, same RNG draws).
+template <int NWAVES, int MIN_WAVES_PER_SIMD, bool TIMELINE, bool SPP1, bool MATLDS>
 __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_persistent_kernel(const FrameArgs a)
 {
     __shared__ __attribute__((aligned(16))) BlockQueue queue; // 16 B: keeps the dynamic-LDS base 16-byte aligned
@@ -790,9 +926,11 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     EnvRef env{nullptr, (LdsFloats)sc.lut, 0, 0}; // descriptor is cold-loaded at the miss-shading site (bounce_step)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // the ring lives behind the staged scene in dynamic LDS
-    RingEntry *ringBase = (RingEntry *)((char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat));
-    RingEntry *ring = ringBase + wave * 64;
-    PathState *pool = (PathState *)(ringBase + NWAVES * 64);
+    constexpr int ENTRY_BYTES = SPP1 ? (int)sizeof(PathEntry) : (int)sizeof(RingEntry);
+    char *ringBase = (char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, a.materialsInLds != 0);
+    RingEntry *ring = (RingEntry *)(ringBase + wave * 64 * ENTRY_BYTES);  // !SPP1: primary rays
+    PathEntry *pring = (PathEntry *)(ringBase + wave * 64 * ENTRY_BYTES); //  SPP1: paths after their first bounce
+    PathState *pool = (PathState *)(ringBase + NWAVES * 64 * ENTRY_BYTES);
     const bool compaction = a.drainCompaction != 0;
     const int donateMax = a.drainCompaction < DONATE_MAX ? a.drainCompaction : DONATE_MAX; // a wavefront this thin donates
     const bool leader = lane == 0;
@@ -818,7 +956,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         // to hold fewer rays than there were idle lanes)
         bool idle = pix < 0;
         unsigned long long m = __ballot(idle);
-        for (int pass = 0; pass < 2 && m != 0ull; pass++) {
+        for (int pass = 0; (SPP1 ? pass < 16 : pass < 2) && m != 0ull; pass++) {
             if (avail == 0) {
                 if (exhausted) break;
                     // ---- refill the ring: one tile, every lane generates one primary ray
@@ -826,6 +964,50 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                     if (tile < 0) {
                         exhausted = true;
                         if (TIMELINE) tExhausted = wall_clock64();
+                    } else if constexpr (SPP1) {
+                        // ---- tile pass: primary rays + the whole first bounce, all 64 lanes together
+                        ColdArgs ca = cold_args();
+                        ColdFloats cam = (ColdFloats)ca;
+                        const int width = ca->width, tilesX = ca->tilesX;
+                        const float invW = f_div_ieee(1.0f, (float)width), invH = f_div_ieee(1.0f, (float)ca->height);
+                        int tx = (int)(tile % tilesX), ty = (int)(tile / tilesX);
+                        int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+                        const bool valid = x < width && ly < ca->rows;
+                        v3 to = V(0.0f, 0.0f, 0.0f), td = V(0.0f, 0.0f, 1.0f), tthr = V(1.0f, 1.0f, 1.0f), trad = V(0.0f, 0.0f, 0.0f);
+                        uint32_t tseed = 0;
+                        int tpix = 0;
+                        if (valid) {
+                            int gy = global_row_v(ca->bandRows, ca->bandWorld, ca->bandRank, ca->localRow0, ca->y0, ly);
+                            tseed = pixel_seed(x, gy, ca->frame);
+                            primary_ray_cam(cam, invW, invH, x, gy, tseed, to, td);
+                            tpix = ly * width + x;
+                        }
+                        unsigned long long masks[4];
+                        cull_spheres(sc, a.numSpheres, valid, to, td, masks);
+                        bool tcont = false;
+                        if (valid) {
+                            if (0 < a.rayDepth)
+                                tcont = bounce_step_t<true, MATLDS>(sc, a.numSpheres, a.numCuboids, env, to, td, tthr, trad, tseed, masks PROF_DUMMY);
+                            if (1 >= a.rayDepth) tcont = false;
+                            if (!tcont) { // the path ended at its first bounce: compute.glsl:125-129 right away
+                                v3 tirr = v_add(V(0.0f, 0.0f, 0.0f), trad);
+                                float4 last = a.accum[tpix];
+                                a.accum[tpix] = resolve_pixel(a, tirr, last);
+                            }
+                        }
+                        const unsigned long long cm = __ballot(tcont);
+                        if (tcont) {
+                            int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+                            PathEntry e;
+                            e.pix = tpix; e.bounce = 1; e.seed = tseed;
+                            e.ro[0] = to.x; e.ro[1] = to.y; e.ro[2] = to.z;
+                            e.rd[0] = td.x; e.rd[1] = td.y; e.rd[2] = td.z;
+                            e.thr[0] = tthr.x; e.thr[1] = tthr.y; e.thr[2] = tthr.z;
+                            e.rad[0] = trad.x; e.rad[1] = trad.y; e.rad[2] = trad.z;
+                            pring[slot] = e;
+                        }
+                        __builtin_amdgcn_wave_barrier(); // ring entries are read by other lanes of this wave below
+                        avail = __builtin_popcountll(cm);
                     } else {
                         // camera block: FrameArgs is the kernel's first argument, so it starts the kernarg segment
                         ColdArgs ca = cold_args(); // opaque: load the camera here, do not keep it live across the loop
@@ -853,8 +1035,24 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                     }
 
                 if (exhausted) break;
+                if (SPP1 && avail == 0) continue; // every path of that tile ended at its first bounce: next tile
             }
-            {
+            if constexpr (SPP1) {
+                // ---- idle lanes pop paths (top down)
+                int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (idle && rank < avail) {
+                    PathEntry e = pring[avail - 1 - rank];
+                    pix = e.pix;
+                    bounce = e.bounce;
+                    seed = e.seed;
+                    ro = V(e.ro[0], e.ro[1], e.ro[2]);
+                    rd = V(e.rd[0], e.rd[1], e.rd[2]);
+                    throughput = V(e.thr[0], e.thr[1], e.thr[2]);
+                    rad = V(e.rad[0], e.rad[1], e.rad[2]);
+                }
+                int n = __builtin_popcountll(m);
+                avail = n < avail ? avail - n : 0;
+            } else {
                 // ---- idle lanes pop ring entries (top down); a popped out-of-image entry leaves the lane idle
                 int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 if (idle && rank < avail) {
@@ -899,17 +1097,19 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         if (idle && (unsigned int)rank < k) {
                             PathState st = pool[taken + rank];
                             pix = st.pix;
-                            px = st.pxy & 0xffff;
-                            py = st.pxy >> 16;
-                            sample = st.counters & 0xfff;
                             bounce = (st.counters >> 12) & 0xfff;
-                            needRay = (st.counters >> 24) & 1;
                             seed = st.seed;
                             ro = V(st.ro[0], st.ro[1], st.ro[2]);
                             rd = V(st.rd[0], st.rd[1], st.rd[2]);
                             throughput = V(st.thr[0], st.thr[1], st.thr[2]);
                             rad = V(st.rad[0], st.rad[1], st.rad[2]);
-                            irr = V(st.irr[0], st.irr[1], st.irr[2]);
+                            if constexpr (!SPP1) {
+                                px = st.pxy & 0xffff;
+                                py = st.pxy >> 16;
+                                sample = st.counters & 0xfff;
+                                needRay = (st.counters >> 24) & 1;
+                                irr = V(st.irr[0], st.irr[1], st.irr[2]);
+                            }
                         }
                     }
                 }
@@ -954,14 +1154,14 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                     if (active) {
                         PathState st;
                         st.pix = pix;
-                        st.pxy = px | (py << 16);
-                        st.counters = sample | (bounce << 12) | ((needRay ? 1 : 0) << 24);
+                        st.pxy = SPP1 ? 0 : (px | (py << 16));
+                        st.counters = SPP1 ? (bounce << 12) : (sample | (bounce << 12) | ((needRay ? 1 : 0) << 24));
                         st.seed = seed;
                         st.ro[0] = ro.x; st.ro[1] = ro.y; st.ro[2] = ro.z;
                         st.rd[0] = rd.x; st.rd[1] = rd.y; st.rd[2] = rd.z;
                         st.thr[0] = throughput.x; st.thr[1] = throughput.y; st.thr[2] = throughput.z;
                         st.rad[0] = rad.x; st.rad[1] = rad.y; st.rad[2] = rad.z;
-                        st.irr[0] = irr.x; st.irr[1] = irr.y; st.irr[2] = irr.z;
+                        st.irr[0] = SPP1 ? 0.0f : irr.x; st.irr[1] = SPP1 ? 0.0f : irr.y; st.irr[2] = SPP1 ? 0.0f : irr.z;
                         st.pad = 0;
                         pool[base + rank] = st;
                     }
@@ -986,6 +1186,22 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         }
         if (TIMELINE) nIter++;
         PROF_MARK(0) // feed: ring refill / pop / adopt / donate
+        if constexpr (SPP1) {
+            if (active) {
+                bool cont = false;
+                if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
+                bounce++;
+#ifdef PT_PROFILE
+                prof_t = __builtin_readcyclecounter();
+#endif
+                if (!cont || bounce >= a.rayDepth) {
+                    v3 firr = v_add(V(0.0f, 0.0f, 0.0f), rad);
+                    float4 last = a.accum[pix];
+                    a.accum[pix] = resolve_pixel(a, firr, last);
+                    pix = -1;
+                }
+            }
+        } else {
         if (active && needRay) { // only for spp > 1: the next sample continues the pixel's RNG stream (compute.glsl:110)
             primary_ray(a, px, py, seed, ro, rd);
             throughput = V(1.0f, 1.0f, 1.0f);
@@ -995,7 +1211,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         }
         if (active) {
             bool cont = false;
-            if (bounce < a.rayDepth) cont = bounce_step(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed PROF_PASS);
+            if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
             bounce++;
 #ifdef PT_PROFILE
             prof_t = __builtin_readcyclecounter();
@@ -1012,6 +1228,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                 }
             }
         }
+        } // !SPP1
         PROF_MARK(7) // resolve
     }
 #ifdef PT_PROFILE
@@ -1041,29 +1258,48 @@ static int pool_tiles_for_variant(int variant)
     }
 }
 
-hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int *ticketsConsumed)
+hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned int *ticketsConsumed)
 {
+    FrameArgs a = args;
+    a.materialsInLds = 1;
     *ticketsConsumed = 0;
     int tiles = a.tilesX * a.tilesY;
-    size_t lds = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat);
+    size_t lds = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, true);
     if (a.variant == 1) {
         int nwg = (tiles + 3) / 4;
         hipLaunchKernelGGL(pt_integrate_kernel, dim3(nwg), dim3(256), lds, stream, a);
     } else if (a.variant == 0 || a.variant >= 10) {
-        // 10+k: 256-thread workgroups, k+1 per CU; 50+k: 512-thread workgroups; 60+k: 1024-thread workgroups
-        int waves = 4, k = a.variant == 0 ? 4 : a.variant - 10;
-        if (a.variant >= 60) { waves = 16; k = a.variant - 60; }
-        else if (a.variant >= 50) { waves = 8; k = a.variant - 50; }
+        // 10+k: k+1 workgroups (256 threads) per CU
+        const int waves = 4;
+        int k = a.variant == 0 ? 4 : a.variant - 10;
+        if (k < 0 || k > 7) k = 4;
         int blocksPerCU = k + 1;
         int nwg = a.numCUs * blocksPerCU;
         int numChunks = (tiles + a.queueChunk - 1) / a.queueChunk;
         if (nwg > numChunks) nwg = numChunks;
         if (nwg < 1) nwg = 1;
-        size_t ldsTotal = lds + (size_t)waves * 64 * sizeof(RingEntry) + (size_t)pool_slots(waves) * sizeof(PathState);
-        if (waves == 4 && a.timeline) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, 5, true>), dim3(nwg), dim3(256), ldsTotal, stream, a);
-        else if (waves == 4) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, 5, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
-        else if (waves == 8) hipLaunchKernelGGL((pt_integrate_persistent_kernel<8, 5, false>), dim3(nwg), dim3(512), ldsTotal, stream, a);
-        else hipLaunchKernelGGL((pt_integrate_persistent_kernel<16, 4, false>), dim3(nwg), dim3(1024), ldsTotal, stream, a);
+        const bool spp1 = a.spp == 1; // tile-pass kernels (the ring holds 60-byte paths instead of 40-byte primary rays)
+        const size_t queues = (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) : sizeof(RingEntry)) + (size_t)pool_slots(waves) * sizeof(PathState);
+        size_t ldsTotal = lds + queues;
+        // materials leave LDS when they would cost a resident workgroup (160 KB per CU; 64 B of static LDS per workgroup)
+        const size_t ldsPerCU = 160 * 1024, fixedLds = 64;
+        const size_t ldsLean = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, false) + queues;
+        size_t wgFull = ldsPerCU / (ldsTotal + fixedLds), wgLean = ldsPerCU / (ldsLean + fixedLds);
+        if (wgFull > (size_t)blocksPerCU) wgFull = (size_t)blocksPerCU;
+        if (wgLean > (size_t)blocksPerCU) wgLean = (size_t)blocksPerCU;
+        if (wgLean > wgFull) {
+            a.materialsInLds = 0;
+            ldsTotal = ldsLean;
+        }
+#define PT_LAUNCH_PERSISTENT(TL, S1, ML) \
+    hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, 5, TL, S1, ML>), dim3(nwg), dim3(256), ldsTotal, stream, a)
+        const bool matLds = a.materialsInLds != 0;
+        if (a.timeline && spp1 && matLds) PT_LAUNCH_PERSISTENT(true, true, true); // per-wavefront timestamps (tools/timeline.py)
+        else if (spp1 && matLds) PT_LAUNCH_PERSISTENT(false, true, true);
+        else if (spp1) PT_LAUNCH_PERSISTENT(false, true, false);
+        else if (matLds) PT_LAUNCH_PERSISTENT(false, false, true);
+        else PT_LAUNCH_PERSISTENT(false, false, false);
+#undef PT_LAUNCH_PERSISTENT
         // every workgroup draws tickets until its first failing one: (numChunks - nwg) successful + nwg failing
         *ticketsConsumed = (unsigned int)(numChunks > nwg ? numChunks : nwg);
     } else {

@@ -107,6 +107,34 @@ def test_full_ubo_max_objects(pkg, native_lib, oracle):
     assert_bit_exact(pt.Result, want, "256 spheres + 64 cuboids")
 
 
+def _random_cameras(n, seed):
+    rng = np.random.RandomState(seed)
+    cams = []
+    for i in range(n):
+        pos = tuple(float(v) for v in rng.uniform([-17.5, -10.5, -20.5], [17.5, 10.5, 0.5]))
+        look = (float(rng.uniform(-180, 180)), float(rng.uniform(-80, 80)))
+        cams.append((pos, look))
+    return cams
+
+
+@pytest.mark.parametrize("scene,size,aperture,focal", [
+    ("stress256", (128, 72), 0.14, 20.0),   # 256 spheres: every tile culls against all four 64-sphere mask words
+    ("stress256", (24, 16), 0.14, 20.0),    # a tile spans a large part of the field of view: wide ray bundles
+    ("default", (8, 8), 0.14, 20.0),        # one tile = the whole image
+    ("default", (96, 54), 8.0, 2.0),        # lens far larger than the scene features: ray origins spread over metres
+    ("edge", (96, 54), 1.0, 6.0),           # cameras inside / next to glass
+    ("randmat", (96, 54), 0.0, 20.0),       # pinhole: zero-radius apex
+], ids=lambda v: str(v))
+def test_tile_pass_culling_is_conservative(pkg, native_lib, oracle, scene, size, aperture, focal):
+    """The spp = 1 kernels run each tile's first bounce with the spheres culled against the tile's ray bundle
+    (cull_spheres, pt_kernels.hip).  A sphere removed by mistake would change pixels, so random cameras all over
+    (and inside) the scene must still match the brute-force oracle bit for bit."""
+    for k, (pos, look) in enumerate(_random_cameras(6, sum(map(ord, scene)) + size[0])):
+        w = configs.Workload(f"cull_{scene}_{k}", scene, size[0], size[1], 6, "sky_f32_32", aperture=aperture,
+                             focal_length=focal, look=look, position=pos)
+        assert_bit_exact(hip_render(pkg, w), oracle_render(oracle, w), f"{w.name} pos={pos} look={look}")
+
+
 # ------------------------------------------------------------------------------------------------ (2) HIP vs reference fixtures
 @pytest.mark.parametrize("name", fixtures.names("frame_"))
 def test_hip_matches_reference_fixtures(pkg, native_lib, name):
