@@ -47,7 +47,7 @@ struct pt_renderer {
     unsigned int *dQueue = nullptr; // global chunk-ticket counter of the persistent kernel (never reset: epoch scheme)
     int queueChunk = 8;             // tiles per global ticket (PT_QUEUE_CHUNK overrides, for tuning runs)
     unsigned long long *dTimeline = nullptr; // tuning only (pt_debug_timeline)
-    int drainCompaction = 32;       // donate threshold in live paths (<= 48); PT_DRAIN_COMPACTION=0 disables (A/B runs)
+    int drainCompaction = -1;       // donate threshold in live paths (<= 32), 0 = off, -1 = auto (see pt_render); env PT_DRAIN_COMPACTION
     int numCUs = 256;
     void *dEnv = nullptr;      // current environment cube
     size_t envBytes = 0;
@@ -422,7 +422,6 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     a.localRow0 = 0;
     a.numCUs = h->numCUs;
     a.queueChunk = h->queueChunk;
-    a.drainCompaction = h->drainCompaction;
     a.timeline = h->dTimeline;
 
     // variant -> (kernel variant, stripes): 0 = default (2 stripes x 5 workgroups/CU); 20+k / 30+k / 40+k = 2 / 3 / 4
@@ -432,6 +431,10 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     else if (h->variant >= 20 && h->variant < 50) { stripes = h->variant / 10; kernelVariant = 10 + h->variant % 10; }
     if (h->rows < 16 * stripes) stripes = 1; // tiny tiles: not worth splitting
     a.variant = kernelVariant;
+    // Drain compaction (a thin draining wavefront donates its paths to its workgroup's pool) shortens the tail of ONE
+    // launch.  With stripes the tail of one launch is covered by the other stripe's (or the next frame's) main phase, and
+    // the pool's LDS and the donor traffic only cost: auto = on for single-launch variants, off for striped frames.
+    a.drainCompaction = h->drainCompaction >= 0 ? h->drainCompaction : (stripes > 1 ? 0 : 32);
 
     if (stripes == 1) {
         if (int rc = join_stripes(h)) return rc;

@@ -1279,7 +1279,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         if (nwg > numChunks) nwg = numChunks;
         if (nwg < 1) nwg = 1;
         const bool spp1 = a.spp == 1; // tile-pass kernels (the ring holds 60-byte paths instead of 40-byte primary rays)
-        const size_t queues = (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) : sizeof(RingEntry)) + (size_t)pool_slots(waves) * sizeof(PathState);
+        const size_t queues = (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) : sizeof(RingEntry)) + (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0); // no pool without drain compaction
         size_t ldsTotal = lds + queues;
         // materials leave LDS when they would cost a resident workgroup (160 KB per CU; 64 B of static LDS per workgroup)
         const size_t ldsPerCU = 160 * 1024, fixedLds = 64;
