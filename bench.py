@@ -55,15 +55,29 @@ def flops_per_sample(mean_bounces: float, ns: int, nc: int) -> float:
     return 100.0 + mean_bounces * (17.0 * ns + 24.0 * nc + 120.0)
 
 
-def load_traffic(workload_key: str):
-    """Measured HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (or None)."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
+def _load_profile_number(file_name: str, workload_key: str):
+    p = os.path.join(ROOT, "profiles", file_name)
     if os.path.exists(p):
         try:
             return json.load(open(p)).get(workload_key)
         except Exception:
             return None
     return None
+
+
+def load_traffic(workload_key: str):
+    """Measured HBM bytes per step from the rocprofv3 PMC passes committed under profiles/ (or None)."""
+    return _load_profile_number("traffic.json", workload_key)
+
+
+def load_valu_insts(workload_key: str):
+    """Measured VALU wave-instructions per step (SQ_INSTS_VALU, same PMC passes) or None."""
+    return _load_profile_number("valu_insts.json", workload_key)
+
+
+# tools/ubench2.hip on MI355X: with >= 3 wavefronts per SIMD a SIMD issues one wave64 VALU instruction (fma, mul, add,
+# compare, select, integer alike) per 2.63 shader clocks at 2.4 GHz; 1024 SIMDs
+VALU_ISSUE_PEAK_GINST = 1024 * 2.4 / 2.626
 
 
 def cpu_baseline(pkg, scene, basic, env, width, height, depth, spp):
@@ -195,7 +209,7 @@ def main():
         kernel_ms = kernel_s_max * 1e3 / args.steps
         algo_bytes = ALGO_BYTES_PER_PIXEL_FRAME * W * rows  # per launch on one GPU (rank 0's row block)
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        wl_key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{args.spp}_{args.env}_g{world}"
+        wl_key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{args.spp}_{args.env}_g{world}" + (f"_variant{args.variant}" if args.variant else "")
         out = {
             "metric": "Msamples/sec + ms/frame @1080p 8-bounce default scene, 1/2/4/8 GPU",
             "value": round(samples / elapsed_max / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -220,6 +234,14 @@ def main():
             "present_ms": round(present_ms, 3),
             "checks": checks,
         }
+        vi = load_valu_insts(wl_key)
+        if vi:
+            rate = vi / (kernel_ms * 1e-3) / 1e9
+            out["roofline"]["valu_issue"] = {"wave_insts_per_step": vi, "achieved": round(rate, 1), "peak": round(VALU_ISSUE_PEAK_GINST, 1),
+                                              "unit": "G wave-instructions/s", "frac": round(rate / VALU_ISSUE_PEAK_GINST, 4),
+                                              "note": "the binding roof: SQ_INSTS_VALU per step (rocprofv3 PMC pass committed under "
+                                                      "profiles/) / kernel time, against the measured wave64 VALU issue rate "
+                                                      "(tools/ubench2.hip: one instruction per 2.63 clocks per SIMD)"}
         mean_bounces = None
         if world == 1 and not args.no_cpu_baseline:
             env_cpu = pt.ReadEnvironment() if args.env != "sky2048" else pkg.envmap.synthetic_sky_srgb8(2048)

@@ -68,5 +68,11 @@ if pmc.get("FETCH_SIZE") and pmc.get("WRITE_SIZE") and fetch_factor and write_fa
     t = json.load(open(tpath)) if os.path.exists(tpath) else {}
     t[key] = round(rd + wr)
     json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
+if pmc.get("SQ_INSTS_VALU"):
+    # VALU wave-instructions per step: the numerator of bench.py's roofline.valu.issue (peak: tools/ubench2.hip)
+    vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
+    v = json.load(open(vpath)) if os.path.exists(vpath) else {}
+    v[key] = round(pmc["SQ_INSTS_VALU"])
+    json.dump(v, open(vpath, "w"), indent=1, sort_keys=True)
 json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
