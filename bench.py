@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--env", default="atmosphere256", choices=["atmosphere256", "sky2048", "sky64"])
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--frame-batch", type=int, default=16,
+                    help="frames one launch may pipeline (pt_set_frame_batch; 1 = one launch per Render())")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: all ranks use cuda:0 and rendezvous over gloo (validates the N>1 logic on a 1-GPU box; "
@@ -152,6 +154,9 @@ def main():
 
     pt = pkg.PathTracer(None, W, H, args.depth, args.spp, 20.0, 0.14, device=local)
     pt.SetVariant(args.variant)
+    pt.SetFrameBatch(args.frame_batch)
+    # frames one launch renders: consecutive Render() calls of the default spp=1 kernel are pipelined inside one launch
+    frames_per_launch = args.frame_batch if (args.variant == 0 and args.spp == 1) else 1
     if args.env == "atmosphere256":   # MainWindow.cs:174-175,189
         pt.EnvironmentMap = pkg.AtmosphericScatterer(256, pkg.camera.atmospheric_data_ubo(), pkg.camera.atmosphere_light_pos(0.5), pt)
     elif args.env == "sky2048":       # MainWindow.cs:177-187 shape, synthetic content
@@ -209,7 +214,7 @@ def main():
         kernel_ms = kernel_s_max * 1e3 / args.steps
         algo_bytes = ALGO_BYTES_PER_PIXEL_FRAME * W * rows  # per launch on one GPU (rank 0's row block)
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        wl_key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{args.spp}_{args.env}_g{world}" + (f"_variant{args.variant}" if args.variant else "")
+        wl_key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{args.spp}_{args.env}_g{world}" + (f"_variant{args.variant}" if args.variant else "") + (f"_fb{args.frame_batch}" if args.frame_batch != 16 else "")
         out = {
             "metric": "Msamples/sec + ms/frame @1080p 8-bounce default scene, 1/2/4/8 GPU",
             "value": round(samples / elapsed_max / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -224,13 +229,16 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(wl_key),
                          "kernel": "pt_integrate_persistent_kernel", "kernel_ms": round(kernel_ms, 5),
-                         "launches_per_step": 2 if args.variant == 0 else (args.variant // 10 if 20 <= args.variant < 50 else 1),
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "32 B/pixel/frame (float4 load + store of the accumulation image), summed over the step's "
-                                 "launches; kernel_ms = GPU time per step from HIP events on the library's streams. The "
-                                 "default variant renders a step as 2 row-stripe launches on 2 streams whose executions "
-                                 "overlap (rocprofv3's per-launch average is therefore longer than kernel_ms/2; run "
-                                 "--variant 14 for one launch per step). The path is fp32-VALU bound, see `valu`"},
+                         "launches_per_step": (1.0 / frames_per_launch if frames_per_launch > 1 else
+                                               (2 if args.variant == 0 else (args.variant // 10 if 20 <= args.variant < 50 else 1))),
+                         "frames_per_launch": frames_per_launch,
+                         "algorithmic_bytes_per_launch": algo_bytes * frames_per_launch,
+                         "note": "32 B/pixel/frame (float4 load + store of the accumulation image); kernel_ms = GPU time per "
+                                 "step (= frame) from HIP events on the library's streams. The default kernel pipelines up to "
+                                 "frames_per_launch consecutive frames inside ONE launch (rocprofv3's average launch duration "
+                                 "= frames_per_launch x kernel_ms; achieved = algorithmic_bytes_per_launch / that duration). "
+                                 "--frame-batch 1 launches every frame on its own (2 overlapping row-stripe launches). "
+                                 "The path is fp32-VALU bound, see `valu_issue`"},
             "present_ms": round(present_ms, 3),
             "checks": checks,
         }

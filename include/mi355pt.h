@@ -108,8 +108,15 @@ PT_API int pt_set_environment(pt_handle h, int face_size, int format, const void
 
 /* PathTracer.Render() — PathTracer.cs:114-123: enqueue one dispatch of the integrator with the current frame
  * index, then post-increment it. Asynchronous. *out_total_samples (optional) = frames * SPP after this call
- * (PathTracer.Samples, PathTracer.cs:112). */
+ * (PathTracer.Samples, PathTracer.cs:112).
+ * Frames of consecutive pt_render calls with nothing in between are launched as ONE pipelined kernel (up to
+ * pt_set_frame_batch frames): the launch happens when the batch is full or at the next call of any other entry point
+ * (uploads and parameter changes apply to LATER frames only, exactly as with one launch per call; every read,
+ * pt_synchronize and pt_timer_* first launch what is pending).  The image is bit-identical either way. */
 PT_API int pt_render(pt_handle h, int *out_total_samples);
+/* Largest number of frames one launch may pipeline (1..16, default 16).  1 = every pt_render launches at once (lowest
+ * latency for a host that never calls anything else between frames, e.g. one that presents through interop). */
+PT_API int pt_set_frame_batch(pt_handle h, int max_frames);
 
 /* What ScreenEffect.Render reads (src/MainWindow.cs:51): blocks until the stream is idle and copies this
  * handle's rows [y0, y0+rows) into dst (row_pitch_bytes >= width*16; 0 means tightly packed). */

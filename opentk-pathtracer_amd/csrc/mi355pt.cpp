@@ -47,6 +47,11 @@ struct pt_renderer {
     unsigned int *dQueue = nullptr; // global chunk-ticket counter of the persistent kernel (never reset: epoch scheme)
     int queueChunk = 8;             // tiles per global ticket (PT_QUEUE_CHUNK overrides, for tuning runs)
     unsigned long long *dTimeline = nullptr; // tuning only (pt_debug_timeline)
+    // Frame pipelining: consecutive pt_render calls are collected and launched as ONE batch kernel (see pt_kernels.hip)
+    // when nothing observable happens in between; every other entry point launches what is pending first.
+    int pendingFrames = 0;          // frames accepted by pt_render, not launched yet
+    int maxBatch = 16;              // PT_FRAME_BATCH=1 turns batching off (every pt_render launches at once)
+    bool batchLaunched = false;     // a batch kernel ran since the last error-word check
     int drainCompaction = -1;       // donate threshold in live paths (<= 32), 0 = off, -1 = auto (see pt_render); env PT_DRAIN_COMPACTION
     int numCUs = 256;
     void *dEnv = nullptr;      // current environment cube
@@ -120,8 +125,12 @@ void make_srgb_lut(float *lut)
 
 // Make the main stream wait for every stripe kernel still in flight (before anything that reads their output or
 // overwrites their inputs).
+int flush_frames(pt_handle h);
+
 int join_stripes(pt_handle h)
 {
+    if (h->pendingFrames > 0)
+        if (int rc = flush_frames(h)) return rc;
     for (int j = 0; j < pt_renderer::kMaxStripes; j++) {
         if (h->stripePending[j]) {
             PT_HIP(h, hipStreamWaitEvent(h->stream, h->stripeDone[j], 0));
@@ -186,6 +195,10 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     if (!h) return fail(nullptr, PT_E_OUT_OF_MEMORY, "host allocation failed");
     h->device = device_id;
     if (const char *dcv = std::getenv("PT_DRAIN_COMPACTION")) h->drainCompaction = std::atoi(dcv);
+    if (const char *fb = std::getenv("PT_FRAME_BATCH")) {
+        int v = std::atoi(fb);
+        if (v >= 1 && v <= 16) h->maxBatch = v;
+    }
     if (const char *qc = std::getenv("PT_QUEUE_CHUNK")) {
         int v = std::atoi(qc);
         if (v >= 1 && v <= 1024) h->queueChunk = v;
@@ -242,6 +255,7 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
 PT_API int pt_destroy(pt_handle h)
 {
     PT_CHECK_HANDLE(h);
+    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     (void)hipSetDevice(h->device);
     for (int j = 0; j < pt_renderer::kMaxStripes; j++)
         if (h->stripeStream[j]) (void)hipStreamSynchronize(h->stripeStream[j]);
@@ -268,6 +282,7 @@ PT_API int pt_destroy(pt_handle h)
 PT_API int pt_set_size(pt_handle h, int width, int height)
 {
     PT_CHECK_HANDLE(h);
+    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (width <= 0 || height <= 0) return fail(h, PT_E_BAD_ARGUMENT, "width/height must be positive");
     if (int rc = bind_device(h)) return rc;
     h->width = width;
@@ -283,6 +298,7 @@ PT_API int pt_set_size(pt_handle h, int width, int height)
 PT_API int pt_set_tile(pt_handle h, int y0, int rows)
 {
     PT_CHECK_HANDLE(h);
+    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (y0 < 0 || rows <= 0 || y0 + rows > h->height) return fail(h, PT_E_BAD_ARGUMENT, "tile outside the image");
     if (int rc = bind_device(h)) return rc;
     h->y0 = y0;
@@ -296,6 +312,7 @@ PT_API int pt_set_tile(pt_handle h, int y0, int rows)
 PT_API int pt_set_interleaved_tile(pt_handle h, int rank, int world, int band_rows)
 {
     PT_CHECK_HANDLE(h);
+    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (world < 1 || rank < 0 || rank >= world || band_rows < 8 || (band_rows & 7))
         return fail(h, PT_E_BAD_ARGUMENT, "need 0 <= rank < world and band_rows a positive multiple of 8");
     if (int rc = bind_device(h)) return rc;
@@ -319,6 +336,7 @@ PT_API int pt_set_interleaved_tile(pt_handle h, int rank, int world, int band_ro
 PT_API int pt_reset(pt_handle h)
 {
     PT_CHECK_HANDLE(h);
+    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     h->frame = 0; // PathTracer.cs:139 — frame 0 weights the old contents by 0, so no clear is needed
     return PT_OK;
 }
@@ -327,6 +345,7 @@ PT_API int pt_set_params(pt_handle h, int num_spheres, int num_cuboids, int ray_
                          float aperture_diameter)
 {
     PT_CHECK_HANDLE(h);
+    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (num_spheres < 0 || num_spheres > PT_MAX_SPHERES || num_cuboids < 0 || num_cuboids > PT_MAX_CUBOIDS)
         return fail(h, PT_E_OUT_OF_RANGE, "object counts exceed the GameObjectsUBO arrays (256 spheres / 64 cuboids)");
     if (ray_depth < 0 || spp < 1) return fail(h, PT_E_BAD_ARGUMENT, "ray_depth must be >= 0 and spp >= 1");
@@ -342,6 +361,7 @@ PT_API int pt_set_params(pt_handle h, int num_spheres, int num_cuboids, int ray_
 PT_API int pt_upload_basic_data(pt_handle h, int byte_offset, int size, const void *src)
 {
     PT_CHECK_HANDLE(h);
+    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (!src) return fail(h, PT_E_BAD_ARGUMENT, "src == NULL");
     if (byte_offset < 0 || size < 0 || (long long)byte_offset + size > PT_BASIC_DATA_UBO_SIZE)
         return fail(h, PT_E_OUT_OF_RANGE, "BasicDataUBO range outside [0,144)");
@@ -390,12 +410,14 @@ PT_API int pt_set_environment(pt_handle h, int face_size, int format, const void
     return PT_OK;
 }
 
-PT_API int pt_render(pt_handle h, int *out_total_samples)
+} // extern "C"
+
+namespace {
+
+// Launch frames [firstFrame, firstFrame + n) with the handle's current inputs.  n == 1: the striped frame; n > 1: one
+// batch kernel on the main stream (pt_kernels.hip, frame pipelining).
+int launch_frames(pt_handle h, int firstFrame, int n)
 {
-    PT_CHECK_HANDLE(h);
-    if (!h->dEnv) return fail(h, PT_E_NO_ENVIRONMENT, "pt_render called before pt_set_environment / pt_atmosphere_render");
-    if (h->boundAccum && h->boundBytes < h->tilePixels() * sizeof(float4))
-        return fail(h, PT_E_BAD_ARGUMENT, "bound result buffer is smaller than the tile");
     if (int rc = bind_device(h)) return rc;
     pt::FrameArgs a;
     std::memcpy(a.invProj, h->basic, 64);
@@ -409,7 +431,8 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     a.numCuboids = h->numCuboids;
     a.rayDepth = h->rayDepth;
     a.spp = h->spp;
-    a.frame = h->frame;
+    a.frame = firstFrame;
+    a.batchFrames = n;
     a.envSize = h->envSize;
     a.envFormat = h->envFormat;
     a.objects = h->dObjects;
@@ -427,7 +450,8 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     // variant -> (kernel variant, stripes): 0 = default (2 stripes x 5 workgroups/CU); 20+k / 30+k / 40+k = 2 / 3 / 4
     // stripes of the persistent kernel with k+1 workgroups per CU; everything else = one kernel on the main stream
     int stripes = 1, kernelVariant = h->variant;
-    if (h->variant == 0) { stripes = 2; kernelVariant = 14; }
+    if (h->variant == 0 && n > 1) { stripes = 1; kernelVariant = 14; h->batchLaunched = true; }
+    else if (h->variant == 0) { stripes = 2; kernelVariant = 14; }
     else if (h->variant >= 20 && h->variant < 50) { stripes = h->variant / 10; kernelVariant = 10 + h->variant % 10; }
     if (h->rows < 16 * stripes) stripes = 1; // tiny tiles: not worth splitting
     a.variant = kernelVariant;
@@ -471,8 +495,33 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
             h->stripePending[j] = true;
         }
     }
+    return PT_OK;
+}
+
+int flush_frames(pt_handle h)
+{
+    const int n = h->pendingFrames;
+    if (n == 0) return PT_OK;
+    h->pendingFrames = 0; // first: launch_frames calls join_stripes
+    return launch_frames(h, h->frame - n, n);
+}
+
+} // namespace
+
+extern "C" {
+
+PT_API int pt_render(pt_handle h, int *out_total_samples)
+{
+    PT_CHECK_HANDLE(h);
+    if (!h->dEnv) return fail(h, PT_E_NO_ENVIRONMENT, "pt_render called before pt_set_environment / pt_atmosphere_render");
+    if (h->boundAccum && h->boundBytes < h->tilePixels() * sizeof(float4))
+        return fail(h, PT_E_BAD_ARGUMENT, "bound result buffer is smaller than the tile");
+    // Only the default kernel with one sample per pixel pipelines frames; everything else launches at once.
+    const bool batchable = h->variant == 0 && h->spp == 1 && h->maxBatch > 1 && h->dTimeline == nullptr;
+    h->pendingFrames++;
     h->frame++; // PathTracer.cs:117 post-increment
     if (out_total_samples) *out_total_samples = h->frame * h->spp; // PathTracer.cs:112
+    if (!batchable || h->pendingFrames >= h->maxBatch) return flush_frames(h);
     return PT_OK;
 }
 
@@ -563,6 +612,15 @@ PT_API int pt_synchronize(pt_handle h)
     if (int rc = bind_device(h)) return rc;
     if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->batchLaunched) { // frame pipelining: did any resolve give up waiting for its pixel's previous frame?
+        unsigned int err = 0;
+        PT_HIP(h, hipMemcpy(&err, h->dQueue + 1, sizeof(err), hipMemcpyDeviceToHost));
+        h->batchLaunched = false;
+        if (err) {
+            PT_HIP(h, hipMemset(h->dQueue + 1, 0, sizeof(err)));
+            return fail(h, PT_E_HIP, "frame pipelining: a pixel's previous frame never arrived (result is not trustworthy)");
+        }
+    }
     return PT_OK;
 }
 
@@ -701,9 +759,19 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_timeline(pt_handl
     return PT_OK;
 }
 
+PT_API int pt_set_frame_batch(pt_handle h, int max_frames)
+{
+    PT_CHECK_HANDLE(h);
+    if (max_frames < 1 || max_frames > 16) return fail(h, PT_E_BAD_ARGUMENT, "max_frames must be 1..16");
+    if (int rc = flush_frames(h)) return rc;
+    h->maxBatch = max_frames;
+    return PT_OK;
+}
+
 PT_API int pt_set_variant(pt_handle h, int variant)
 {
     PT_CHECK_HANDLE(h);
+    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (int rc = bind_device(h)) return rc;
     if (int rc = join_stripes(h)) return rc; // a different stripe partition must not overlap frames in flight
     h->variant = variant;

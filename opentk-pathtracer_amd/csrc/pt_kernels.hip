@@ -790,6 +790,33 @@ __global__ __launch_bounds__(256) void pt_integrate_pool_kernel(const FrameArgs 
     }
 }
 
+// ---- frame pipelining (persistent spp = 1 kernels).  One launch can render a BATCH of consecutive frames: its tile queue
+// runs over (frame, tile) pairs, frame-major, so wavefronts only drain once per batch instead of once per frame (the
+// drain tail is ~75 us of a ~215 us frame at 1080p).  The only dependency between frames is per pixel: the running
+// mean of frame f+1 needs the pixel's value after frame f (compute.glsl:126-129).  It is carried IN the pixel: inside a
+// batch, frame j of the batch stores alpha = FRAME_TAG + j instead of 1 (the last frame of the batch stores the 1 the
+// reference stores), and the resolve of frame j only proceeds when it reads the tag of frame j-1.  Pixels are written
+// with ONE 16-byte device-scope (sc1) store and read with ONE 16-byte sc1 load — single-copy atomic and coherent
+// across the 8 XCD L2s — so colour and tag always belong together.  A resolve that finds its predecessor missing is
+// simply retried in the wavefront's next iteration (never a spin loop: the predecessor may live in another lane of
+// the same wavefront); after FRAME_RETRY_LIMIT attempts it proceeds anyway and raises the launch's error word.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr float FRAME_TAG = 2.0f;
+constexpr int FRAME_RETRY_LIMIT = 1 << 22;
+constexpr int MAX_BATCH_FRAMES = 16;
+
+PT_DEV float4 load_pixel_sc1(const float4 *p)
+{
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+PT_DEV void store_pixel_sc1(float4 *p, float4 c)
+{
+    f32x4 v = {c.x, c.y, c.z, c.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+
 // ---- variant 0 (default) and >= 10: persistent wavefronts + two-level tile queue + LDS ring of primary rays.
 // The grid is sized to the machine (blocksPerCU x CUs), not to the image.  Each wavefront repeatedly
 //   1. takes an 8x8 tile from its workgroup's queue: an LDS (cursor,end) pair advanced with one 64-bit LDS atomic
@@ -851,7 +878,7 @@ PT_DEV int queue_pop_tile(BlockQueue *q)
             if (!isDone && (unsigned int)cur >= (unsigned int)(cur >> 32)) {
                 unsigned int ticket = 0;
                 ColdArgs ca = cold_args();
-                const int numTiles = ca->tilesX * ca->tilesY, chunk = ca->queueChunk;
+                const int numTiles = ca->tilesX * ca->tilesY * ca->batchFrames, chunk = ca->queueChunk; // (frame, tile) pairs, frame-major
                 if (leader) ticket = atomicAdd(ca->queue, 1u) - ca->queueBase;
                 ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
                 long long first = ((long long)gridDim.x + ticket) * chunk;
@@ -908,7 +935,11 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
 {
     __shared__ __attribute__((aligned(16))) BlockQueue queue; // 16 B: keeps the dynamic-LDS base 16-byte aligned
     __shared__ __attribute__((aligned(16))) DrainControl drain; // 32 B
-    const int numTiles = a.tilesX * a.tilesY;
+    __shared__ float frameWeight[MAX_BATCH_FRAMES];             // 1 / (frame + j + 1): running-mean weight of the batch's frame j
+    const int numTilesFrame = a.tilesX * a.tilesY;
+    const int numTiles = numTilesFrame * a.batchFrames;         // (frame, tile) pairs, frame-major
+    if ((int)threadIdx.x < a.batchFrames && threadIdx.x < MAX_BATCH_FRAMES)
+        frameWeight[threadIdx.x] = f_div_ieee(1.0f, (float)(a.frame + (int)threadIdx.x + 1));
     if (threadIdx.x == 0) { // the workgroup's first chunk is static: chunk index = workgroup index
         long long first = (long long)blockIdx.x * a.queueChunk;
         long long last = first + a.queueChunk < numTiles ? first + a.queueChunk : numTiles;
@@ -949,6 +980,28 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     bool needRay = false;
     uint32_t seed = 0;
     v3 ro = V(0, 0, 0), rd = V(0, 0, 1), throughput = V(1, 1, 1), rad = V(0, 0, 0), irr = V(0, 0, 0);
+    // SPP1 / frame pipelining: index of the path's frame inside the batch, "ended, waiting for its pixel's previous
+    // frame" flag, and the number of failed resolve attempts
+    int fj = 0, retries = 0;
+    bool pending = false;
+
+    // compute.glsl:125-129 for one finished path of frame `rfj` of the batch.  False = the pixel still holds an older
+    // frame (only possible inside a batch): try again in the next iteration.
+    auto try_resolve = [&](int rpix, int rfj, v3 rirr, bool force) -> bool {
+        float4 *ptr = a.accum + rpix;
+        if (a.batchFrames == 1) {
+            float4 last = *ptr;
+            *ptr = resolve_pixel(a, rirr, last);
+            return true;
+        }
+        float4 last = load_pixel_sc1(ptr);
+        if (rfj > 0 && !force && last.w != FRAME_TAG + (float)(rfj - 1)) return false;
+        rirr = v_scale(rirr, f_div_ieee(1.0f, (float)a.spp));
+        const float w = frameWeight[rfj];
+        const float alpha = rfj == a.batchFrames - 1 ? 1.0f : FRAME_TAG + (float)rfj;
+        store_pixel_sc1(ptr, make_float4(f_mix(last.x, rirr.x, w), f_mix(last.y, rirr.y, w), f_mix(last.z, rirr.z, w), alpha));
+        return true;
+    };
 
     for (;;) {
         // ---- feed idle lanes: pop from the ring; if the ring runs dry while lanes are still idle, refill it with the next
@@ -970,6 +1023,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         ColdFloats cam = (ColdFloats)ca;
                         const int width = ca->width, tilesX = ca->tilesX;
                         const float invW = f_div_ieee(1.0f, (float)width), invH = f_div_ieee(1.0f, (float)ca->height);
+                        const int tfj = tile / numTilesFrame; // frame of the batch this (frame, tile) ticket belongs to
+                        tile -= tfj * numTilesFrame;
                         int tx = (int)(tile % tilesX), ty = (int)(tile / tilesX);
                         int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
                         const bool valid = x < width && ly < ca->rows;
@@ -978,28 +1033,29 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         int tpix = 0;
                         if (valid) {
                             int gy = global_row_v(ca->bandRows, ca->bandWorld, ca->bandRank, ca->localRow0, ca->y0, ly);
-                            tseed = pixel_seed(x, gy, ca->frame);
+                            tseed = pixel_seed(x, gy, ca->frame + tfj);
                             primary_ray_cam(cam, invW, invH, x, gy, tseed, to, td);
                             tpix = ly * width + x;
                         }
                         unsigned long long masks[4];
                         cull_spheres(sc, a.numSpheres, valid, to, td, masks);
-                        bool tcont = false;
+                        bool tcont = false, tkeep = false; // tkeep: the path goes to the ring (it continues, or its resolve must wait)
                         if (valid) {
                             if (0 < a.rayDepth)
                                 tcont = bounce_step_t<true, MATLDS>(sc, a.numSpheres, a.numCuboids, env, to, td, tthr, trad, tseed, masks PROF_DUMMY);
                             if (1 >= a.rayDepth) tcont = false;
+                            tkeep = tcont;
                             if (!tcont) { // the path ended at its first bounce: compute.glsl:125-129 right away
                                 v3 tirr = v_add(V(0.0f, 0.0f, 0.0f), trad);
-                                float4 last = a.accum[tpix];
-                                a.accum[tpix] = resolve_pixel(a, tirr, last);
+                                tkeep = !try_resolve(tpix, tfj, tirr, false);
                             }
                         }
-                        const unsigned long long cm = __ballot(tcont);
-                        if (tcont) {
+                        const unsigned long long cm = __ballot(tkeep);
+                        if (tkeep) {
                             int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
                             PathEntry e;
-                            e.pix = tpix; e.bounce = 1; e.seed = tseed;
+                            // a path whose resolve has to wait re-enters the bounce loop "at full depth": it is resolved there
+                            e.pix = tpix; e.bounce = (tcont ? 1 : a.rayDepth) | (tfj << 16); e.seed = tseed;
                             e.ro[0] = to.x; e.ro[1] = to.y; e.ro[2] = to.z;
                             e.rd[0] = td.x; e.rd[1] = td.y; e.rd[2] = td.z;
                             e.thr[0] = tthr.x; e.thr[1] = tthr.y; e.thr[2] = tthr.z;
@@ -1043,7 +1099,10 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                 if (idle && rank < avail) {
                     PathEntry e = pring[avail - 1 - rank];
                     pix = e.pix;
-                    bounce = e.bounce;
+                    bounce = e.bounce & 0xffff;
+                    fj = e.bounce >> 16;
+                    pending = false;
+                    retries = 0;
                     seed = e.seed;
                     ro = V(e.ro[0], e.ro[1], e.ro[2]);
                     rd = V(e.rd[0], e.rd[1], e.rd[2]);
@@ -1098,6 +1157,9 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                             PathState st = pool[taken + rank];
                             pix = st.pix;
                             bounce = (st.counters >> 12) & 0xfff;
+                            pending = (st.counters >> 25) & 1;
+                            fj = (st.counters >> 26) & 0x3f;
+                            retries = 0;
                             seed = st.seed;
                             ro = V(st.ro[0], st.ro[1], st.ro[2]);
                             rd = V(st.rd[0], st.rd[1], st.rd[2]);
@@ -1155,7 +1217,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         PathState st;
                         st.pix = pix;
                         st.pxy = SPP1 ? 0 : (px | (py << 16));
-                        st.counters = SPP1 ? (bounce << 12) : (sample | (bounce << 12) | ((needRay ? 1 : 0) << 24));
+                        st.counters = SPP1 ? ((bounce << 12) | ((pending ? 1 : 0) << 25) | (fj << 26))
+                                           : (sample | (bounce << 12) | ((needRay ? 1 : 0) << 24));
                         st.seed = seed;
                         st.ro[0] = ro.x; st.ro[1] = ro.y; st.ro[2] = ro.z;
                         st.rd[0] = rd.x; st.rd[1] = rd.y; st.rd[2] = rd.z;
@@ -1188,19 +1251,29 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         PROF_MARK(0) // feed: ring refill / pop / adopt / donate
         if constexpr (SPP1) {
             if (active) {
-                bool cont = false;
-                if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
-                bounce++;
+                if (!pending) {
+                    bool cont = false;
+                    if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
+                    bounce++;
+                    pending = !cont || bounce >= a.rayDepth;
+                }
 #ifdef PT_PROFILE
                 prof_t = __builtin_readcyclecounter();
 #endif
-                if (!cont || bounce >= a.rayDepth) {
+                if (pending) {
                     v3 firr = v_add(V(0.0f, 0.0f, 0.0f), rad);
-                    float4 last = a.accum[pix];
-                    a.accum[pix] = resolve_pixel(a, firr, last);
-                    pix = -1;
+                    const bool force = retries > FRAME_RETRY_LIMIT;
+                    if (try_resolve(pix, fj, firr, force)) {
+                        if (force) atomicOr(cold_args()->queue + 1, 1u); // error word next to the ticket counter
+                        pix = -1;
+                        pending = false;
+                    } else {
+                        retries++;
+                    }
                 }
             }
+            // nothing but waiting paths left in this wavefront: do not hammer the pixel
+            if (__ballot(active && pending) != 0ull && __ballot(active && !pending) == 0ull) __builtin_amdgcn_s_sleep(8);
         } else {
         if (active && needRay) { // only for spp > 1: the next sample continues the pixel's RNG stream (compute.glsl:110)
             primary_ray(a, px, py, seed, ro, rd);
@@ -1275,7 +1348,8 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         if (k < 0 || k > 7) k = 4;
         int blocksPerCU = k + 1;
         int nwg = a.numCUs * blocksPerCU;
-        int numChunks = (tiles + a.queueChunk - 1) / a.queueChunk;
+        if (a.batchFrames < 1 || a.batchFrames > MAX_BATCH_FRAMES || (a.batchFrames > 1 && a.spp != 1)) return hipErrorInvalidValue;
+        int numChunks = (int)(((long long)tiles * a.batchFrames + a.queueChunk - 1) / a.queueChunk); // (frame, tile) pairs
         if (nwg > numChunks) nwg = numChunks;
         if (nwg < 1) nwg = 1;
         const bool spp1 = a.spp == 1; // tile-pass kernels (the ring holds 60-byte paths instead of 40-byte primary rays)

@@ -263,6 +263,7 @@ public:
     }
     int Samples() const { int f = 0; Check(pt_get_frame_index(h_, &f), h_); return f * spp_; } // PathTracer.cs:112
     void Render() { Check(pt_render(h_, nullptr), h_); }                                        // PathTracer.cs:114-129
+    void SetFrameBatch(int maxFrames) { Check(pt_set_frame_batch(h_, maxFrames), h_); }         // frames one launch may pipeline
     void SetSize(int width, int height) { Check(pt_set_size(h_, width, height), h_); width_ = width; height_ = height; } // :131-135
     void ResetRenderer() { Check(pt_reset(h_), h_); }                                           // :137-140
 

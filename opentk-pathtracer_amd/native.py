@@ -122,6 +122,7 @@ def load() -> C.CDLL:
         "pt_timer_begin": [vp],
         "pt_timer_end": [vp, fp],
         "pt_set_variant": [vp, C.c_int],
+        "pt_set_frame_batch": [vp, C.c_int],
         "pt_device_count": [],
     }
     for name, args in sig.items():

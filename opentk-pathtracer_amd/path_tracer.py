@@ -181,6 +181,10 @@ class PathTracer:
     def SetVariant(self, variant: int) -> None:
         check(self._lib.pt_set_variant(self._h, variant), self._h)
 
+    def SetFrameBatch(self, max_frames: int) -> None:
+        """Largest number of consecutive Render() calls one launch pipelines (1 = launch every frame at once)."""
+        check(self._lib.pt_set_frame_batch(self._h, max_frames), self._h)
+
     def TimerBegin(self) -> None:
         check(self._lib.pt_timer_begin(self._h), self._h)
 

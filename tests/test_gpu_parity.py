@@ -135,6 +135,55 @@ def test_tile_pass_culling_is_conservative(pkg, native_lib, oracle, scene, size,
         assert_bit_exact(hip_render(pkg, w), oracle_render(oracle, w), f"{w.name} pos={pos} look={look}")
 
 
+@pytest.mark.parametrize("size,frames,batch", [((8, 8), 64, 16), ((24, 16), 40, 16), ((128, 72), 23, 16), ((128, 72), 23, 5),
+                                               ((128, 72), 23, 1), ((96, 54), 37, 2)], ids=lambda v: str(v))
+def test_frame_pipelining_is_bit_exact(pkg, native_lib, oracle, size, frames, batch):
+    """Consecutive Render() calls are launched as one kernel that pipelines the frames (pt_set_frame_batch); the running
+    mean of frame f+1 must see frame f of the same pixel (carried by the alpha tag inside a batch).  Tiny images put
+    the same tile of consecutive frames into flight at the same time, so the hand-over is exercised constantly."""
+    w = configs.Workload("pipelined", "default", size[0], size[1], 8, "sky_f32_32", frames=frames)
+    sc, basic, objs, env, kw = configs.inputs(w)
+    pt = pkg.PathTracer(env, w.width, w.height, w.ray_depth, 1, w.focal_length, w.aperture)
+    pt.SetFrameBatch(batch)
+    pt.UploadScene(sc)
+    pt.UploadBasicData(basic)
+    for _ in range(frames):
+        pt.Render()
+    got = pt.Result
+    assert pt.Samples == frames
+    pt.Dispose()
+    assert (got[..., 3] == 1.0).all(), "alpha tags must never be visible after a read"
+    assert_bit_exact(got, oracle_render(oracle, w), f"pipelined {size} x{frames} batch {batch}")
+
+
+def test_frame_pipelining_applies_uploads_to_later_frames_only(pkg, native_lib, oracle):
+    """Inputs changed between two Render() calls must not reach the frames already accepted: 5 frames with camera A,
+    then 4 with camera B and a moved sphere, then a depth change — compared with the same sequence launched frame by
+    frame."""
+    def run(batch):
+        w = configs.Workload("seq", "default", 96, 54, 6, "sky_f32_32")
+        sc, basic, objs, env, kw = configs.inputs(w)
+        pt = pkg.PathTracer(env, w.width, w.height, w.ray_depth, 1, w.focal_length, w.aperture)
+        pt.SetFrameBatch(batch)
+        pt.UploadScene(sc)
+        pt.UploadBasicData(basic)
+        for _ in range(5):
+            pt.Render()
+        cam = pkg.camera.Camera(position=(-10.0, 2.0, -6.0), look_x=-60.0, look_y=-5.0)
+        pt.UploadBasicData(pkg.camera.basic_data_ubo(cam, w.width, w.height))
+        sc.spheres[3].position = pkg.scene.vec3(-9.0, 0.0, -9.0)
+        pt.UploadScene(sc)
+        for _ in range(4):
+            pt.Render()
+        pt.RayDepth = 3
+        for _ in range(3):
+            pt.Render()
+        out = pt.Result
+        pt.Dispose()
+        return out
+    assert_bit_exact(run(16), run(1), "batched vs frame-by-frame launch sequence")
+
+
 # ------------------------------------------------------------------------------------------------ (2) HIP vs reference fixtures
 @pytest.mark.parametrize("name", fixtures.names("frame_"))
 def test_hip_matches_reference_fixtures(pkg, native_lib, name):
