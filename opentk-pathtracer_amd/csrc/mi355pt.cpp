@@ -50,7 +50,8 @@ struct pt_renderer {
     // Frame pipelining: consecutive pt_render calls are collected and launched as ONE batch kernel (see pt_kernels.hip)
     // when nothing observable happens in between; every other entry point launches what is pending first.
     int pendingFrames = 0;          // frames accepted by pt_render, not launched yet
-    int maxBatch = 16;              // PT_FRAME_BATCH=1 turns batching off (every pt_render launches at once)
+    int maxBatch = 32;              // PT_FRAME_BATCH=1 turns batching off (every pt_render launches at once)
+    int batchWorkgroupsPerCU = 6;   // grid of the batch kernel (PT_BATCH_WG, tuning)
     bool batchLaunched = false;     // a batch kernel ran since the last error-word check
     int drainCompaction = -1;       // donate threshold in live paths (<= 32), 0 = off, -1 = auto (see pt_render); env PT_DRAIN_COMPACTION
     int numCUs = 256;
@@ -195,9 +196,13 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     if (!h) return fail(nullptr, PT_E_OUT_OF_MEMORY, "host allocation failed");
     h->device = device_id;
     if (const char *dcv = std::getenv("PT_DRAIN_COMPACTION")) h->drainCompaction = std::atoi(dcv);
+    if (const char *bw = std::getenv("PT_BATCH_WG")) {
+        int v = std::atoi(bw);
+        if (v >= 1 && v <= 8) h->batchWorkgroupsPerCU = v;
+    }
     if (const char *fb = std::getenv("PT_FRAME_BATCH")) {
         int v = std::atoi(fb);
-        if (v >= 1 && v <= 16) h->maxBatch = v;
+        if (v >= 1 && v <= 32) h->maxBatch = v;
     }
     if (const char *qc = std::getenv("PT_QUEUE_CHUNK")) {
         int v = std::atoi(qc);
@@ -450,7 +455,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     // variant -> (kernel variant, stripes): 0 = default (2 stripes x 5 workgroups/CU); 20+k / 30+k / 40+k = 2 / 3 / 4
     // stripes of the persistent kernel with k+1 workgroups per CU; everything else = one kernel on the main stream
     int stripes = 1, kernelVariant = h->variant;
-    if (h->variant == 0 && n > 1) { stripes = 1; kernelVariant = 14; h->batchLaunched = true; }
+    if (h->variant == 0 && n > 1) { stripes = 1; kernelVariant = 10 + h->batchWorkgroupsPerCU - 1; h->batchLaunched = true; }
     else if (h->variant == 0) { stripes = 2; kernelVariant = 14; }
     else if (h->variant >= 20 && h->variant < 50) { stripes = h->variant / 10; kernelVariant = 10 + h->variant % 10; }
     if (h->rows < 16 * stripes) stripes = 1; // tiny tiles: not worth splitting
@@ -458,7 +463,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     // Drain compaction (a thin draining wavefront donates its paths to its workgroup's pool) shortens the tail of ONE
     // launch.  With stripes the tail of one launch is covered by the other stripe's (or the next frame's) main phase, and
     // the pool's LDS and the donor traffic only cost: auto = on for single-launch variants, off for striped frames.
-    a.drainCompaction = h->drainCompaction >= 0 ? h->drainCompaction : (stripes > 1 ? 0 : 32);
+    a.drainCompaction = h->drainCompaction >= 0 ? h->drainCompaction : (stripes > 1 || n > 1 ? 0 : 32); // a batch drains once per n frames
 
     if (stripes == 1) {
         if (int rc = join_stripes(h)) return rc;
@@ -762,7 +767,7 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_timeline(pt_handl
 PT_API int pt_set_frame_batch(pt_handle h, int max_frames)
 {
     PT_CHECK_HANDLE(h);
-    if (max_frames < 1 || max_frames > 16) return fail(h, PT_E_BAD_ARGUMENT, "max_frames must be 1..16");
+    if (max_frames < 1 || max_frames > 32) return fail(h, PT_E_BAD_ARGUMENT, "max_frames must be 1..32");
     if (int rc = flush_frames(h)) return rc;
     h->maxBatch = max_frames;
     return PT_OK;
