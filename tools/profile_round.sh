@@ -12,8 +12,8 @@ TAG=${1:-r01}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-BENCH="python $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline ${@:2}"
-CAL="python $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --depth 0 ${@:2}"
+BENCH="python $R/bench.py --steps 640 --warmup 320 --no-cpu-baseline ${@:2}"   # multiples of the 32-frame batch: every launch renders 32 frames
+CAL="python $R/bench.py --steps 640 --warmup 320 --no-cpu-baseline --depth 0 ${@:2}"
 run() { name=$1; opts=$2; cmd=$3; rocprofv3 --kernel-trace $opts --output-format csv -d $OUT/$name -o $name -- $cmd > $OUT/$name.log 2>&1; }
 run stats "--stats" "$BENCH"
 run fetch "--pmc FETCH_SIZE" "$BENCH"
@@ -23,6 +23,6 @@ run sq2 "--pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD 
 run tcc "--pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "$BENCH"
 run cal_fetch "--pmc FETCH_SIZE" "$CAL"
 run cal_write "--pmc WRITE_SIZE" "$CAL"
-python $R/bench.py --steps 300 --warmup 30 ${@:2} > $OUT/bench.json 2> $OUT/bench.err
+python $R/bench.py ${@:2} > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json
 ls $OUT

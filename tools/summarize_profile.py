@@ -41,7 +41,7 @@ W, H = bench.get("config", {}).get("image", [1920, 1080])
 pixels = W * H
 # a step (frame) may be several launches (row stripes on separate streams): counters are averaged per launch above,
 # so scale them to per-step values before comparing with per-frame byte counts
-L = int(bench.get("roofline", {}).get("launches_per_step", 1))
+L = float(bench.get("roofline", {}).get("launches_per_step", 1))  # 1/32 when a launch pipelines 32 frames
 pmc = {k: v * L for k, v in pmc.items()}
 cal = {k: (v * L if v else v) for k, v in cal.items()}
 # calibration: the depth-0 launch reads 16 B and writes 16 B per pixel, nothing else of size
@@ -52,6 +52,8 @@ summary = {
     "tag": tag, "workload": key, "launches_per_step": L,
     "kernel_avg_ns_rocprof": float(kstats[0]["AverageNs"]) if kstats else None,
     "kernel_calls": int(kstats[0]["Calls"]) if kstats else None,
+    "frames_per_launch": bench.get("roofline", {}).get("frames_per_launch", 1),
+    "kernel_avg_ns_rocprof_per_frame": (float(kstats[0]["AverageNs"]) * L if kstats else None),
     "bench_kernel_ms_hip_events": bench.get("roofline", {}).get("kernel_ms"),
     "pmc_mean_per_step": pmc,
     "calibration_depth0": {"known_bytes_each_way": known, "FETCH_SIZE_KiB": cal["FETCH_SIZE"], "WRITE_SIZE_KiB": cal["WRITE_SIZE"],
