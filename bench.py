@@ -5,9 +5,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A "step" is one PathTracer.Render() — one dispatch of the integrator over the whole image with the inputs (scene
+A "step" is one PathTracer.Render() — one pass of the integrator over the whole image with the inputs (scene
 UBO, camera UBO, environment cube, accumulation image) already resident in HBM; frames accumulate progressively
-exactly as in the reference (src/Render/PathTracer.cs:114-123).
+exactly as in the reference (src/Render/PathTracer.cs:114-123).  The library launches consecutive Render() calls as one
+kernel that pipelines up to --frame-batch frames; every frame is computed in full inside the
+timed region, which ends with pt_timer_end + pt_synchronize.  Defaults: 960 steps after 320 warm-up steps (the GPU
+reaches its steady clock after ~40 ms of load).
 
 N = 1 runs BASELINE.json configs[1]: default scene (48 spheres + 7 cuboids), 1920x1080, 8 bounces, 1 spp, the
 reference's default environment (256^2 RGBA32F atmosphere cube, computed by the atmosphere kernel).

@@ -8,7 +8,7 @@ python $R/bench.py --no-cpu-baseline --scene stress256 >> $O                    
 python $R/bench.py --no-cpu-baseline --scene glass --depth 32 >> $O              # C5: glass-heavy, 32 bounces, atmosphere env
 python $R/bench.py --no-cpu-baseline --env sky2048 >> $O                         # default scene with a 2048^2 sRGB sky cube
 python $R/bench.py --no-cpu-baseline --depth 13 >> $O                            # the reference's shipped default depth
-python $R/bench.py --no-cpu-baseline --spp 4 --steps 100 >> $O                   # 4 samples per pixel per frame
+python $R/bench.py --no-cpu-baseline --spp 4 --steps 240 --warmup 80 >> $O                   # 4 samples per pixel per frame
 python $R/bench.py --no-cpu-baseline --variant 1 >> $O                           # tile-per-wave kernel (reference mapping)
 python $R/bench.py --no-cpu-baseline --variant 14 >> $O                          # persistent kernel, one launch per frame
 python - <<PY
