@@ -970,7 +970,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     bool exhausted = false;
     bool lastAlive = false;  // this wavefront found itself the last one of its workgroup: it can neither donate nor leave early
 #ifdef PT_PROFILE
-    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_util[3] = {0, 0, 0};
     unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
     unsigned long long tStart = 0, tExhausted = 0, nIter = 0;
@@ -1019,6 +1019,9 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         if (TIMELINE) tExhausted = wall_clock64();
                     } else if constexpr (SPP1) {
                         // ---- tile pass: primary rays + the whole first bounce, all 64 lanes together
+#ifdef PT_PROFILE
+                        const unsigned long long prof_tile0 = __builtin_readcyclecounter();
+#endif
                         ColdArgs ca = cold_args();
                         ColdFloats cam = (ColdFloats)ca;
                         const int width = ca->width, tilesX = ca->tilesX;
@@ -1064,6 +1067,13 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         }
                         __builtin_amdgcn_wave_barrier(); // ring entries are read by other lanes of this wave below
                         avail = __builtin_popcountll(cm);
+#ifdef PT_PROFILE
+                        { // slot 6 = the tile pass (taken out of the feed slot)
+                            const unsigned long long d_ = __builtin_readcyclecounter() - prof_tile0;
+                            prof[6] += d_;
+                            prof_t += d_;
+                        }
+#endif
                     } else {
                         // camera block: FrameArgs is the kernel's first argument, so it starts the kernarg segment
                         ColdArgs ca = cold_args(); // opaque: load the camera here, do not keep it live across the loop
@@ -1249,6 +1259,12 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         }
         if (TIMELINE) nIter++;
         PROF_MARK(0) // feed: ring refill / pop / adopt / donate
+#ifdef PT_PROFILE
+        // lane utilisation of the generic bounce iteration: iterations, active lanes, lanes waiting for their pixel
+        prof_util[0] += 1ull;
+        prof_util[1] += (unsigned long long)__builtin_popcountll(am);
+        prof_util[2] += (unsigned long long)__builtin_popcountll(__ballot(active && pending));
+#endif
         if constexpr (SPP1) {
             if (active) {
                 if (!pending) {
@@ -1306,7 +1322,10 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     }
 #ifdef PT_PROFILE
     if (a.timeline && lane == 0)
-        for (int k = 0; k < 8; k++) atomicAdd(a.timeline + 200000 + k, prof[k]);
+        for (int k = 0; k < 8; k++) {
+            atomicAdd(a.timeline + 200000 + k, prof[k]);
+            if (k < 3) atomicAdd(a.timeline + 200008 + k, prof_util[k]);
+        }
 #endif
     if (TIMELINE && lane == 0) {
         unsigned long long *t = a.timeline + ((size_t)blockIdx.x * NWAVES + wave) * 4;

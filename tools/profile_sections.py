@@ -21,8 +21,12 @@ pt.Synchronize()
 buf = np.zeros((65536, 4), np.uint64)
 lib.pt_debug_timeline(pt._h, buf.ctypes.data_as(C.c_void_p), 65536)
 prof = buf.reshape(-1)[200000:200008].astype(np.float64) / frames
+util = buf.reshape(-1)[200008:200011].astype(np.float64) / frames
+if util[0] > 0:
+    print(f"generic bounce iterations per frame {util[0]:.0f}, mean active lanes {util[1] / util[0]:.2f} of 64, "
+          f"of which waiting for their pixel's previous frame {util[2] / util[0]:.3f}")
 names = ["feed (refill/pop/adopt/donate)", "sphere pass", "cuboid pass (+3 rcp)", "winner material+normal", "Beer absorption",
-         "BSDF", "miss shading (env)", "RR + resolve + bookkeeping"]
+         "BSDF", "tile pass (whole first bounce of a tile)", "RR + resolve + bookkeeping"]
 tot = prof.sum()
 print(f"scene {scene_name}: wave-cycles per frame (s_memtime ticks, summed over wavefronts): {tot:.3e}")
 for n, v in zip(names, prof):
