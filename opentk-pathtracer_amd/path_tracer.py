@@ -147,6 +147,16 @@ class PathTracer:
         check(self._lib.pt_read_result(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), 0), self._h)
         return out
 
+    def ReadInto(self, out: np.ndarray) -> np.ndarray:
+        assert out.dtype == np.float32 and out.shape == (self.rows, self.Width, 4) and out.flags.c_contiguous
+        check(self._lib.pt_read_result(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), 0), self._h)
+        return out
+
+    def PresentInto(self, out: np.ndarray) -> np.ndarray:
+        assert out.dtype == np.uint8 and out.shape == (self.rows, self.Width, 4) and out.flags.c_contiguous
+        check(self._lib.pt_present_rgba8(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), 0), self._h)
+        return out
+
     def Present(self) -> np.ndarray:
         """ScreenEffect.Render(PathTracer.Result) (ScreenEffect.cs:29-37, PostProcessing/fragment.glsl): the tone-mapped
         RGBA8 image of this tile, (rows, Width, 4) uint8, row 0 = image row y0."""
