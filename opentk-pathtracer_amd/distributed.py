@@ -106,3 +106,34 @@ def present(tile, height: int, rank: int, world: int, dst: int = 0, band_rows: i
         return out
     dist.gather(tile, gather_list=None, dst=dst)
     return None
+
+
+class _DeviceBytes:
+    """Zero-copy view of `nbytes` of device memory at `ptr` for torch.as_tensor (CUDA array interface, version 2)."""
+
+    def __init__(self, ptr: int, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def postprocessed_tile(tracer, pad_rows: int | None = None):
+    """This rank's tone-mapped RGBA8 rows (PostProcessing/fragment.glsl: ACES + gamma, run by the library on the GPU) as
+    a torch uint8 CUDA tensor of shape (pad_rows or rows, W, 4) — what `present_rgba8` gathers."""
+    import torch
+
+    ptr, nbytes = tracer.PostProcessDevice()
+    rows, w = tracer.rows, tracer.Width
+    assert nbytes >= rows * w * 4
+    torch.cuda.init()  # the array-interface path does not initialise torch's lazy CUDA state by itself
+    view = torch.as_tensor(_DeviceBytes(ptr, (rows, w, 4)), device="cuda")
+    tracer.Synchronize()  # the post-process kernel ran on the library's stream; torch reads on its own
+    pad = rows if pad_rows is None else pad_rows
+    out = torch.zeros((pad, w, 4), dtype=torch.uint8, device=view.device)
+    out[:rows].copy_(view)
+    return out
+
+
+def present_rgba8(tracer, height: int, rank: int, world: int, dst: int = 0, band_rows: int = 0):
+    """Multi-GPU present of the DISPLAYED image: every rank tone-maps its own rows on its GPU and the gather moves
+    4 bytes per pixel instead of 16 (the reference presents an RGBA8 image, ScreenEffect.cs:29-37)."""
+    pad = (max_interleaved_rows(height, world, band_rows) if band_rows and world > 1 else max_rows(height, world))
+    return present(postprocessed_tile(tracer, pad), height, rank, world, dst=dst, band_rows=band_rows)

@@ -6,7 +6,9 @@ fallback anywhere in this package: if the shared object is missing or no HIP dev
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 import re
 import shutil
 import subprocess
@@ -86,6 +88,29 @@ def declared_symbols() -> list[str]:
 _lib = None
 
 
+def _share_torch_hip_runtime() -> None:
+    """PyTorch's ROCm wheels bundle their own libamdhip64.  Whichever copy is loaded first serves the whole process:
+    if this library pulled in /opt/rocm's copy first, a later `import torch` could not initialise its GPU state
+    ("No HIP GPUs are available").  So when torch is installed, its copy is loaded first (no torch import needed);
+    the library binds to it through the common SONAME — the order bench.py and the tests always had."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load() -> C.CDLL:
     """dlopen the in-tree library (never builds implicitly on a box without hipcc; never falls back)."""
     global _lib
@@ -93,6 +118,7 @@ def load() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing — run __graft_entry__.build() (hipcc, gfx950); there is no CPU fallback")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
     sig = {

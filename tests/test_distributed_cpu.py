@@ -57,10 +57,14 @@ def _worker(rank, world, port, height, out_path, band=0):
         img = oracle.render(wl.width, wl.height, basic, objs, env, num_frames=2, y0=y0, rows=rows, threads=2, **kw)
         tile[:rows] = t.from_numpy(img)
     full = D.present(tile, height, rank, world, dst=0, band_rows=band)
+    # the displayed image: every rank tone-maps its own rows (here with the oracle's post-process), 4 B per pixel gathered
+    _, ldr = oracle.postprocess(tile.numpy())
+    full8 = D.present(t.from_numpy(ldr), height, rank, world, dst=0, band_rows=band)
     if rank == 0:
         np.save(out_path, full.numpy())
+        np.save(out_path.replace(".npy", "_rgba8.npy"), full8.numpy())
     else:
-        assert full is None
+        assert full is None and full8 is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -76,3 +80,6 @@ def test_tiled_present_over_gloo(tmp_path, oracle, world, height, band):
     want = oracle.render(wl.width, wl.height, basic, objs, env, num_frames=2, **kw)
     assert got.shape == want.shape
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "tiled+gathered image differs from untiled"
+    got8 = np.load(out.replace(".npy", "_rgba8.npy"))
+    _, want8 = oracle.postprocess(want)
+    assert got8.dtype == np.uint8 and np.array_equal(got8, want8), "gathered RGBA8 present differs from the untiled one"

@@ -488,6 +488,27 @@ def test_present_rgba8_equals_oracle_and_reference(pkg, native_lib, oracle):
     assert np.array_equal(np.concatenate(parts), ldr)
 
 
+def test_device_side_rgba8_tile_for_the_multi_gpu_present(pkg, native_lib):
+    """distributed.present_rgba8: the tile every rank contributes is the library's own post-processed image, read
+    zero-copy from device memory (world 1 here; the gather itself is covered over gloo on CPU)."""
+    import torch
+    from opentk_pathtracer_amd import distributed as D
+    w = configs.Workload("p8", "default", 200, 120, 6, "sky_f32_32")
+    sc, basic, objs, env, kw = configs.inputs(w)
+    pt = pkg.PathTracer(env, w.width, w.height, w.ray_depth, 1, w.focal_length, w.aperture)
+    pt.UploadScene(sc)
+    pt.UploadBasicData(basic)
+    pt.SetInterleavedTile(1, 3, 16)  # rank 1 of 3, 16-row bands
+    for _ in range(4):
+        pt.Render()
+    pad = D.max_interleaved_rows(w.height, 3, 16)
+    tile = D.postprocessed_tile(pt, pad)
+    assert tile.dtype == torch.uint8 and tuple(tile.shape) == (pad, w.width, 4) and tile.is_cuda
+    assert np.array_equal(tile[:pt.rows].cpu().numpy(), pt.Present())
+    assert not tile[pt.rows:].any()
+    pt.Dispose()
+
+
 def test_converged_accumulation_vs_reference(pkg, native_lib):
     """96 accumulated frames on the GPU against the reference's 96-frame accumulation (llvmpipe fixture): > 50 dB PSNR,
     99 % of pixels within 2 %, unbiased mean — the statistical half of the stated tolerance."""
