@@ -161,7 +161,7 @@ def main():
     pt.SetVariant(args.variant)
     pt.SetFrameBatch(args.frame_batch)
     # frames one launch renders: consecutive Render() calls of the default spp=1 kernel are pipelined inside one launch
-    frames_per_launch = args.frame_batch if (args.variant == 0 and args.spp == 1) else 1
+    frames_per_launch = args.frame_batch if args.variant == 0 else 1
     if args.env == "atmosphere256":   # MainWindow.cs:174-175,189
         pt.EnvironmentMap = pkg.AtmosphericScatterer(256, pkg.camera.atmospheric_data_ubo(), pkg.camera.atmosphere_light_pos(0.5), pt)
     elif args.env == "sky2048":       # MainWindow.cs:177-187 shape, synthetic content

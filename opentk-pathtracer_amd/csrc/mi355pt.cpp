@@ -521,8 +521,8 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     if (!h->dEnv) return fail(h, PT_E_NO_ENVIRONMENT, "pt_render called before pt_set_environment / pt_atmosphere_render");
     if (h->boundAccum && h->boundBytes < h->tilePixels() * sizeof(float4))
         return fail(h, PT_E_BAD_ARGUMENT, "bound result buffer is smaller than the tile");
-    // Only the default kernel with one sample per pixel pipelines frames; everything else launches at once.
-    const bool batchable = h->variant == 0 && h->spp == 1 && h->maxBatch > 1 && h->dTimeline == nullptr;
+    // Only the default kernel pipelines frames; the A/B variants launch at once.
+    const bool batchable = h->variant == 0 && h->maxBatch > 1 && h->dTimeline == nullptr;
     h->pendingFrames++;
     h->frame++; // PathTracer.cs:117 post-increment
     if (out_total_samples) *out_total_samples = h->frame * h->spp; // PathTracer.cs:112

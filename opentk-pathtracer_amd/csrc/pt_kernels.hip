@@ -881,7 +881,7 @@ PT_DEV int queue_pop_tile(BlockQueue *q)
                 const int numTiles = ca->tilesX * ca->tilesY * ca->batchFrames, chunk = ca->queueChunk; // (frame, tile) pairs, frame-major
                 if (leader) ticket = atomicAdd(ca->queue, 1u) - ca->queueBase;
                 ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
-                long long first = ((long long)gridDim.x + ticket) * chunk;
+                long long first = ((ca->batchFrames > 1 ? 0ll : (long long)gridDim.x) + ticket) * chunk; // batches have no static chunks
                 if (first >= numTiles) {
                     if (leader) lds_store(&q->done, 1u);
                 } else {
@@ -940,10 +940,14 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     const int numTiles = numTilesFrame * a.batchFrames;         // (frame, tile) pairs, frame-major
     if ((int)threadIdx.x < a.batchFrames && threadIdx.x < MAX_BATCH_FRAMES)
         frameWeight[threadIdx.x] = f_div_ieee(1.0f, (float)(a.frame + (int)threadIdx.x + 1));
-    if (threadIdx.x == 0) { // the workgroup's first chunk is static: chunk index = workgroup index
+    if (threadIdx.x == 0) {
+        // One frame per launch: the workgroup's first chunk is static (chunk index = workgroup index).  A pipelined batch
+        // hands out EVERY chunk through the global counter instead: frames depend on each other per pixel, and a workgroup
+        // that is not resident yet (more workgroups launched than fit, or another process on the GPU) must not own early
+        // work that resident workgroups are waiting for — tickets are only ever held by workgroups that are running.
         long long first = (long long)blockIdx.x * a.queueChunk;
         long long last = first + a.queueChunk < numTiles ? first + a.queueChunk : numTiles;
-        if (first >= numTiles) { first = 0; last = 0; }
+        if (first >= numTiles || a.batchFrames > 1) { first = 0; last = 0; }
         queue.pair = ((unsigned long long)last << 32) | (unsigned long long)first;
         queue.lock = 0u;
         queue.done = 0u;
@@ -1080,14 +1084,16 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         ColdFloats cam = (ColdFloats)ca;
                         const int width = ca->width, tilesX = ca->tilesX;
                         const float invW = f_div_ieee(1.0f, (float)width), invH = f_div_ieee(1.0f, (float)ca->height);
+                        const int tfj = tile / numTilesFrame; // frame of the batch this (frame, tile) ticket belongs to
+                        tile -= tfj * numTilesFrame;
                         int tx = (int)(tile % tilesX), ty = (int)(tile / tilesX);
                         int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
                         RingEntry e;
                         e.pix = -1;
-                        e.pxy = 0; e.seed = 0; e.ox = e.oy = e.oz = e.dx = e.dy = e.dz = 0.0f; e.pad = 0;
+                        e.pxy = 0; e.seed = 0; e.ox = e.oy = e.oz = e.dx = e.dy = e.dz = 0.0f; e.pad = tfj;
                         if (x < width && ly < ca->rows) {
                             int gy = global_row_v(ca->bandRows, ca->bandWorld, ca->bandRank, ca->localRow0, ca->y0, ly);
-                            uint32_t sd = pixel_seed(x, gy, ca->frame);
+                            uint32_t sd = pixel_seed(x, gy, ca->frame + tfj);
                             v3 o, d;
                             primary_ray_cam(cam, invW, invH, x, gy, sd, o, d);
                             e.pix = ly * width + x;
@@ -1137,6 +1143,9 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         rad = V(0.0f, 0.0f, 0.0f);
                         irr = V(0.0f, 0.0f, 0.0f);
                         sample = 0;
+                        fj = e.pad;
+                        pending = false;
+                        retries = 0;
                         bounce = 0;
                         needRay = false;
                     }
@@ -1227,8 +1236,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         PathState st;
                         st.pix = pix;
                         st.pxy = SPP1 ? 0 : (px | (py << 16));
-                        st.counters = SPP1 ? ((bounce << 12) | ((pending ? 1 : 0) << 25) | (fj << 26))
-                                           : (sample | (bounce << 12) | ((needRay ? 1 : 0) << 24));
+                        st.counters = (SPP1 ? 0 : (sample | ((needRay ? 1 : 0) << 24))) | (bounce << 12) | ((pending ? 1 : 0) << 25) | (fj << 26);
                         st.seed = seed;
                         st.ro[0] = ro.x; st.ro[1] = ro.y; st.ro[2] = ro.z;
                         st.rd[0] = rd.x; st.rd[1] = rd.y; st.rd[2] = rd.z;
@@ -1299,24 +1307,32 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             needRay = false;
         }
         if (active) {
-            bool cont = false;
-            if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
-            bounce++;
+            if (!pending) {
+                bool cont = false;
+                if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
+                bounce++;
+                if (!cont || bounce >= a.rayDepth) {
+                    irr = v_add(irr, rad);
+                    sample++;
+                    if (sample < a.spp) needRay = true;
+                    else pending = true; // the pixel's last sample: fold into the accumulation image
+                }
+            }
 #ifdef PT_PROFILE
             prof_t = __builtin_readcyclecounter();
 #endif
-            if (!cont || bounce >= a.rayDepth) {
-                irr = v_add(irr, rad);
-                sample++;
-                if (sample < a.spp) {
-                    needRay = true;
-                } else {
-                    float4 last = a.accum[pix];
-                    a.accum[pix] = resolve_pixel(a, irr, last);
+            if (pending) {
+                const bool force = retries > FRAME_RETRY_LIMIT;
+                if (try_resolve(pix, fj, irr, force)) {
+                    if (force) atomicOr(cold_args()->queue + 1, 1u);
                     pix = -1;
+                    pending = false;
+                } else {
+                    retries++;
                 }
             }
         }
+        if (__ballot(active && pending) != 0ull && __ballot(active && !pending) == 0ull) __builtin_amdgcn_s_sleep(8);
         } // !SPP1
         PROF_MARK(7) // resolve
     }
@@ -1366,8 +1382,9 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         int k = a.variant == 0 ? 4 : a.variant - 10;
         if (k < 0 || k > 7) k = 4;
         int blocksPerCU = k + 1;
+        if (a.spp != 1 && blocksPerCU > 5) blocksPerCU = 5; // the kernels without tile pass need 88 VGPRs: 5 wavefronts per SIMD
         int nwg = a.numCUs * blocksPerCU;
-        if (a.batchFrames < 1 || a.batchFrames > MAX_BATCH_FRAMES || (a.batchFrames > 1 && a.spp != 1)) return hipErrorInvalidValue;
+        if (a.batchFrames < 1 || a.batchFrames > MAX_BATCH_FRAMES) return hipErrorInvalidValue;
         int numChunks = (int)(((long long)tiles * a.batchFrames + a.queueChunk - 1) / a.queueChunk); // (frame, tile) pairs
         if (nwg > numChunks) nwg = numChunks;
         if (nwg < 1) nwg = 1;
@@ -1394,7 +1411,8 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         else PT_LAUNCH_PERSISTENT(false, false, false);
 #undef PT_LAUNCH_PERSISTENT
         // every workgroup draws tickets until its first failing one: (numChunks - nwg) successful + nwg failing
-        *ticketsConsumed = (unsigned int)(numChunks > nwg ? numChunks : nwg);
+        // (a pipelined batch draws every chunk dynamically: numChunks successful + nwg failing)
+        *ticketsConsumed = a.batchFrames > 1 ? (unsigned int)(numChunks + nwg) : (unsigned int)(numChunks > nwg ? numChunks : nwg);
     } else {
         int poolTiles = pool_tiles_for_variant(a.variant);
         int pools = (tiles + poolTiles - 1) / poolTiles;

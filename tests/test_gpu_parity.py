@@ -156,6 +156,35 @@ def test_frame_pipelining_is_bit_exact(pkg, native_lib, oracle, size, frames, ba
     assert_bit_exact(got, oracle_render(oracle, w), f"pipelined {size} x{frames} batch {batch}")
 
 
+@pytest.mark.parametrize("scene,depth,env,frames,spp", [("default", 0, "sky_f32_32", 9, 1), ("default", 1, "sky_f32_32", 9, 1),
+                                                        ("empty", 4, "tiny_4", 20, 1), ("edge", 24, "sky_srgb_32", 12, 1),
+                                                        ("stress256", 8, "sky_f32_32", 7, 1), ("default", 6, "sky_f32_32", 21, 3),
+                                                        ("randmat", 13, "sky_f32_32", 9, 10), ("default", 0, "sky_f32_32", 5, 2)],
+                         ids=lambda v: str(v))
+def test_frame_pipelining_edge_parameters(pkg, native_lib, oracle, scene, depth, env, frames, spp):
+    """Pipelined launches with degenerate depths (every path ends in the tile pass), an empty scene, NaN-producing glass
+    (edge scene), materials read from device memory (256 spheres) and several samples per pixel (the kernel without
+    the tile pass)."""
+    w = configs.Workload("pipe_edge", scene, 72, 40, depth, env, frames=frames, spp=spp)
+    assert_bit_exact(hip_render(pkg, w), oracle_render(oracle, w), f"{scene} depth {depth} x{frames}")
+
+
+@pytest.mark.parametrize("spp", [1, 2])
+def test_frame_pipelining_survives_oversubscription(pkg, native_lib, oracle, spp, monkeypatch):
+    """More workgroups than the GPU can keep resident (8 per CU requested; registers allow 6 resp. 5): a workgroup that
+    starts late must not own early (frame, tile) work that running workgroups wait for — every chunk of a pipelined
+    launch is drawn from the global counter.  (With static first chunks this configuration deadlocks.)"""
+    monkeypatch.setenv("PT_BATCH_WG", "8")
+    w = configs.Workload("oversub", "default", 640, 360, 5, "sky_f32_32", frames=24, spp=spp)
+    got = hip_render(pkg, w)
+    xy = np.stack([np.arange(0, 640 * 360, 97) % 640, np.arange(0, 640 * 360, 97) // 640], 1)
+    sc, basic, objs, env, kw = configs.inputs(w)
+    want = None
+    for f in range(w.frames):
+        want = oracle.render_pixels(w.width, w.height, basic, objs, env, xy, frame=f, last=want, **kw)
+    assert np.array_equal(bits(got[xy[:, 1], xy[:, 0]]), bits(want))
+
+
 def test_frame_pipelining_applies_uploads_to_later_frames_only(pkg, native_lib, oracle):
     """Inputs changed between two Render() calls must not reach the frames already accepted: 5 frames with camera A,
     then 4 with camera B and a moved sphere, then a depth change — compared with the same sequence launched frame by
