@@ -232,7 +232,10 @@ def main():
                        "image": [W, H], "ray_depth": args.depth, "spp": args.spp, "parallelism": f"rowbands{world}",
                        "kernel_variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(wl_key),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         # measured HBM bytes per LAUNCH (calibrated PMC passes, profiles/traffic.json holds bytes per frame)
+                         "traffic": (load_traffic(wl_key) * frames_per_launch if load_traffic(wl_key) else None),
+                         "traffic_per_frame": load_traffic(wl_key),
                          "kernel": "pt_integrate_persistent_kernel", "kernel_ms": round(kernel_ms, 5),
                          "launches_per_step": (1.0 / frames_per_launch if frames_per_launch > 1 else
                                                (2 if args.variant == 0 else (args.variant // 10 if 20 <= args.variant < 50 else 1))),
