@@ -1,0 +1,30 @@
+"""Soak test of the frame pipelining (development helper): N consecutive frames at full size, sparse pixels compared
+bit for bit with the oracle's frame-by-frame accumulation.  python tools/soak.py [frames] [W H]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import __graft_entry__ as g
+import configs
+pkg = g.load_package()
+oracle = g.load_oracle().Oracle()
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
+w = configs.Workload("soak", "default", W, H, 8, "sky_f32_32", frames=frames)
+sc, basic, objs, env, kw = configs.inputs(w)
+pt = pkg.PathTracer(env, W, H, w.ray_depth, 1, w.focal_length, w.aperture)
+pt.UploadScene(sc); pt.UploadBasicData(basic)
+t = time.perf_counter()
+for _ in range(frames): pt.Render()
+pt.Synchronize()
+dt = time.perf_counter() - t
+got = pt.Result
+rng = np.random.RandomState(3)
+xy = np.stack([rng.randint(0, W, 384), rng.randint(0, H, 384)], 1)
+want = None
+for f in range(frames):
+    want = oracle.render_pixels(W, H, basic, objs, env, xy, frame=f, last=want, **kw)
+same = (got[xy[:, 1], xy[:, 0]].view(np.uint32) == want.view(np.uint32)).all(-1)
+print(f"{frames} frames {W}x{H}: {dt / frames * 1e3:.4f} ms/frame, alpha==1: {(got[..., 3] == 1).all()}, "
+      f"sparse pixels bit-identical to the oracle: {same.sum()}/{len(same)}")
+sys.exit(0 if same.all() and (got[..., 3] == 1).all() else 1)
