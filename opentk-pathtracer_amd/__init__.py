@@ -11,8 +11,9 @@ which registers it as the module `opentk_pathtracer_amd`.
   camera.py        Camera + OpenTK matrix formulas -> BasicDataUBO / AtmosphericDataUBO blobs
   envmap.py        procedural stand-in environment cubes
   distributed.py   row-block tiling across GPUs (one process per GPU) + gather at present time
+  checkpoint.py    accumulation checkpoints (raw RGBA32F + frame index) and PNG screenshots
 """
-from . import camera, envmap, native, scene  # noqa: F401
+from . import camera, checkpoint, envmap, native, scene  # noqa: F401
 from .path_tracer import AtmosphericScatterer, EnvironmentMap, PathTracer  # noqa: F401
 
 __all__ = ["camera", "envmap", "native", "scene", "PathTracer", "AtmosphericScatterer", "EnvironmentMap"]

@@ -14,6 +14,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -280,6 +281,53 @@ public:
         std::vector<uint8_t> img((size_t)width_ * height_ * 4);
         Check(pt_present_rgba8(h_, img.data(), 0), h_);
         return img;
+    }
+    // Accumulation checkpoint (same file as opentk-pathtracer_amd/checkpoint.py): 8-byte magic, int32 x 8
+    // (width, height, y0, rows, band rows / world / rank, frame index), int32 x 2 (depth, spp), float x 2 (focal length,
+    // aperture), then the raw RGBA32F rows.  The C++ mirror renders whole images (no tiling).
+    void SaveCheckpoint(const std::string &path) const
+    {
+        int frame = 0;
+        Check(pt_get_frame_index(h_, &frame), h_);
+        std::vector<float> img = Result();
+        std::FILE *f = std::fopen(path.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot open " + path);
+        const int32_t ints[10] = {width_, height_, 0, height_, 0, 1, 0, frame, rayDepth_, spp_};
+        const float lens[2] = {focalLength_, apertureDiameter_};
+        bool ok = std::fwrite("PTCKPT1\0", 1, 8, f) == 8 && std::fwrite(ints, 4, 10, f) == 10 && std::fwrite(lens, 4, 2, f) == 2 &&
+                  std::fwrite(img.data(), 4, img.size(), f) == img.size();
+        ok = (std::fclose(f) == 0) && ok;
+        if (!ok) throw std::runtime_error("short write to " + path);
+    }
+    int LoadCheckpoint(const std::string &path) // returns the restored frame index
+    {
+        std::FILE *f = std::fopen(path.c_str(), "rb");
+        if (!f) throw std::runtime_error("cannot open " + path);
+        char magic[8];
+        int32_t ints[10];
+        float lens[2];
+        std::vector<float> img((size_t)width_ * height_ * 4);
+        bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "PTCKPT1\0", 8) == 0 && std::fread(ints, 4, 10, f) == 10 &&
+                  std::fread(lens, 4, 2, f) == 2;
+        ok = ok && ints[0] == width_ && ints[1] == height_ && ints[2] == 0 && ints[3] == height_ && ints[7] >= 0 &&
+             ints[8] == rayDepth_ && ints[9] == spp_ && lens[0] == focalLength_ && lens[1] == apertureDiameter_;
+        ok = ok && std::fread(img.data(), 4, img.size(), f) == img.size() && std::fgetc(f) == EOF;
+        std::fclose(f);
+        if (!ok) throw std::runtime_error(path + ": not a checkpoint of this renderer (size, depth, spp or lens differ, or corrupt)");
+        Check(pt_write_result(h_, img.data(), 0, ints[7]), h_);
+        return ints[7];
+    }
+    // The GUI's screenshot (Gui.cs:28-33 -> Framebuffer.cs:67-82), headless: the displayed image, flipped vertically like the
+    // reference's, as a binary PPM (no PNG encoder in the C++ standard library; checkpoint.py writes PNG).
+    void SaveScreenshotPPM(const std::string &path) const
+    {
+        std::vector<uint8_t> img = Present();
+        std::FILE *f = std::fopen(path.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot open " + path);
+        std::fprintf(f, "P6\n%d %d\n255\n", width_, height_);
+        for (int y = height_ - 1; y >= 0; y--)
+            for (int x = 0; x < width_; x++) std::fwrite(&img[((size_t)y * width_ + x) * 4], 1, 3, f);
+        std::fclose(f);
     }
     int Width() const { return width_; }
     int Height() const { return height_; }

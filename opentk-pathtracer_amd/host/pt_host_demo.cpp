@@ -53,7 +53,34 @@ int main(int argc, char **argv)
             std::printf("rendered %dx%d, %d samples/pixel\n", W, H, pathTracer.Samples());
             return 0;
         }
-        std::fprintf(stderr, "usage: pt_host_demo render W H frames out.f32 [rayDepth] [atmoSize] | dump-scene out.bin | dump-camera W H out.bin\n");
+        if (mode == "resume" && argc == 9) {
+            // render framesA, checkpoint, restore into a NEW renderer, render framesB more
+            int W = std::atoi(argv[2]), H = std::atoi(argv[3]), framesA = std::atoi(argv[4]), framesB = std::atoi(argv[5]);
+            auto start = [&](PathTracer &pt, AtmosphericScatterer &atmo) {
+                atmo.Render();
+                LoadScene(pt);
+                UploadCamera(pt, camera, W, H);
+            };
+            {
+                PathTracer first(nullptr, W, H, 13, 1, 20.0f, 0.14f);
+                AtmosphericScatterer atmo(first, 256);
+                start(first, atmo);
+                for (int i = 0; i < framesA; i++) first.Render();
+                first.SaveCheckpoint(argv[7]);
+            }
+            PathTracer second(nullptr, W, H, 13, 1, 20.0f, 0.14f);
+            AtmosphericScatterer atmo(second, 256);
+            start(second, atmo);
+            int restored = second.LoadCheckpoint(argv[7]);
+            for (int i = 0; i < framesB; i++) second.Render();
+            std::vector<float> img = second.Result();
+            write_file(argv[6], img.data(), img.size() * sizeof(float));
+            second.SaveScreenshotPPM(argv[8]);
+            std::printf("resumed at frame %d, now %d samples/pixel\n", restored, second.Samples());
+            return 0;
+        }
+        std::fprintf(stderr, "usage: pt_host_demo render W H frames out.f32 [rayDepth] [atmoSize] | resume W H framesA framesB out.f32 ckpt shot.ppm | "
+                             "dump-scene out.bin | dump-camera W H out.bin\n");
         return 1;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "pt_host_demo: %s\n", e.what()); // Program.cs:15-25: catch-all prints the exception

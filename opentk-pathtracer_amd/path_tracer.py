@@ -126,6 +126,7 @@ class PathTracer:
         check(self._lib.pt_set_size(self._h, width, height), self._h)
         self.Width, self.Height = width, height
         self.y0, self.rows = 0, height
+        self.band_rows, self.band_world, self.band_rank = 0, 1, 0
 
     def ResetRenderer(self) -> None:  # PathTracer.cs:137-140
         check(self._lib.pt_reset(self._h), self._h)
@@ -134,11 +135,26 @@ class PathTracer:
     def SetTile(self, y0: int, rows: int) -> None:
         check(self._lib.pt_set_tile(self._h, y0, rows), self._h)
         self.y0, self.rows = y0, rows
+        self.band_rows, self.band_world, self.band_rank = 0, 1, 0
 
     def SetInterleavedTile(self, rank: int, world: int, band_rows: int) -> None:
         check(self._lib.pt_set_interleaved_tile(self._h, rank, world, band_rows), self._h)
         from .distributed import interleaved_rows
         self.y0, self.rows = 0, len(interleaved_rows(self.Height, rank, world, band_rows))
+        self.band_rows, self.band_world, self.band_rank = band_rows, world, rank
+
+    # -- persistence (the reference only has the screenshot button, Gui.cs:28-33)
+    def SaveCheckpoint(self, path) -> None:
+        from . import checkpoint
+        checkpoint.save_checkpoint(path, self)
+
+    def LoadCheckpoint(self, path, strict: bool = True) -> dict:
+        from . import checkpoint
+        return checkpoint.load_checkpoint(path, self, strict)
+
+    def SaveScreenshot(self, path) -> None:  # Gui.cs:28-33 -> Framebuffer.cs:67-82
+        from . import checkpoint
+        checkpoint.save_screenshot(path, self)
 
     @property
     def Result(self) -> np.ndarray:
@@ -264,11 +280,6 @@ class AtmosphericScatterer:
         lp = np.ascontiguousarray(self.LightPos, dtype=np.float32)
         check(t._lib.pt_atmosphere_render(t._h, self.Size, self.ISteps, self.JSteps,
                                           lp.ctypes.data_as(C.POINTER(C.c_float)), max(self.LightIntensity, 0.0)), t._h)
-
-    def SetInterleavedTile(self, rank: int, world: int, band_rows: int) -> None:
-        check(self._lib.pt_set_interleaved_tile(self._h, rank, world, band_rows), self._h)
-        from .distributed import interleaved_rows
-        self.y0, self.rows = 0, len(interleaved_rows(self.Height, rank, world, band_rows))
 
     @property
     def Result(self) -> np.ndarray:

@@ -306,6 +306,42 @@ def test_resume_from_checkpoint(pkg, native_lib):
     assert np.array_equal(bits(pt.Result), bits(straight))
 
 
+def test_checkpoint_file_resume_and_screenshot(pkg, native_lib, tmp_path):
+    """checkpoint.py on a real renderer: 5 frames, save, load into a fresh renderer (also a banded multi-GPU tile), 4 more
+    frames == 9 frames straight; the screenshot PNG holds pt_present_rgba8's bytes top-down."""
+    w = configs.Workload("ckpt", "default", 160, 96, 8, "sky_f32_32")
+    sc, basic, objs, env, kw = configs.inputs(w)
+
+    def renderer(tile=None):
+        pt = pkg.PathTracer(env, w.width, w.height, w.ray_depth, 1, w.focal_length, w.aperture)
+        pt.UploadScene(sc)
+        pt.UploadBasicData(basic)
+        if tile:
+            pt.SetInterleavedTile(*tile)
+        return pt
+
+    for tile in (None, (1, 3, 16)):
+        straight = renderer(tile)
+        for _ in range(9):
+            straight.Render()
+        a = renderer(tile)
+        for _ in range(5):
+            a.Render()
+        path = str(tmp_path / f"acc_{bool(tile)}.ptck")
+        a.SaveCheckpoint(path)
+        b = renderer(tile)
+        assert b.LoadCheckpoint(path)["frame_index"] == 5 and b.FrameIndex == 5
+        for _ in range(4):
+            b.Render()
+        assert np.array_equal(bits(b.Result), bits(straight.Result))
+        if tile is None:
+            with pytest.raises(pkg.checkpoint.CheckpointError):
+                renderer((0, 2, 16)).LoadCheckpoint(path)
+            png = str(tmp_path / "shot.png")
+            b.SaveScreenshot(png)
+            assert np.array_equal(pkg.checkpoint.decode_png_rgb8(open(png, "rb").read()), b.Present()[::-1, :, :3])
+
+
 def test_reset_and_resize_semantics(pkg, native_lib, oracle):
     """ResetRenderer (PathTracer.cs:137-140) restarts at frame 0 and the stale image must not leak in;
     SetSize (PathTracer.cs:131-135) reallocates; partial scene updates (Gui.cs:212-216) take effect."""
@@ -444,6 +480,24 @@ def test_cpp_host_startup_sequence(pkg, native_lib, oracle, tmp_path):
                          num_frames=frames)
     close = np.abs(got - want) <= 1e-3 * np.maximum(1.0, np.abs(want))
     assert close.all(-1).mean() > 0.99
+
+
+def test_cpp_host_checkpoint_resume(pkg, native_lib, tmp_path):
+    """host/pt_host.hpp SaveCheckpoint / LoadCheckpoint / SaveScreenshotPPM: 3 frames + checkpoint + NEW renderer + 2 frames
+    in C++ == 5 frames straight (bit for bit); the file is the one checkpoint.py reads."""
+    import subprocess
+    demo = pkg.native.build_host_demo()
+    W, H = 96, 64
+    straight, resumed, ck, ppm = (tmp_path / n for n in ("straight.f32", "resumed.f32", "acc.ptck", "shot.ppm"))
+    subprocess.run([demo, "render", str(W), str(H), "5", str(straight)], check=True)
+    subprocess.run([demo, "resume", str(W), str(H), "3", "2", str(resumed), str(ck), str(ppm)], check=True)
+    a, b = np.fromfile(straight, np.float32), np.fromfile(resumed, np.float32)
+    assert a.size == W * H * 4 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    hdr, img = pkg.checkpoint.read_checkpoint_file(str(ck))
+    assert (hdr["width"], hdr["height"], hdr["rows"], hdr["frame_index"], hdr["ray_depth"], hdr["spp"]) == (W, H, H, 3, 13, 1)
+    assert img.shape == (H, W, 4) and (img[..., 3] == 1).all()
+    head = ppm.read_bytes()[:15]
+    assert head.startswith(b"P6\n96 64\n255\n") and ppm.stat().st_size == len(b"P6\n96 64\n255\n") + W * H * 3
 
 
 def test_many_consecutive_frames_queue_accounting(pkg, native_lib, oracle):

@@ -176,3 +176,61 @@ def test_cpp_host_mirror_packs_the_same_bytes(pkg, native_lib, tmp_path):
     if native_lib.pt_device_count() == 0:
         r = subprocess.run([demo, "render", "64", "64", "1", str(tmp_path / "x.f32")], capture_output=True, text=True)
         assert r.returncode == 3 and "no CPU fallback" in r.stderr
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints / screenshots
+class _FakeTracer:
+    """Just the attributes checkpoint.py touches — the file logic is host code, testable without a GPU."""
+
+    def __init__(self, w=7, h=5, rows=5, y0=0, frame=3):
+        self.Width, self.Height, self.y0, self.rows = w, h, y0, rows
+        self.RayDepth, self.SPP, self.FocalLength, self.ApertureDiameter = 8, 1, 20.0, 0.14
+        self.FrameIndex = frame
+        rng = np.random.RandomState(1)
+        self.Result = rng.rand(rows, w, 4).astype(np.float32)
+        self.Result[..., 3] = 1.0
+        self.written = None
+
+    def WriteResult(self, img, frame):
+        self.written = (img.copy(), frame)
+
+    def Present(self):
+        return (np.clip(self.Result, 0, 1) * 255).astype(np.uint8)
+
+
+def test_checkpoint_file_round_trip_and_validation(pkg, tmp_path):
+    ck = pkg.checkpoint
+    a = _FakeTracer()
+    path = str(tmp_path / "a.ptck")
+    ck.save_checkpoint(path, a)
+    assert os.path.getsize(path) == 56 + 5 * 7 * 16
+    b = _FakeTracer(frame=0)
+    hdr = ck.load_checkpoint(path, b)
+    assert hdr["frame_index"] == 3 and b.written[1] == 3
+    assert np.array_equal(b.written[0].view(np.uint32), a.Result.view(np.uint32))
+    with pytest.raises(ck.CheckpointError, match="width"):
+        ck.load_checkpoint(path, _FakeTracer(w=8))
+    other = _FakeTracer()
+    other.RayDepth = 13
+    with pytest.raises(ck.CheckpointError, match="ray_depth"):
+        ck.load_checkpoint(path, other)
+    assert ck.load_checkpoint(path, other, strict=False)["ray_depth"] == 8
+    open(str(tmp_path / "bad.ptck"), "wb").write(b"NOTACKPT" + bytes(48))
+    with pytest.raises(ck.CheckpointError, match="magic"):
+        ck.read_checkpoint_file(str(tmp_path / "bad.ptck"))
+    data = open(path, "rb").read()
+    open(str(tmp_path / "short.ptck"), "wb").write(data[:-16])
+    with pytest.raises(ck.CheckpointError, match="payload"):
+        ck.read_checkpoint_file(str(tmp_path / "short.ptck"))
+
+
+def test_screenshot_png_is_flipped_like_the_reference(pkg, tmp_path):
+    """Framebuffer.cs:79 flips the GL image (row 0 = bottom) when saving; the PNG must start with the TOP row."""
+    ck = pkg.checkpoint
+    t = _FakeTracer(w=9, h=4, rows=4)
+    path = str(tmp_path / "s.png")
+    ck.save_screenshot(path, t)
+    rgb = ck.decode_png_rgb8(open(path, "rb").read())
+    assert rgb.shape == (4, 9, 3)
+    assert np.array_equal(rgb, t.Present()[::-1, :, :3])
+    assert np.array_equal(ck.decode_png_rgb8(ck.encode_png(t.Present(), flip_vertically=False)), t.Present()[..., :3])
