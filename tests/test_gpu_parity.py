@@ -443,6 +443,29 @@ def test_atmosphere_equals_oracle_and_reference(pkg, native_lib, oracle):
     assert len(ubo) == 464
 
 
+def test_atmosphere_service_resolutions_and_parameter_changes(pkg, native_lib, oracle):
+    """the GUI re-renders the atmosphere whenever a knob moves and switches its resolution between 32 and
+    2048 (Gui.cs:89-145).  Re-rendering on one renderer with changed parameters == a fresh computation (bit for bit, vs
+    the oracle at 128); the largest size the GUI offers runs, is finite everywhere, and is timed through pt_timer_*."""
+    pt = pkg.PathTracer(None, 16, 16, 1, 1, 1.0, 0.0)
+    at = pkg.AtmosphericScatterer(128, pkg.camera.atmospheric_data_ubo(), pkg.camera.atmosphere_light_pos(0.5), pt)
+    pt.EnvironmentMap = at
+    first = at.Result
+    at.LightPos = pkg.camera.atmosphere_light_pos(0.15)      # Gui.cs "Time" slider
+    at.LightIntensity, at.ISteps, at.JSteps = 22.0, 30, 8
+    at.Render()
+    changed = at.Result
+    want = oracle.atmosphere(128, pkg.camera.atmospheric_data_ubo(), pkg.camera.atmosphere_light_pos(0.15), 22.0, 30, 8)
+    assert np.array_equal(bits(changed), bits(want)) and not np.array_equal(bits(changed), bits(first))
+    at.Size, at.ISteps, at.JSteps = 2048, 50, 15            # Gui.cs:93 resolution switch
+    pt.TimerBegin()
+    at.Render()
+    ms = pt.TimerEnd()
+    big = at.Result
+    assert big.shape == (6, 2048, 2048, 4) and np.isfinite(big).all() and (big[..., 3] == 1).all() and 0.0 < ms < 2000.0
+    pt.Dispose()
+
+
 def test_default_startup_sequence(pkg, native_lib, oracle):
     """MainWindow.OnLoad (MainWindow.cs:174-189,203): atmosphere cube at 256 -> PathTracer(env = atmosphere,
     rayDepth 13, spp 1, f 20, aperture 0.14) -> LoadScene -> frames.  End-to-end against the oracle, which renders
