@@ -1402,7 +1402,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
             ldsTotal = ldsLean;
         }
 #define PT_LAUNCH_PERSISTENT(TL, S1, ML) \
-    hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, 5, TL, S1, ML>), dim3(nwg), dim3(256), ldsTotal, stream, a)
+    hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, (S1 ? 6 : 5), TL, S1, ML>), dim3(nwg), dim3(256), ldsTotal, stream, a)
         const bool matLds = a.materialsInLds != 0;
         if (a.timeline && spp1 && matLds) PT_LAUNCH_PERSISTENT(true, true, true); // per-wavefront timestamps (tools/timeline.py)
         else if (spp1 && matLds) PT_LAUNCH_PERSISTENT(false, true, true);
