@@ -817,30 +817,31 @@ PT_DEV void store_pixel_sc1(float4 *p, float4 c)
     asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 
-// ---- variant 0 (default) and >= 10: persistent wavefronts + two-level tile queue + LDS ring of primary rays.
+// ---- variant 0 (default) and >= 10: persistent wavefronts + two-level tile queue + per-wavefront LDS ring.
 // The grid is sized to the machine (blocksPerCU x CUs), not to the image.  Each wavefront repeatedly
-//   1. takes an 8x8 tile from its workgroup's queue: an LDS (cursor,end) pair advanced with one 64-bit LDS atomic
-//      per tile; when the pair runs dry ONE wavefront of the workgroup refills it with a chunk of a.queueChunk tiles
-//      from the global counter (one device atomic per queueChunk x 64 pixels; the workgroup's first chunk is static),
-//   2. generates the tile's 64 primary rays with ALL lanes (camera code at full utilisation) into a per-wave LDS
-//      ring (pixel, RNG state after the 4 camera draws, origin, direction),
-//   3. runs bounce iterations in which every lane whose path ended pops the next ray of the ring.
+//   1. takes an 8x8 tile — or, in a pipelined batch, a (frame, tile) pair — from its workgroup's queue: an LDS
+//      (cursor,end) pair advanced with one 64-bit LDS atomic per tile; when the pair runs dry ONE wavefront of the
+//      workgroup refills it with a chunk of a.queueChunk tiles from the global counter (one device atomic per
+//      queueChunk x 64 pixels; with one frame per launch the workgroup's first chunk is static),
+//   2. spp = 1: runs the TILE PASS — the tile's 64 primary rays and their whole first bounce with all lanes, spheres
+//      culled against the tile's ray bundle — and parks the surviving paths in its LDS ring (PathEntry);
+//      spp > 1: generates the tile's 64 primary rays with all lanes into the ring (RingEntry),
+//   3. runs bounce iterations in which every lane whose path ended resolves its pixel and pops the next ring entry.
 // So the traversal loops always run (nearly) full, the camera code is never executed divergently (for spp = 1),
-// work is balanced dynamically across the chip and the only tail is the drain at the very end of the frame.
-// Pixels keep their own RNG streams -> bit-identical to every other variant.
-struct RingEntry { // 40 bytes
+// work is balanced dynamically across the chip, and the only tail is the drain at the end of the launch (once per
+// batch of frames, see "frame pipelining" above).  Pixels keep their own RNG streams -> bit-identical to every variant.
+struct RingEntry { // 40 bytes (spp > 1)
     int pix;       // linear index into accum, -1 = pixel outside the image (ragged tile)
     int pxy;       // px | py << 16 (global coordinates)
     uint32_t seed; // RNG state after the primary-ray draws
     float ox, oy, oz, dx, dy, dz;
-    int pad;
+    int pad;       // frame of the batch (frame pipelining)
 };
-
 
 // spp == 1 kernels: the ring holds paths AFTER their first bounce (see the tile pass in the kernel), 60 bytes each
 struct PathEntry {
     int pix;       // linear index into accum
-    int bounce;    // bounces done so far
+    int bounce;    // bounces done so far | frame of the batch << 16
     uint32_t seed; // RNG state
     float ro[3], rd[3], thr[3], rad[3];
 };
@@ -1350,7 +1351,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
 }
 
 // Kernel variants (pt_set_variant; every variant produces the same bits):
-//   0        default = persistent queue kernel, 4 workgroups per CU
+//   0        default = persistent queue kernel (5 workgroups per CU per stripe; 6 for a pipelined batch)
 //   1        one wavefront per 8x8 tile, one pixel per lane (the reference's own mapping; simplest kernel)
 //   2..6     wave-local pixel pools of 8 / 4 / 16 / 32 / 2 tiles with path regeneration
 //   10 + k   persistent queue kernel with k + 1 workgroups per CU
