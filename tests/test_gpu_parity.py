@@ -213,6 +213,18 @@ def test_frame_pipelining_applies_uploads_to_later_frames_only(pkg, native_lib, 
     assert_bit_exact(run(32), run(1), "batched vs frame-by-frame launch sequence")
 
 
+def test_randomised_scenes_cameras_and_parameters(pkg, native_lib):
+    """tools/fuzz_parity.py: random scenes (0-256 spheres from tiny to room-sized, nested / overlapping, 0-64 cuboids,
+    random materials), random cameras, lens, depth, spp, image size, frame count and batch size; every image must equal the
+    oracle bit for bit.  (4,000 cases were run when the tile pass and the frame pipelining were introduced; 80 here.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "80", "7"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 # ------------------------------------------------------------------------------------------------ (2) HIP vs reference fixtures
 @pytest.mark.parametrize("name", fixtures.names("frame_"))
 def test_hip_matches_reference_fixtures(pkg, native_lib, name):
