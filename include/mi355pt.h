@@ -135,6 +135,8 @@ PT_API int pt_postprocess_device(pt_handle h, void **out_device_ptr, size_t *out
 PT_API int pt_write_result(pt_handle h, const float *src_rgba32f, size_t row_pitch_bytes, int frame_index);
 
 PT_API int pt_get_frame_index(pt_handle h, int *out_frame_index);
+/* Launch what is pending and wait for the handle's stream.  Also the place where a failed frame hand-over inside a
+ * pipelined launch is reported (PT_E_HIP; it cannot happen unless the device loses workgroups mid-launch). */
 PT_API int pt_synchronize(pt_handle h);
 
 /* ---- atmosphere environment (secondary kernel) ------------------------------------------------------------- */
