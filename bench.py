@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--env", default="atmosphere256", choices=["atmosphere256", "sky2048", "sky64"])
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--frame-batch", type=int, default=32,
+    ap.add_argument("--frame-batch", type=int, default=64,
                     help="frames one launch may pipeline (pt_set_frame_batch; 1 = one launch per Render())")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--share-gpu", action="store_true",
@@ -219,7 +219,7 @@ def main():
         kernel_ms = kernel_s_max * 1e3 / args.steps
         algo_bytes = ALGO_BYTES_PER_PIXEL_FRAME * W * rows  # per launch on one GPU (rank 0's row block)
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        wl_key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{args.spp}_{args.env}_g{world}" + (f"_variant{args.variant}" if args.variant else "") + (f"_fb{args.frame_batch}" if args.frame_batch != 32 else "")
+        wl_key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{args.spp}_{args.env}_g{world}" + (f"_variant{args.variant}" if args.variant else "") + (f"_fb{args.frame_batch}" if args.frame_batch != 64 else "")
         out = {
             "metric": "Msamples/sec + ms/frame @1080p 8-bounce default scene, 1/2/4/8 GPU",
             "value": round(samples / elapsed_max / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,

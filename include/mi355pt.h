@@ -114,7 +114,7 @@ PT_API int pt_set_environment(pt_handle h, int face_size, int format, const void
  * (uploads and parameter changes apply to LATER frames only, exactly as with one launch per call; every read,
  * pt_synchronize and pt_timer_* first launch what is pending).  The image is bit-identical either way. */
 PT_API int pt_render(pt_handle h, int *out_total_samples);
-/* Largest number of frames one launch may pipeline (1..32, default 32).  1 = every pt_render launches at once (lowest
+/* Largest number of frames one launch may pipeline (1..64, default 64).  1 = every pt_render launches at once (lowest
  * latency for a host that never calls anything else between frames, e.g. one that presents through interop). */
 PT_API int pt_set_frame_batch(pt_handle h, int max_frames);
 

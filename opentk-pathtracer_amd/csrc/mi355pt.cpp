@@ -50,7 +50,7 @@ struct pt_renderer {
     // Frame pipelining: consecutive pt_render calls are collected and launched as ONE batch kernel (see pt_kernels.hip)
     // when nothing observable happens in between; every other entry point launches what is pending first.
     int pendingFrames = 0;          // frames accepted by pt_render, not launched yet
-    int maxBatch = 32;              // PT_FRAME_BATCH=1 turns batching off (every pt_render launches at once)
+    int maxBatch = 64;              // PT_FRAME_BATCH=1 turns batching off (every pt_render launches at once)
     int batchWorkgroupsPerCU = 6;   // grid of the batch kernel (PT_BATCH_WG, tuning)
     bool batchLaunched = false;     // a batch kernel ran since the last error-word check
     int drainCompaction = -1;       // donate threshold in live paths (<= 32), 0 = off, -1 = auto (see pt_render); env PT_DRAIN_COMPACTION
@@ -202,7 +202,7 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     }
     if (const char *fb = std::getenv("PT_FRAME_BATCH")) {
         int v = std::atoi(fb);
-        if (v >= 1 && v <= 32) h->maxBatch = v;
+        if (v >= 1 && v <= 64) h->maxBatch = v;
     }
     if (const char *qc = std::getenv("PT_QUEUE_CHUNK")) {
         int v = std::atoi(qc);
@@ -767,7 +767,7 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_timeline(pt_handl
 PT_API int pt_set_frame_batch(pt_handle h, int max_frames)
 {
     PT_CHECK_HANDLE(h);
-    if (max_frames < 1 || max_frames > 32) return fail(h, PT_E_BAD_ARGUMENT, "max_frames must be 1..32");
+    if (max_frames < 1 || max_frames > 64) return fail(h, PT_E_BAD_ARGUMENT, "max_frames must be 1..64");
     if (int rc = flush_frames(h)) return rc;
     h->maxBatch = max_frames;
     return PT_OK;

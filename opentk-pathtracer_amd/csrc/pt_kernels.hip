@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256) void pt_integrate_pool_kernel(const FrameArgs 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr float FRAME_TAG = 2.0f;
 constexpr int FRAME_RETRY_LIMIT = 1 << 22;
-constexpr int MAX_BATCH_FRAMES = 32;
+constexpr int MAX_BATCH_FRAMES = 64;
 
 PT_DEV float4 load_pixel_sc1(const float4 *p)
 {

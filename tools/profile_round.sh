@@ -12,7 +12,7 @@ TAG=${1:-r01}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-BENCH="python $R/bench.py --steps 640 --warmup 320 --no-cpu-baseline ${@:2}"   # multiples of the 32-frame batch: every launch renders 32 frames
+BENCH="python $R/bench.py --steps 640 --warmup 320 --no-cpu-baseline ${@:2}"   # multiples of the 64-frame batch: every launch renders 32 frames
 CAL="python $R/bench.py --steps 640 --warmup 320 --no-cpu-baseline --depth 0 ${@:2}"
 run() { name=$1; opts=$2; cmd=$3; rocprofv3 --kernel-trace $opts --output-format csv -d $OUT/$name -o $name -- $cmd > $OUT/$name.log 2>&1; }
 run stats "--stats" "$BENCH"

@@ -41,7 +41,7 @@ W, H = bench.get("config", {}).get("image", [1920, 1080])
 pixels = W * H
 # a step (frame) may be several launches (row stripes on separate streams): counters are averaged per launch above,
 # so scale them to per-step values before comparing with per-frame byte counts
-L = float(bench.get("roofline", {}).get("launches_per_step", 1))  # 1/32 when a launch pipelines 32 frames
+L = float(bench.get("roofline", {}).get("launches_per_step", 1))  # 1/64 when a launch pipelines 64 frames
 pmc = {k: v * L for k, v in pmc.items()}
 cal = {k: (v * L if v else v) for k, v in cal.items()}
 # calibration: the depth-0 launch reads 16 B and writes 16 B per pixel, nothing else of size
