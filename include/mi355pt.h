@@ -110,7 +110,8 @@ PT_API int pt_set_environment(pt_handle h, int face_size, int format, const void
  * index, then post-increment it. Asynchronous. *out_total_samples (optional) = frames * SPP after this call
  * (PathTracer.Samples, PathTracer.cs:112).
  * Frames of consecutive pt_render calls with nothing in between are launched as ONE pipelined kernel (up to
- * pt_set_frame_batch frames): the launch happens when the batch is full or at the next call of any other entry point
+ * pt_set_frame_batch frames).  A frame is only held back while earlier frames of this handle are still running on the GPU
+ * (so deferral never idles the device); the launch happens when the GPU has drained, when the batch is full, or at the next call of any other entry point
  * (uploads and parameter changes apply to LATER frames only, exactly as with one launch per call; every read,
  * pt_synchronize and pt_timer_* first launch what is pending).  The image is bit-identical either way. */
 PT_API int pt_render(pt_handle h, int *out_total_samples);

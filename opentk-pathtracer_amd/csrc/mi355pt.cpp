@@ -53,6 +53,9 @@ struct pt_renderer {
     int maxBatch = 64;              // PT_FRAME_BATCH=1 turns batching off (every pt_render launches at once)
     int batchWorkgroupsPerCU = 6;   // grid of the batch kernel (PT_BATCH_WG, tuning)
     bool batchLaunched = false;     // a batch kernel ran since the last error-word check
+    hipEvent_t mainDone = nullptr;  // recorded behind the last integrator launch on the main stream
+    bool mainInFlight = false;      // ... and not yet seen complete
+    bool stripeInFlight[4] = {false, false, false, false}; // same for the stripe streams (stripeDone events)
     int drainCompaction = -1;       // donate threshold in live paths (<= 32), 0 = off, -1 = auto (see pt_render); env PT_DRAIN_COMPACTION
     int numCUs = 256;
     void *dEnv = nullptr;      // current environment cube
@@ -229,6 +232,7 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
         PT_CREATE_HIP(hipEventCreateWithFlags(&h->stripeDone[j], hipEventDisableTiming));
     }
     PT_CREATE_HIP(hipEventCreateWithFlags(&h->inputsReady, hipEventDisableTiming));
+    PT_CREATE_HIP(hipEventCreateWithFlags(&h->mainDone, hipEventDisableTiming));
     PT_CREATE_HIP(hipEventCreate(&h->evBegin));
     PT_CREATE_HIP(hipEventCreate(&h->evEnd));
     PT_CREATE_HIP(hipMalloc((void **)&h->dObjects, PT_GAME_OBJECTS_UBO_SIZE));
@@ -270,6 +274,7 @@ PT_API int pt_destroy(pt_handle h)
         if (h->stripeStream[j]) (void)hipStreamDestroy(h->stripeStream[j]);
     }
     if (h->inputsReady) (void)hipEventDestroy(h->inputsReady);
+    if (h->mainDone) (void)hipEventDestroy(h->mainDone);
     if (h->dObjects) (void)hipFree(h->dObjects);
     if (h->dLut) (void)hipFree(h->dLut);
     if (h->dQueue) (void)hipFree(h->dQueue);
@@ -476,6 +481,8 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         unsigned int tickets = 0;
         PT_HIP(h, pt::launch_integrate(a, h->stream, &tickets));
         h->stripeQueueBase[0] += tickets; // unsigned wrap-around is fine: the kernel subtracts queueBase modulo 2^32
+        PT_HIP(h, hipEventRecord(h->mainDone, h->stream));
+        h->mainInFlight = true;
     } else {
         // inputs uploaded on the main stream (scene, environment, clears) must be visible to the stripe streams;
         // a stripe's frame f+1 follows its own frame f in stream order, which is the only dependency between frames
@@ -498,9 +505,26 @@ int launch_frames(pt_handle h, int firstFrame, int n)
             h->stripeQueueBase[j] += tickets;
             PT_HIP(h, hipEventRecord(h->stripeDone[j], h->stripeStream[j]));
             h->stripePending[j] = true;
+            h->stripeInFlight[j] = true;
         }
     }
     return PT_OK;
+}
+
+// Is an integrator launch of this handle still running (or queued) on the GPU?  Cheap event queries, no waiting.
+bool gpu_busy(pt_handle h)
+{
+    bool busy = false;
+    if (h->mainInFlight) {
+        if (hipEventQuery(h->mainDone) == hipErrorNotReady) busy = true;
+        else h->mainInFlight = false;
+    }
+    for (int j = 0; j < pt_renderer::kMaxStripes; j++) {
+        if (!h->stripeInFlight[j]) continue;
+        if (hipEventQuery(h->stripeDone[j]) == hipErrorNotReady) busy = true;
+        else h->stripeInFlight[j] = false;
+    }
+    return busy;
 }
 
 int flush_frames(pt_handle h)
@@ -526,7 +550,9 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     h->pendingFrames++;
     h->frame++; // PathTracer.cs:117 post-increment
     if (out_total_samples) *out_total_samples = h->frame * h->spp; // PathTracer.cs:112
-    if (!batchable || h->pendingFrames >= h->maxBatch) return flush_frames(h);
+    // Frames are only held back while the GPU still has integrator work of this handle in flight: deferring can then
+    // never idle the device, and a host that leaves time between its frames gets every frame launched at once.
+    if (!batchable || h->pendingFrames >= h->maxBatch || !gpu_busy(h)) return flush_frames(h);
     return PT_OK;
 }
 
