@@ -9,8 +9,9 @@ A "step" is one PathTracer.Render() — one pass of the integrator over the whol
 UBO, camera UBO, environment cube, accumulation image) already resident in HBM; frames accumulate progressively
 exactly as in the reference (src/Render/PathTracer.cs:114-123).  The library launches consecutive Render() calls as one
 kernel that pipelines up to --frame-batch frames; every frame is computed in full inside the
-timed region, which ends with pt_timer_end + pt_synchronize.  Defaults: 960 steps after 320 warm-up steps (the GPU
-reaches its steady clock after ~40 ms of load).
+timed region, which ends with pt_timer_end + pt_synchronize.  Defaults: 960 steps after 320 warm-up steps; before the
+warm-up steps the GPU is kept busy for --clock-warmup-ms (80 ms, reported in the JSON line) because it needs ~40 ms of
+load to reach its steady clock — that time is neither a step nor timed, and the accumulation restarts at frame 0 after it.
 
 N = 1 runs BASELINE.json configs[1]: default scene (48 spheres + 7 cuboids), 1920x1080, 8 bounces, 1 spp, the
 reference's default environment (256^2 RGBA32F atmosphere cube, computed by the atmosphere kernel).
@@ -122,6 +123,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--frame-batch", type=int, default=64,
                     help="frames one launch may pipeline (pt_set_frame_batch; 1 = one launch per Render())")
+    ap.add_argument("--clock-warmup-ms", type=float, default=80.0,
+                    help="wall time of untimed rendering before the W warm-up steps (GPU clock ramp); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: all ranks use cuda:0 and rendezvous over gloo (validates the N>1 logic on a 1-GPU box; "
@@ -186,6 +189,15 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # Clock warm-up (NOT counted as steps): the GPU needs ~40 ms of load to leave its idle clock; render for a fixed wall
+    # time, then restart the accumulation so that the W warm-up steps and the K timed steps start from frame 0.
+    if args.clock_warmup_ms > 0:
+        t_w = time.perf_counter()
+        while (time.perf_counter() - t_w) * 1e3 < args.clock_warmup_ms:
+            for _ in range(16):
+                pt.Render()
+            pt.Synchronize()
+        pt.ResetRenderer()
     for _ in range(args.warmup):
         pt.Render()
     if world > 1:  # first RCCL call (communicator setup) outside the timed region; also validates the gather
@@ -248,6 +260,7 @@ def main():
                                  "--frame-batch 1 launches every frame on its own (2 overlapping row-stripe launches). "
                                  "The path is fp32-VALU bound, see `valu_issue`"},
             "present_ms": round(present_ms, 3),
+            "clock_warmup_ms": args.clock_warmup_ms,
             "checks": checks,
         }
         vi = load_valu_insts(wl_key)
