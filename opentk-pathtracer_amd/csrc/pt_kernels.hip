@@ -20,607 +20,12 @@
 //
 // Arithmetic: the "pt-f32" contract of pt_math.hpp (bit-identical to oracle/pt_oracle.c).
 // Build flags (see __graft_entry__.build): -O3 -ffp-contract=off -fno-fast-math --offload-arch=gfx950
+#include "pt_atmosphere.hpp"
+#include "pt_device.hpp"
 #include "pt_kernels.hpp"
 #include "pt_math.hpp"
 
-// Section profiling (tuning builds only: hipcc -DPT_PROFILE): per-wavefront s_memtime deltas accumulated per section of
-// the bounce iteration and added to FrameArgs::timeline[0..7] at the end.  Compiled out of the product build.
-#ifdef PT_PROFILE
-#define PROF_PARAM , unsigned long long *prof
-#define PROF_PASS , prof
-#define PROF_DUMMY , prof_dummy
-#define PROF_BEGIN unsigned long long prof_t = __builtin_readcyclecounter();
-#define PROF_MARK(slot) { unsigned long long n_ = __builtin_readcyclecounter(); prof[slot] += n_ - prof_t; prof_t = n_; }
-#else
-#define PROF_PARAM
-#define PROF_PASS
-#define PROF_DUMMY
-#define PROF_BEGIN
-#define PROF_MARK(slot)
-#endif
-
 namespace pt {
-
-struct Material { // std140 Material, compute.glsl:13-26
-    v3 albedo;
-    float specularChance;
-    v3 emissiv;
-    float specularRoughness;
-    v3 absorbance;
-    float refractionChance;
-    float refractionRoughness, ior;
-};
-
-struct Hit { // compute.glsl:44-51 HitInfo
-    float T;
-    bool fromInside;
-    v3 nearHitPos, normal;
-    Material m;
-};
-
-struct SceneLds {
-    const float4 *sph;  // [numSpheres]  (centre.xyz, radius)
-    const float4 *cmin; // [numCuboids]
-    const float4 *cmax; // [numCuboids]
-    const float4 *mat;  // [(numSpheres + numCuboids) * 4]
-    const float *invr;  // [numSpheres rounded up to 4] 1 / radius (IEEE quotient, computed once per workgroup)
-    const float *lut;   // [256] sRGB8 -> linear (only staged for SRGB8_A8 environments)
-    const float4 *objects; // the std140 GameObjectsUBO in device memory (materials of large scenes are read from here)
-};
-
-// Geometry (16 B per sphere + 4 B 1/radius, 32 B per cuboid) is read by every ray and always lives in LDS.  The
-// 64-byte materials are read once per hit, by the winner only: they are staged too while the workgroup still fits
-// 5-per-CU, and stay in device memory (L2-resident, 26 KB) for large scenes, where they would cost a resident workgroup.
-__host__ __device__ inline size_t scene_lds_bytes(int ns, int nc, int envFormat, bool matInLds)
-{
-    return (size_t)(ns + 2 * nc + (matInLds ? 4 * (ns + nc) : 0)) * 16 + (size_t)((ns + 3) & ~3) * 4 + (envFormat == 1 ? 1024 : 0);
-}
-
-// ---------------------------------------------------------------------------------------------- environment
-// texture(SamplerEnvironment, dir) (compute.glsl:177): LOD 0, LINEAR magnification, seamless cube edges
-// (src/MainWindow.cs:168,178).  Face selection per OpenGL 4.5 table 8.19 (ties: Z, then X, then Y).
-typedef const __attribute__((address_space(3))) float *LdsFloats; // keeps LUT reads as ds_read (a generic pointer would make them flat loads)
-struct EnvRef {
-    const void *data;
-    LdsFloats lut;
-    int size, format;
-};
-
-// Rarely needed launch parameters are re-read from the kernarg segment where they are used (scalar loads, always
-// cached) instead of being kept live in SGPRs for the whole kernel: the bounce loop needs its SGPRs for exec-mask
-// nesting, and every spilled SGPR costs v_writelane / v_readlane VALU slots.  FrameArgs is the kernel's first argument.
-// The pointer stays in the CONSTANT address space (4), so every access is a scalar s_load (uniform, cached), not a
-// per-lane flat load.
-typedef const __attribute__((address_space(4))) FrameArgs *ColdArgs;
-typedef const __attribute__((address_space(4))) float *ColdFloats;
-PT_DEV ColdArgs cold_args()
-{
-    ColdArgs p = (ColdArgs)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-PT_DEV v3 env_texel(const EnvRef &e, int face, int x, int y)
-{
-    size_t idx = ((size_t)face * e.size + (size_t)y) * e.size + (size_t)x;
-    if (e.format == 0) {
-        float4 t = ((const float4 *)e.data)[idx];
-        return V(t.x, t.y, t.z);
-    }
-    uchar4 t = ((const uchar4 *)e.data)[idx];
-    return V(e.lut[t.x], e.lut[t.y], e.lut[t.z]);
-}
-
-PT_DEV void face_to_dir(int face, float sc, float tc, float &x, float &y, float &z)
-{
-    switch (face) {
-    case 0: x = 1.0f; y = -tc; z = -sc; break;
-    case 1: x = -1.0f; y = -tc; z = sc; break;
-    case 2: x = sc; y = 1.0f; z = tc; break;
-    case 3: x = sc; y = -1.0f; z = -tc; break;
-    case 4: x = sc; y = -tc; z = 1.0f; break;
-    default: x = -sc; y = -tc; z = -1.0f; break;
-    }
-}
-
-PT_DEV void dir_to_face(float x, float y, float z, int &face, float &sc, float &tc, float &ma)
-{
-    float ax = f_abs(x), ay = f_abs(y), az = f_abs(z);
-    if (az >= f_max(ax, ay)) {
-        face = z < 0.0f ? 5 : 4; ma = az; sc = z < 0.0f ? -x : x; tc = -y;
-    } else if (ax >= ay) {
-        face = x < 0.0f ? 1 : 0; ma = ax; sc = x < 0.0f ? z : -z; tc = -y;
-    } else {
-        face = y < 0.0f ? 3 : 2; ma = ay; sc = x; tc = y < 0.0f ? -z : z;
-    }
-}
-
-// texel (ix,iy), possibly one step outside `face` in one direction -> the texel across the seam
-PT_DEV v3 env_texel_wrapped(const EnvRef &e, int face, int ix, int iy)
-{
-    int S = e.size;
-    if (ix >= 0 && ix < S && iy >= 0 && iy < S) return env_texel(e, face, ix, iy);
-    float fs = (float)S;
-    float rfs = f_div_ieee(1.0f, fs); // uniform
-    float sc = ((float)ix + 0.5f) * rfs * 2.0f - 1.0f;
-    float tc = ((float)iy + 0.5f) * rfs * 2.0f - 1.0f;
-    float x, y, z, ma, nsc, ntc;
-    int nface;
-    face_to_dir(face, sc, tc, x, y, z);
-    dir_to_face(x, y, z, nface, nsc, ntc, ma);
-    float rma = f_rcp(ma);
-    float u = (nsc * rma * 0.5f + 0.5f) * fs;
-    float v = (ntc * rma * 0.5f + 0.5f) * fs;
-    int nx = (int)__builtin_floorf(u), ny = (int)__builtin_floorf(v);
-    nx = nx < 0 ? 0 : (nx > S - 1 ? S - 1 : nx);
-    ny = ny < 0 ? 0 : (ny > S - 1 ? S - 1 : ny);
-    return env_texel(e, nface, nx, ny);
-}
-
-PT_DEV v3 sample_env(const EnvRef &e, v3 d)
-{
-    int S = e.size, face;
-    float sc, tc, ma;
-    dir_to_face(d.x, d.y, d.z, face, sc, tc, ma);
-    float ima = 0.5f * f_rcp(ma);
-    float fs = (float)S;
-    float u = f_fma(sc, ima, 0.5f) * fs - 0.5f;
-    float v = f_fma(tc, ima, 0.5f) * fs - 0.5f;
-    u = f_min(f_max(u, -1.0f), fs); // NaN / inf directions: defined, identical clamp on CPU and GPU
-    v = f_min(f_max(v, -1.0f), fs);
-    float fu = __builtin_floorf(u), fv = __builtin_floorf(v);
-    float wu = u - fu, wv = v - fv;
-    int x0 = (int)fu, y0 = (int)fv, x1 = x0 + 1, y1 = y0 + 1;
-    bool offx0 = x0 < 0, offx1 = x1 >= S, offy0 = y0 < 0, offy1 = y1 >= S;
-    float w00 = (1.0f - wu) * (1.0f - wv), w10 = wu * (1.0f - wv), w01 = (1.0f - wu) * wv, w11 = wu * wv;
-    v3 t00, t10, t01, t11;
-    if (!(offx0 || offx1 || offy0 || offy1)) { // interior: the overwhelmingly common case
-        // one base index, the other three taps at +1, +S, +S+1 (32-bit index math, a single 64-bit address)
-        const unsigned base = ((unsigned)face * (unsigned)S + (unsigned)y0) * (unsigned)S + (unsigned)x0;
-        if (e.format == 0) {
-            const float4 *p = (const float4 *)e.data + base;
-            float4 a = p[0], b = p[1], c = p[S], d = p[S + 1];
-            t00 = V(a.x, a.y, a.z); t10 = V(b.x, b.y, b.z); t01 = V(c.x, c.y, c.z); t11 = V(d.x, d.y, d.z);
-        } else {
-            const uchar4 *p = (const uchar4 *)e.data + base;
-            uchar4 a = p[0], b = p[1], c = p[S], d = p[S + 1];
-            t00 = V(e.lut[a.x], e.lut[a.y], e.lut[a.z]); t10 = V(e.lut[b.x], e.lut[b.y], e.lut[b.z]);
-            t01 = V(e.lut[c.x], e.lut[c.y], e.lut[c.z]); t11 = V(e.lut[d.x], e.lut[d.y], e.lut[d.z]);
-        }
-    } else {
-        bool miss00 = offx0 && offy0, miss10 = offx1 && offy0, miss01 = offx0 && offy1, miss11 = offx1 && offy1;
-        v3 zero = V(0.0f, 0.0f, 0.0f);
-        t00 = miss00 ? zero : env_texel_wrapped(e, face, x0, y0);
-        t10 = miss10 ? zero : env_texel_wrapped(e, face, x1, y0);
-        t01 = miss01 ? zero : env_texel_wrapped(e, face, x0, y1);
-        t11 = miss11 ? zero : env_texel_wrapped(e, face, x1, y1);
-        if (miss00 || miss10 || miss01 || miss11) {
-            // cube corner: the missing tap's weight is shared equally by the three existing taps
-            float a = (miss00 ? w00 : miss10 ? w10 : miss01 ? w01 : w11) * 0.333333343f;
-            w00 = miss00 ? 0.0f : w00 + a;
-            w10 = miss10 ? 0.0f : w10 + a;
-            w01 = miss01 ? 0.0f : w01 + a;
-            w11 = miss11 ? 0.0f : w11 + a;
-        }
-    }
-    v3 o;
-    o.x = f_fma(t11.x, w11, f_fma(t01.x, w01, f_fma(t10.x, w10, t00.x * w00)));
-    o.y = f_fma(t11.y, w11, f_fma(t01.y, w01, f_fma(t10.y, w10, t00.y * w00)));
-    o.z = f_fma(t11.z, w11, f_fma(t01.z, w01, f_fma(t10.z, w10, t00.z * w00)));
-    return o;
-}
-
-// ---------------------------------------------------------------------------------------------- traversal
-PT_DEV float f_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
-PT_DEV float f_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
-
-// compute.glsl:322-332 GetNormal(Cuboid)
-PT_DEV v3 cuboid_normal(v3 mn, v3 mx, v3 p)
-{
-    v3 half = v_scale(v_sub(mx, mn), 0.5f);
-    v3 cs = v_sub(p, v_scale(v_add(mx, mn), 0.5f));
-    v3 n;
-    n.x = f_sign(cs.x) * f_step(f_abs(f_abs(cs.x) - half.x), EPSILON);
-    n.y = f_sign(cs.y) * f_step(f_abs(f_abs(cs.y) - half.y), EPSILON);
-    n.z = f_sign(cs.z) * f_step(f_abs(f_abs(cs.z) - half.z), EPSILON);
-    return v_normalize(n);
-}
-
-PT_DEV Material load_material(const float4 *m)
-{
-    float4 a = m[0], b = m[1], c = m[2], d = m[3];
-    Material r;
-    r.albedo = V(a.x, a.y, a.z);     r.specularChance = a.w;
-    r.emissiv = V(b.x, b.y, b.z);    r.specularRoughness = b.w;
-    r.absorbance = V(c.x, c.y, c.z); r.refractionChance = c.w;
-    r.refractionRoughness = d.x;     r.ior = d.y;
-    return r;
-}
-
-// compute.glsl:226-258 RayTrace (+ :261-294 intersections, :316-332 normals).
-// Acceptance uses the ENTRY distance t1 against the stored GetSmallestPositive (compute.glsl:234,247,347-350);
-// objects are visited in reference order; material + normal are evaluated once for the surviving candidate.
-// MASKED: only the spheres whose bit is set in the wave-uniform masks[0..3] are visited (still in index order).  The
-// masks come from cull_spheres(): a sphere outside them fails its own `t2 > 0` / discriminant test for EVERY ray of
-// the wavefront, and a sphere that fails its own test never changes T — skipping it cannot change the result.
-template <bool MASKED, bool MATLDS>
-PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, const unsigned long long *masks PROF_PARAM)
-{
-    PROF_BEGIN
-    float T = FLOAT_MAX, wt2 = 0.0f;
-    int winner = -1;
-    // Sphere pass, 4 spheres per step: the four discriminants are computed branch-free from four broadcast LDS
-    // reads issued together (ILP instead of one exposed LDS latency per sphere); only lanes with a real
-    // forward candidate enter the exact sqrt path, and candidates are accepted strictly in index order.
-    // A sphere entirely behind the origin (c > 0: origin outside, b > 0: pointing away) can never pass `t2 > 0`
-    // (sqrt(b*b - c) <= b when c > 0), so it is rejected before the square root — an exact shortcut.
-    auto candidate = [&](int i, float b, float c, float disc) {
-        if (!(disc < 0.0f) && !(c > 0.0f && b > 1e-10f)) {
-            float sq = pt_sqrt(disc);
-            float t1 = -b - sq, t2 = -b + sq;
-            if (t1 <= t2 && t2 > 0.0f && t1 < T) {
-                T = t1 < 0.0f ? t2 : t1;
-                wt2 = t2;
-                winner = i;
-            }
-        }
-    };
-    int i = 0;
-    if (MASKED) {
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            if (w * 64 >= ns) break;
-            unsigned long long mk = masks[w];
-            while (mk != 0ull) {
-                int k = w * 64 + (int)__builtin_ctzll(mk);
-                mk &= mk - 1ull;
-                float4 s = sc.sph[k];
-                v3 oc = V(o.x - s.x, o.y - s.y, o.z - s.z);
-                float b = v_dot(d, oc);
-                float c = f_fma(-s.w, s.w, v_dot(oc, oc));
-                candidate(k, b, c, f_fma(b, b, -c));
-            }
-        }
-        i = ns;
-    }
-    for (; i + 4 <= ns; i += 4) {
-        float4 s0 = sc.sph[i], s1 = sc.sph[i + 1], s2 = sc.sph[i + 2], s3 = sc.sph[i + 3];
-        float b[4], c[4], disc[4];
-        const float4 sv[4] = {s0, s1, s2, s3};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            v3 oc = V(o.x - sv[k].x, o.y - sv[k].y, o.z - sv[k].z);
-            b[k] = v_dot(d, oc);
-            c[k] = f_fma(-sv[k].w, sv[k].w, v_dot(oc, oc));
-            disc[k] = f_fma(b[k], b[k], -c[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) candidate(i + k, b[k], c[k], disc[k]); // one wave-level branch per sphere
-    }
-    for (; i < ns; i++) {
-        float4 s = sc.sph[i];
-        v3 oc = V(o.x - s.x, o.y - s.y, o.z - s.z);
-        float b = v_dot(d, oc);
-        float c = f_fma(-s.w, s.w, v_dot(oc, oc));
-        candidate(i, b, c, f_fma(b, b, -c));
-    }
-    PROF_MARK(1) // sphere pass
-    v3 invd = V(f_rcp(d.x), f_rcp(d.y), f_rcp(d.z)); // slab test by reciprocal (pt-f32 contract)
-    for (int i = 0; i < nc; i++) {
-        float4 mn = sc.cmin[i], mx = sc.cmax[i];
-        v3 t0s = V((mn.x - o.x) * invd.x, (mn.y - o.y) * invd.y, (mn.z - o.z) * invd.z);
-        v3 t1s = V((mx.x - o.x) * invd.x, (mx.y - o.y) * invd.y, (mx.z - o.z) * invd.z);
-        v3 sm = V(f_min(t0s.x, t1s.x), f_min(t0s.y, t1s.y), f_min(t0s.z, t1s.z));
-        v3 bg = V(f_max(t0s.x, t1s.x), f_max(t0s.y, t1s.y), f_max(t0s.z, t1s.z));
-        float t1 = f_max(FLOAT_MIN, f_max(sm.x, f_max(sm.y, sm.z)));
-        float t2 = f_min(FLOAT_MAX, f_min(bg.x, f_min(bg.y, bg.z)));
-        if (t1 <= t2 && t2 > 0.0f && t1 < T) {
-            T = t1 < 0.0f ? t2 : t1;
-            wt2 = t2;
-            winner = 256 + i;
-        }
-    }
-    PROF_MARK(2) // cuboid pass
-    if (winner < 0 || !(T != FLOAT_MAX)) return false; // compute.glsl:257
-    h.T = T;
-    h.fromInside = (T == wt2);
-    h.nearHitPos = v_fma(d, T, o);
-    if (winner < 256) {
-        float4 s = sc.sph[winner];
-        if (MATLDS) h.m = load_material(sc.mat + 4 * winner);
-        else h.m = load_material(sc.objects + 5 * winner + 1); // std140 Sphere = geometry + 4 x float4 material
-        v3 pc = V(h.nearHitPos.x - s.x, h.nearHitPos.y - s.y, h.nearHitPos.z - s.z);
-        h.normal = v_scale(pc, sc.invr[winner]); // compute.glsl:316-319; 1/radius = IEEE quotient staged in LDS
-    } else {
-        int ci = winner - 256;
-        float4 mn = sc.cmin[ci], mx = sc.cmax[ci];
-        if (MATLDS) h.m = load_material(sc.mat + 4 * (ns + ci));
-        else h.m = load_material(sc.objects + 1280 + 6 * ci + 2); // Cuboids[] start at float4 index 1280: min, max, material
-        h.normal = cuboid_normal(V(mn.x, mn.y, mn.z), V(mx.x, mx.y, mx.z), h.nearHitPos);
-    }
-    PROF_MARK(3) // winner: material + normal
-    return true;
-}
-PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h PROF_PARAM)
-{
-    return ray_trace_t<false, true>(sc, ns, nc, o, d, h, nullptr PROF_PASS);
-}
-
-// ---- per-tile sphere culling for a wavefront of (nearly) coherent rays
-// Wavefront-wide maximum of a non-negative value.  row_shr:1/2/4/8 inside each row of 16 lanes (a lane shifted in
-// from outside the row contributes 0, the identity here), then row_bcast:15 / row_bcast:31 carry the row results
-// across the rows; lane 63 ends up with the maximum, which is broadcast.  Must be called with all 64 lanes active.
-PT_DEV float wave_max_nonneg(float x)
-{
-#define PT_DPP_MAX(ctrl, rowmask) \
-    x = __builtin_fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rowmask, 0xf, false)))
-    PT_DPP_MAX(0x111, 0xf);
-    PT_DPP_MAX(0x112, 0xf);
-    PT_DPP_MAX(0x114, 0xf);
-    PT_DPP_MAX(0x118, 0xf);
-    PT_DPP_MAX(0x142, 0xa);
-    PT_DPP_MAX(0x143, 0xc);
-#undef PT_DPP_MAX
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
-}
-
-// The 64 primary rays of one 8x8 tile leave (almost) one point in (almost) one direction.  They are bounded by a cone:
-// apex region = ball of radius rho around one reference ray's origin O, axis A = that ray's direction, half-angle theta =
-// the largest angle any ray of the wavefront makes with A (both measured from the actual rays, so any camera matrix,
-// aperture or jitter is covered).  A ray (o, d) of the bundle can only reach sphere (c, r) with t > 0 if the ray (O, d)
-// reaches the sphere (c, R = r + rho), i.e. if |c - O| <= R or angle(A, c - O) <= theta + asin(R / |c - O|).  Lane j
-// tests sphere j (+64, +128, +192): masks[] = spheres that pass.  Every quantity is padded (0.1 % and absolute slack far
-// above float rounding), and the test only ever REMOVES spheres that no ray of the wavefront can hit — those would fail
-// `discriminant >= 0 && t2 > 0` (compute.glsl:261-277) for every lane and leave T untouched — so the traced result is
-// bit-identical to visiting all spheres.  Hardware sqrt/rcp approximations are fine here: they only move the padding.
-PT_DEV void cull_spheres(const SceneLds &sc, int ns, bool valid, v3 o, v3 d, unsigned long long masks[4])
-{
-    const int lane = threadIdx.x & 63;
-    masks[0] = masks[1] = masks[2] = masks[3] = 0ull;
-    const unsigned long long vm = __ballot(valid);
-    if (vm == 0ull) return;
-    const int ref = ((vm >> 36) & 1ull) ? 36 : (int)__builtin_ctzll(vm); // pixel (4,4) of the tile, else the first valid lane
-    const v3 O = V(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.x), ref)),
-                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.y), ref)),
-                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.z), ref)));
-    const v3 A = V(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.x), ref)),
-                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.y), ref)),
-                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.z), ref)));
-    const v3 dv = v_sub(o, O);
-    // a NaN ray hits nothing (every comparison of its intersection tests is false): fmax drops it from the bounds
-    float dev2 = wave_max_nonneg(__builtin_fmaxf(valid ? v_dot(dv, dv) : 0.0f, 0.0f));
-    float spread = wave_max_nonneg(__builtin_fmaxf(valid ? 1.0f - v_dot(A, d) : 0.0f, 0.0f)); // 1 - cos(angle to A)
-    const float rho = __builtin_amdgcn_sqrtf(dev2) * 1.001f;
-    const float ct = 1.0f - spread * 1.01f - 1e-5f;          // padded cos(theta)
-    const bool coneUsable = ct > 0.05f;                       // a bundle wider than ~87 degrees is not culled at all
-    const float st = __builtin_amdgcn_sqrtf(__builtin_fmaxf(f_fma(-ct, ct, 1.0f), 0.0f));
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        if (w * 64 >= ns) break;
-        const int i = w * 64 + lane;
-        const bool in = i < ns;
-        const float4 s = sc.sph[in ? i : 0];
-        const v3 v = V(s.x - O.x, s.y - O.y, s.z - O.z);
-        const float L = __builtin_amdgcn_sqrtf(v_dot(v, v));
-        const float R = f_fma(f_abs(s.w) + rho, 1.001f, f_fma(L, 1e-4f, 1e-3f));
-        bool outside = false;
-        if (coneUsable && L > R) { // NaN / inf anywhere -> comparisons false -> the sphere is kept
-            const float sb = R * __builtin_amdgcn_rcpf(L);
-            const float cb = __builtin_amdgcn_sqrtf(__builtin_fmaxf(f_fma(-sb, sb, 1.0f), 0.0f));
-            const float cosSum = f_fma(ct, cb, -(st * sb)) - 1e-4f; // padded cos(theta + beta)
-            outside = v_dot(v, A) < L * cosSum;
-        }
-        masks[w] = __ballot(in && !outside);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------- sampling / BSDF
-// compute.glsl:297-307
-PT_DEV v3 cosine_sample_hemisphere(v3 n, uint32_t &seed)
-{
-    float z = f_fma(rand01(seed), 2.0f, -1.0f);
-    float a = rand01(seed) * 2.0f * PI;
-    float r = pt_sqrt(f_fma(-z, z, 1.0f));
-    float sn, cs;
-    pt_sincos(a, sn, cs);
-    return v_normalize(v_add(n, V(r * cs, r * sn, z)));
-}
-
-// compute.glsl:359-364
-PT_DEV float fresnel_schlick(float cosTheta, float n1, float n2)
-{
-    float r0 = (n1 - n2) * f_rcp(n1 + n2);
-    r0 *= r0;
-    return f_fma(1.0f - r0, pt_pow5(1.0f - cosTheta), r0);
-}
-
-PT_DEV v3 f_reflect(v3 i, v3 n) { return v_fma(n, -(2.0f * v_dot(n, i)), i); }
-
-PT_DEV v3 f_refract(v3 i, v3 n, float eta)
-{
-    float ni = v_dot(n, i);
-    float k = f_fma(-(eta * eta), f_fma(-ni, ni, 1.0f), 1.0f);
-    if (k < 0.0f) return V(0.0f, 0.0f, 0.0f);
-    float f = f_fma(eta, ni, pt_sqrt(k));
-    return V(f_fma(eta, i.x, -(f * n.x)), f_fma(eta, i.y, -(f * n.y)), f_fma(eta, i.z, -(f * n.z)));
-}
-
-// compute.glsl:184-224 BSDF: picks the next ray, returns its probability
-PT_DEV float bsdf(v3 &ro, v3 &rd, const Hit &h, bool &isRefractive, uint32_t &seed)
-{
-    isRefractive = false;
-    float spec = h.m.specularChance, refr = h.m.refractionChance;
-    if (spec > 0.0f) {
-        float n1 = h.fromInside ? h.m.ior : 1.0f, n2 = !h.fromInside ? h.m.ior : 1.0f;
-        spec = f_mix(spec, 1.0f, fresnel_schlick(v_dot(v_neg(rd), h.normal), n1, n2));
-        float diffuse = 1.0f - spec - refr;
-        refr = 1.0f - spec - diffuse;
-    }
-    v3 diffuseRay = cosine_sample_hemisphere(h.normal, seed);
-    float prob;
-    float roll = rand01(seed);
-    // the specular and the refractive lobe both end in normalize(mix(...)); the mix is evaluated per lobe and the
-    // normalisation once for whichever lobe the lane took (same arithmetic per lane, one code instance per wave)
-    v3 raw = diffuseRay;
-    bool lobe = false;
-    if (spec > roll) {
-        v3 refl = f_reflect(rd, h.normal);
-        raw = v_mix(refl, diffuseRay, h.m.specularRoughness * h.m.specularRoughness);
-        prob = spec;
-        lobe = true;
-    } else if (spec + refr > roll) {
-        v3 rf = f_refract(rd, h.normal, h.fromInside ? h.m.ior : f_rcp(h.m.ior));
-        v3 rough = cosine_sample_hemisphere(v_neg(h.normal), seed);
-        raw = v_mix(rf, rough, h.m.refractionRoughness * h.m.refractionRoughness);
-        prob = refr;
-        isRefractive = true;
-        lobe = true;
-    } else {
-        prob = 1.0f - spec - refr;
-    }
-    rd = lobe ? v_normalize(raw) : raw;
-    ro = v_fma(rd, EPSILON, h.nearHitPos);
-    return f_max(prob, EPSILON);
-}
-
-// One iteration of Radiance's bounce loop (compute.glsl:140-180) for one path.  Returns true when the path
-// continues (hit, survived Russian roulette), false when it ended (miss -> environment, or roulette kill).
-template <bool MASKED, bool MATLDS>
-PT_DEV bool bounce_step_t(const SceneLds &sc, int ns, int nc, const EnvRef &env, v3 &ro, v3 &rd, v3 &throughput, v3 &rad,
-                          uint32_t &seed, const unsigned long long *masks PROF_PARAM)
-{
-    Hit h;
-    if (ray_trace_t<MASKED, MATLDS>(sc, ns, nc, ro, rd, h, masks PROF_PASS)) {
-        PROF_BEGIN
-        if (h.fromInside) { // Beer's law, compute.glsl:145-149
-            h.normal = v_neg(h.normal);
-            throughput.x *= pt_exp(-h.m.absorbance.x * h.T);
-            throughput.y *= pt_exp(-h.m.absorbance.y * h.T);
-            throughput.z *= pt_exp(-h.m.absorbance.z * h.T);
-        }
-        PROF_MARK(4) // Beer
-        bool isRefractive;
-        float prob = bsdf(ro, rd, h, isRefractive, seed);
-        PROF_MARK(5) // BSDF
-        rad = V(f_fma(h.m.emissiv.x, throughput.x, rad.x), f_fma(h.m.emissiv.y, throughput.y, rad.y),
-                f_fma(h.m.emissiv.z, throughput.z, rad.z));
-        if (!isRefractive) throughput = v_mul(throughput, h.m.albedo);
-        throughput = v_scale(throughput, f_rcp(prob));
-        float p = f_max(throughput.x, f_max(throughput.y, throughput.z)); // Russian roulette, :167-173
-        if (rand01(seed) > p) return false;
-        throughput = v_scale(throughput, f_rcp(p));
-        return true;
-    }
-    PROF_BEGIN
-    v3 e;
-    if (env.data == nullptr) { // persistent kernel: fetch the environment descriptor where it is needed (see cold_args)
-        ColdArgs ca = cold_args();
-        EnvRef cold{ca->env, env.lut, ca->envSize, ca->envFormat};
-        e = sample_env(cold, rd); // compute.glsl:177
-    } else {
-        e = sample_env(env, rd);
-    }
-    rad = V(f_fma(e.x, throughput.x, rad.x), f_fma(e.y, throughput.y, rad.y), f_fma(e.z, throughput.z, rad.z));
-    PROF_MARK(6) // miss shading
-    return false;
-}
-PT_DEV bool bounce_step(const SceneLds &sc, int ns, int nc, const EnvRef &env, v3 &ro, v3 &rd, v3 &throughput, v3 &rad,
-                        uint32_t &seed PROF_PARAM)
-{
-    return bounce_step_t<false, true>(sc, ns, nc, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
-}
-
-// compute.glsl:132-182 Radiance
-PT_DEV v3 radiance(const FrameArgs &a, const SceneLds &sc, const EnvRef &env, v3 ro, v3 rd, uint32_t &seed)
-{
-#ifdef PT_PROFILE
-    unsigned long long prof_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    v3 throughput = V(1.0f, 1.0f, 1.0f), rad = V(0.0f, 0.0f, 0.0f);
-    for (int i = 0; i < a.rayDepth; i++)
-        if (!bounce_step(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed PROF_DUMMY)) break;
-    return rad;
-}
-
-// GLSL mat4 * vec4 on the column-major view of the UBO bytes: m[4c + r]
-template <typename FP>
-PT_DEV void mat_vec(FP m, float x, float y, float z, float w, float *out)
-{
-#pragma unroll
-    for (int r = 0; r < 4; r++) out[r] = f_fma(m[12 + r], w, f_fma(m[8 + r], z, f_fma(m[4 + r], y, m[r] * x)));
-}
-
-// compute.glsl:113-121: sub-pixel jitter, GetWorldSpaceRay (:352-357), thin lens (UniformSampleUnitCircle :309-314).
-// Consumes 4 RNG draws.
-// The camera block (invProj[16], invView[16], viewPos[3], focalLength, apertureDiameter = the first 37 floats of
-// FrameArgs) is read through `cam`.  The persistent kernel passes a pointer into its kernarg segment that is made
-// opaque once per ring refill, so these 37 scalars are s_load-ed where they are used instead of being kept live in
-// SGPRs across the whole bounce loop (which spilled SGPRs into VGPR lanes).
-template <typename FP>
-PT_DEV void primary_ray_cam(FP cam, float invW, float invH, int px, int py, uint32_t &seed, v3 &ro, v3 &rd)
-{
-    FP invProj = cam, invView = cam + 16;
-    v3 viewPos = V(cam[32], cam[33], cam[34]);
-    float u0 = rand01(seed), u1 = rand01(seed); // :113
-    float ndcx = f_fma(((float)px + u0) * invW, 2.0f, -1.0f); // uniform 1/W, 1/H (IEEE quotients)
-    float ndcy = f_fma(((float)py + u1) * invH, 2.0f, -1.0f);
-    float eye[4], wd[4];
-    mat_vec(invProj, ndcx, ndcy, -1.0f, 0.0f, eye);
-    mat_vec(invView, eye[0], eye[1], -1.0f, 0.0f, wd);
-    v3 dir = v_normalize(V(wd[0], wd[1], wd[2]));
-    v3 focal = v_fma(dir, cam[35], viewPos); // :117
-    float angle = rand01(seed) * 2.0f * PI;
-    float rr = pt_sqrt(rand01(seed));
-    float sn, cs;
-    pt_sincos(angle, sn, cs);
-    float half_ap = cam[36] * 0.5f;
-    float ox = half_ap * (cs * rr), oy = half_ap * (sn * rr);
-    float org[4];
-    mat_vec(invView, ox, oy, 0.0f, 1.0f, org); // :120
-    ro = V(org[0], org[1], org[2]);
-    rd = v_normalize(v_sub(focal, ro));
-}
-
-PT_DEV void primary_ray(const FrameArgs &a, int px, int py, uint32_t &seed, v3 &ro, v3 &rd)
-{
-    primary_ray_cam<const float *>(a.invProj, f_div_ieee(1.0f, (float)a.width), f_div_ieee(1.0f, (float)a.height), px, py, seed, ro, rd);
-}
-
-// image row of local row `ly` of this launch (contiguous row block, or block-cyclic bands across GPUs)
-PT_DEV int global_row_v(int bandRows, int bandWorld, int bandRank, int localRow0, int y0, int ly)
-{
-    if (bandRows == 0) return y0 + ly;
-    int l = localRow0 + ly;
-    int band = l / bandRows;
-    return (band * bandWorld + bandRank) * bandRows + (l - band * bandRows);
-}
-PT_DEV int global_row(const FrameArgs &a, int ly) { return global_row_v(a.bandRows, a.bandWorld, a.bandRank, a.localRow0, a.y0, ly); }
-
-PT_DEV uint32_t pixel_seed(int px, int py, int frame)
-{
-    return ((uint32_t)px * 1973u + (uint32_t)py * 9277u + (uint32_t)frame * 2699u) | 1u; // compute.glsl:106
-}
-
-// compute.glsl:125-129: irradiance /= SPP; running mean with the previous accumulation value; alpha = 1
-PT_DEV float4 resolve_pixel(const FrameArgs &a, v3 irr, float4 last)
-{
-    irr = v_scale(irr, f_div_ieee(1.0f, (float)a.spp)); // uniform reciprocal
-    float w = f_div_ieee(1.0f, (float)(a.frame + 1));
-    return make_float4(f_mix(last.x, irr.x, w), f_mix(last.y, irr.y, w), f_mix(last.z, irr.z, w), 1.0f);
-}
-
-// compute.glsl:101-130 main for one pixel: returns the new accumulation value
-PT_DEV float4 shade_pixel(const FrameArgs &a, const SceneLds &sc, const EnvRef &env, int px, int py, float4 last)
-{
-    uint32_t seed = pixel_seed(px, py, a.frame);
-    v3 irr = V(0.0f, 0.0f, 0.0f);
-    for (int s = 0; s < a.spp; s++) {
-        v3 ro, rd;
-        primary_ray(a, px, py, seed, ro, rd);
-        irr = v_add(irr, radiance(a, sc, env, ro, rd, seed));
-    }
-    return resolve_pixel(a, irr, last);
-}
 
 // ---------------------------------------------------------------------------------------------- kernels
 extern __shared__ float4 g_lds[];
@@ -1491,70 +896,7 @@ hipError_t launch_postprocess(const float4 *accum, void *outRgba8, size_t n, hip
 }
 
 // ---------------------------------------------------------------------------------------------- atmosphere
-// /root/reference/OpenTK-PathTracer/res/shaders/AtmosphericScattering/compute.glsl:30-171
-// (algorithm credited there to github.com/wwwtyro/glsl-atmosphere); one thread per cube texel.
-PT_DEV void atmo_rsi(v3 r0, v3 rd, float sr, float &x, float &y) // :58-71
-{
-    float a = v_dot(rd, rd);
-    float b = 2.0f * v_dot(rd, r0);
-    float c = f_fma(-sr, sr, v_dot(r0, r0));
-    float d = f_fma(b, b, -(4.0f * a * c));
-    if (d < 0.0f) { x = 1e5f; y = -1e5f; return; }
-    float sq = f_sqrt(d), den = 2.0f * a;
-    x = (-b - sq) / den;
-    y = (-b + sq) / den;
-}
-
-PT_DEV v3 atmosphere(v3 r, v3 r0, v3 pSun, float iSun, float rPlanet, float rAtmos, v3 kRlh, float kMie, float shRlh,
-                     float shMie, float g, int iSteps, int jSteps) // :73-159
-{
-    pSun = v_normalize(pSun);
-    r = v_normalize(r);
-    float px, py, qx, qy;
-    atmo_rsi(r0, r, rAtmos, px, py);
-    if (px > py) return V(0.0f, 0.0f, 0.0f);
-    atmo_rsi(r0, r, rPlanet, qx, qy);
-    py = f_min(py, qx);
-    float iStepSize = (py - px) / (float)iSteps;
-    float iTime = 0.0f;
-    v3 totalRlh = V(0.0f, 0.0f, 0.0f), totalMie = V(0.0f, 0.0f, 0.0f);
-    float iOdRlh = 0.0f, iOdMie = 0.0f;
-    float mu = v_dot(r, pSun), mumu = mu * mu, gg = g * g;
-    float pRlh = 3.0f / (16.0f * PI) * (1.0f + mumu);
-    float base = 1.0f + gg - 2.0f * mu * g;
-    float pMie = 3.0f / (8.0f * PI) * ((1.0f - gg) * (mumu + 1.0f)) / ((base * f_sqrt(base)) * (2.0f + gg));
-    float invShRlh = -1.0f / shRlh, invShMie = -1.0f / shMie;
-    for (int i = 0; i < iSteps; i++) {
-        v3 iPos = v_fma(r, f_fma(iStepSize, 0.5f, iTime), r0);
-        float iHeight = f_sqrt(v_dot(iPos, iPos)) - rPlanet;
-        float odStepRlh = pt_exp(iHeight * invShRlh) * iStepSize;
-        float odStepMie = pt_exp(iHeight * invShMie) * iStepSize;
-        iOdRlh += odStepRlh;
-        iOdMie += odStepMie;
-        float sx, sy;
-        atmo_rsi(iPos, pSun, rAtmos, sx, sy);
-        float jStepSize = sy / (float)jSteps;
-        float jTime = 0.0f, jOdRlh = 0.0f, jOdMie = 0.0f;
-        for (int j = 0; j < jSteps; j++) {
-            v3 jPos = v_fma(pSun, f_fma(jStepSize, 0.5f, jTime), iPos);
-            float jHeight = f_sqrt(v_dot(jPos, jPos)) - rPlanet;
-            jOdRlh = f_fma(pt_exp(jHeight * invShRlh), jStepSize, jOdRlh);
-            jOdMie = f_fma(pt_exp(jHeight * invShMie), jStepSize, jOdMie);
-            jTime += jStepSize;
-        }
-        float mieTerm = kMie * (iOdMie + jOdMie), rl = iOdRlh + jOdRlh;
-        v3 attn = V(pt_exp(-f_fma(kRlh.x, rl, mieTerm)), pt_exp(-f_fma(kRlh.y, rl, mieTerm)),
-                    pt_exp(-f_fma(kRlh.z, rl, mieTerm)));
-        totalRlh = v_fma(attn, odStepRlh, totalRlh);
-        totalMie = v_fma(attn, odStepMie, totalMie);
-        iTime += iStepSize;
-    }
-    float pm = pMie * kMie;
-    return V(iSun * f_fma(pRlh * kRlh.x, totalRlh.x, pm * totalMie.x),
-             iSun * f_fma(pRlh * kRlh.y, totalRlh.y, pm * totalMie.y),
-             iSun * f_fma(pRlh * kRlh.z, totalRlh.z, pm * totalMie.z));
-}
-
+// device functions: pt_atmosphere.hpp
 __global__ __launch_bounds__(256) void atmo_precompute_kernel(const AtmoArgs a)
 {
     const int S = a.size;

@@ -127,7 +127,7 @@ def _random_cameras(n, seed):
 ], ids=lambda v: str(v))
 def test_tile_pass_culling_is_conservative(pkg, native_lib, oracle, scene, size, aperture, focal):
     """The spp = 1 kernels run each tile's first bounce with the spheres culled against the tile's ray bundle
-    (cull_spheres, pt_kernels.hip).  A sphere removed by mistake would change pixels, so random cameras all over
+    (cull_spheres, pt_device.hpp).  A sphere removed by mistake would change pixels, so random cameras all over
     (and inside) the scene must still match the brute-force oracle bit for bit."""
     for k, (pos, look) in enumerate(_random_cameras(6, sum(map(ord, scene)) + size[0])):
         w = configs.Workload(f"cull_{scene}_{k}", scene, size[0], size[1], 6, "sky_f32_32", aperture=aperture,
