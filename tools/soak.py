@@ -1,5 +1,5 @@
 """Soak test of the frame pipelining (development helper): N consecutive frames at full size, sparse pixels compared
-bit for bit with the oracle's frame-by-frame accumulation.  python tools/soak.py [frames] [W H]"""
+bit for bit with the oracle's frame-by-frame accumulation.  python tools/soak.py [frames] [W H] [scene depth spp]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,9 +10,10 @@ pkg = g.load_package()
 oracle = g.load_oracle().Oracle()
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
-w = configs.Workload("soak", "default", W, H, 8, "sky_f32_32", frames=frames)
+scene, depth, spp = (sys.argv[4], int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else ("default", 8, 1)
+w = configs.Workload("soak", scene, W, H, depth, "sky_f32_32", frames=frames, spp=spp)
 sc, basic, objs, env, kw = configs.inputs(w)
-pt = pkg.PathTracer(env, W, H, w.ray_depth, 1, w.focal_length, w.aperture)
+pt = pkg.PathTracer(env, W, H, w.ray_depth, spp, w.focal_length, w.aperture)
 pt.UploadScene(sc); pt.UploadBasicData(basic)
 t = time.perf_counter()
 for _ in range(frames): pt.Render()
@@ -25,6 +26,6 @@ want = None
 for f in range(frames):
     want = oracle.render_pixels(W, H, basic, objs, env, xy, frame=f, last=want, **kw)
 same = (got[xy[:, 1], xy[:, 0]].view(np.uint32) == want.view(np.uint32)).all(-1)
-print(f"{frames} frames {W}x{H}: {dt / frames * 1e3:.4f} ms/frame, alpha==1: {(got[..., 3] == 1).all()}, "
+print(f"{frames} frames {W}x{H} {scene} depth {depth} spp {spp}: {dt / frames * 1e3:.4f} ms/frame, alpha==1: {(got[..., 3] == 1).all()}, "
       f"sparse pixels bit-identical to the oracle: {same.sum()}/{len(same)}")
 sys.exit(0 if same.all() and (got[..., 3] == 1).all() else 1)
