@@ -414,6 +414,29 @@ def test_bound_external_buffer_and_pitch(pkg, native_lib):
     assert np.array_equal(bits(pitched[:, :w.width]), bits(ref_img)) and (pitched[:, w.width:] == 0).all()
 
 
+def test_two_renderers_interleaved(pkg, native_lib, oracle):
+    """Two handles on one device, different scenes / sizes / parameters, frames interleaved call by call: handles share
+    no state (each has its own streams, queue counters, pending-frame list)."""
+    wa = configs.Workload("a", "default", 160, 90, 8, "sky_f32_32", frames=11)
+    wb = configs.Workload("b", "stress256", 96, 64, 5, "sky_srgb_32", frames=7, spp=2)
+    pts = []
+    for w in (wa, wb):
+        sc, basic, objs, env, kw = configs.inputs(w)
+        pt = pkg.PathTracer(env, w.width, w.height, w.ray_depth, w.spp, w.focal_length, w.aperture)
+        pt.UploadScene(sc)
+        pt.UploadBasicData(basic)
+        pts.append(pt)
+    for i in range(11):
+        pts[0].Render()
+        if i < 7:
+            pts[1].Render()
+    got = [pt.Result for pt in pts]
+    for pt in pts:
+        pt.Dispose()
+    assert_bit_exact(got[0], oracle_render(oracle, wa), "renderer A")
+    assert_bit_exact(got[1], oracle_render(oracle, wb), "renderer B")
+
+
 def test_error_codes(pkg, native_lib):
     N = pkg.native
     h = C.c_void_p()
