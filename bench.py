@@ -125,6 +125,9 @@ def main():
                     help="frames one launch may pipeline (pt_set_frame_batch; 1 = one launch per Render())")
     ap.add_argument("--clock-warmup-ms", type=float, default=80.0,
                     help="wall time of untimed rendering before the W warm-up steps (GPU clock ramp); 0 = none")
+    ap.add_argument("--strong-4k", action="store_true",
+                    help="BASELINE configs[3]: ONE 3840x2160 image row-tiled over the N GPUs (strong scaling) instead of the "
+                         "weak-scaling image that grows with N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: all ranks use cuda:0 and rendezvous over gloo (validates the N>1 logic on a 1-GPU box; "
@@ -155,7 +158,7 @@ def main():
     torch.cuda.set_device(local)
     import torch.distributed as dist
 
-    W, H = image_size(world)
+    W, H = (3840, 2160) if args.strong_4k else image_size(world)  # --strong-4k: BASELINE configs[3], one 4K image over N GPUs
     scene = {"default": pkg.scene.default_scene, "stress256": pkg.scene.stress_scene, "glass": pkg.scene.glass_scene}[args.scene]()
     cam = pkg.camera.Camera()
     basic = pkg.camera.basic_data_ubo(cam, W, H)
@@ -231,11 +234,11 @@ def main():
         kernel_ms = kernel_s_max * 1e3 / args.steps
         algo_bytes = ALGO_BYTES_PER_PIXEL_FRAME * W * rows  # per launch on one GPU (rank 0's row block)
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        wl_key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{args.spp}_{args.env}_g{world}" + (f"_variant{args.variant}" if args.variant else "") + (f"_fb{args.frame_batch}" if args.frame_batch != 64 else "")
+        wl_key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{args.spp}_{args.env}_g{world}" + (f"_variant{args.variant}" if args.variant else "") + (f"_fb{args.frame_batch}" if args.frame_batch != 64 else "") + ("_strong4k" if args.strong_4k else "")
         out = {
             "metric": "Msamples/sec + ms/frame @1080p 8-bounce default scene, 1/2/4/8 GPU",
             "value": round(samples / elapsed_max / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong" if args.strong_4k else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} scene ({scene.num_spheres} spheres + {scene.num_cuboids} cuboids), {W}x{H}, "
                                    f"{args.depth} bounces, {args.spp} spp, progressive accumulate, env {args.env}, "
