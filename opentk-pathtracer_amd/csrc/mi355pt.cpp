@@ -264,7 +264,7 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
 PT_API int pt_destroy(pt_handle h)
 {
     PT_CHECK_HANDLE(h);
-    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
+    h->pendingFrames = 0; // frames nobody can observe any more are not worth launching
     (void)hipSetDevice(h->device);
     for (int j = 0; j < pt_renderer::kMaxStripes; j++)
         if (h->stripeStream[j]) (void)hipStreamSynchronize(h->stripeStream[j]);
@@ -281,6 +281,7 @@ PT_API int pt_destroy(pt_handle h)
     if (h->dEnv) (void)hipFree(h->dEnv);
     if (h->dAccum) (void)hipFree(h->dAccum);
     if (h->dRgba8) (void)hipFree(h->dRgba8);
+    if (h->dTimeline) (void)hipFree(h->dTimeline);
     if (h->evBegin) (void)hipEventDestroy(h->evBegin);
     if (h->evEnd) (void)hipEventDestroy(h->evEnd);
     if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
