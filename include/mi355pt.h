@@ -14,10 +14,14 @@
  *     (or for the last failed pt_create when handle == NULL);
  *   - the host owns every source/destination array for the duration of the call only (as with
  *     GL.NamedBufferSubData, src/Render/Objects/BufferObject.cs:37-48); the library owns all device memory;
- *   - one handle = one renderer on one GPU, callable from one thread at a time (the reference calls
- *     everything from the GameWindow thread, src/MainWindow.cs:40,72,146).  Work is enqueued on the handle's
- *     HIP stream: pt_upload_*, pt_set_* and pt_render are stream-ordered; only pt_read_*, pt_synchronize,
+ *   - one handle = one renderer on one GPU (pt_create) or on a GROUP of GPUs (pt_create_multi: the image is
+ *     row-tiled across the devices inside the library and gathered over xGMI only when it is read or presented),
+ *     callable from one thread at a time (the reference calls everything from the GameWindow thread,
+ *     src/MainWindow.cs:40,72,146).  Work is enqueued on the handle's HIP stream: pt_upload_*, pt_set_* and
+ *     pt_render are stream-ordered; only pt_read_*, pt_present_rgba8, pt_present_wait, pt_synchronize,
  *     pt_timer_end and pt_destroy block;
+ *   - limits (PT_E_OUT_OF_RANGE beyond them): width, height <= PT_MAX_IMAGE_DIM; ray_depth <= PT_MAX_RAY_DEPTH;
+ *     spp <= PT_MAX_SPP (the reference GUI offers rayDepth 1..50 and SPP 1..10, src/Render/Gui.cs:40,48);
  *   - image rows: row 0 is the BOTTOM of the image (NDC y = -1), as in the GL image the reference writes
  *     (res/shaders/PathTracing/compute.glsl:104,114); pixels are RGBA32F, alpha = 1.
  */
@@ -57,6 +61,11 @@ enum { PT_ENV_RGBA32F = 0, PT_ENV_SRGB8_A8 = 1 };
 #define PT_ATMOSPHERE_UBO_SIZE 464      /* src/Render/AtmosphericScatterer.cs:72 ; AtmosphericScattering/compute.glsl:11-15 */
 #define PT_MAX_SPHERES 256
 #define PT_MAX_CUBOIDS 64
+#define PT_MAX_IMAGE_DIM 32767   /* pixel coordinates travel in 16-bit fields inside the kernels */
+#define PT_MAX_RAY_DEPTH 4095    /* bounce counters travel in 12-bit fields */
+#define PT_MAX_SPP 4095
+#define PT_MAX_GROUP_DEVICES 16
+#define PT_PRESENT_SLOTS 3       /* pinned host images of the non-blocking present path */
 
 /* ---- lifetime -------------------------------------------------------------------------------------------- */
 
@@ -65,6 +74,24 @@ enum { PT_ENV_RGBA32F = 0, PT_ENV_SRGB8_A8 = 1 };
  * (the reference leaves it undefined, src/Render/Objects/Texture.cs:169-197; frame 0 multiplies it by 0). */
 PT_API int pt_create(int device_id, int width, int height, pt_handle *out);
 PT_API int pt_destroy(pt_handle h);
+
+/* The same renderer on n_devices GPUs of this process (no reference counterpart, the reference
+ * owns one GL context): the image is tiled across device_ids[0..n) in block-cyclic bands of 16 rows (balanced: rows
+ * near the floor cost ~2x sky rows; pt_multi_set_partition changes the band height or selects contiguous row
+ * blocks), every device keeps its rows resident and renders them with global pixel coordinates, so the image is
+ * bit-identical to the single-GPU one.  Nothing is exchanged per frame.  Every entry point accepts the group handle:
+ * uploads / parameters / environment are replicated to all devices, pt_render enqueues on all of them, and
+ * pt_read_result / pt_present_rgba8 / pt_present_rgba8_async GATHER the rows on device_ids[0] with peer copies over
+ * xGMI (hipMemcpyPeerAsync; each peer has its own link to the root) before the single device-to-host copy.
+ * device_ids may name the same device more than once (used to test the group path on a one-GPU box).
+ * Not available on a group handle (PT_E_BAD_ARGUMENT): pt_set_tile, pt_set_interleaved_tile, pt_bind_result_buffer,
+ * pt_set_stream, pt_postprocess_device. */
+PT_API int pt_create_multi(const int *device_ids, int n_devices, int width, int height, pt_handle *out);
+/* band_rows = 0: contiguous row blocks (device g owns rows [g*H/G, (g+1)*H/G)); else a multiple of 8: block-cyclic
+ * bands of that many rows (default 16).  Resets the frame counter and zeroes, like pt_set_tile. */
+PT_API int pt_multi_set_partition(pt_handle h, int band_rows);
+/* Number of devices behind the handle (1 for pt_create handles). */
+PT_API int pt_device_count_of(pt_handle h, int *out_n_devices);
 
 /* PathTracer.SetSize — PathTracer.cs:131-135: frame counter = 0, image reallocated (and zeroed). The tile is
  * reset to the whole image. */
@@ -131,8 +158,23 @@ PT_API int pt_read_result(pt_handle h, float *dst_rgba32f, size_t row_pitch_byte
 PT_API int pt_present_rgba8(pt_handle h, uint8_t *dst_rgba8, size_t row_pitch_bytes);
 PT_API int pt_postprocess_device(pt_handle h, void **out_device_ptr, size_t *out_bytes);
 
+/* Non-blocking present for the reference's per-frame loop (src/MainWindow.cs:49-56: Render() -> PostProcesser.Render
+ * (PathTracer.Result) -> blit, every frame).  pt_present_rgba8_async snapshots the image as it is after the frames
+ * rendered so far: tone map (ACES + gamma, as pt_present_rgba8) into a device-side RGBA8 image of slot `slot`
+ * (0 <= slot < PT_PRESENT_SLOTS), stream-ordered behind those frames, then a device-to-host copy into the library-owned
+ * PINNED host image of that slot on a separate copy stream.  It returns at once; later pt_render calls only wait for
+ * the (microseconds-long) tone-map pass, so frame f+1 renders while frame f's 4 B/pixel cross PCIe.
+ * pt_present_wait blocks until the slot's copy has landed and returns the pinned image (tightly packed rows, row 0 =
+ * bottom, valid until the next pt_present_rgba8_async on the same slot or pt_set_size/pt_destroy) and the frame index
+ * (= number of accumulated frames) it shows.  Typical loop: render; present_async(f % 2); present_wait((f + 1) % 2) ->
+ * upload to the GL texture -> swap.  Works on group handles (the gather of the RGBA8 rows happens on the copy stream). */
+PT_API int pt_present_rgba8_async(pt_handle h, int slot);
+PT_API int pt_present_wait(pt_handle h, int slot, const uint8_t **out_host_rgba8, size_t *out_row_pitch_bytes,
+                           int *out_frame_index);
+
 /* Resume support (no reference counterpart; the reference discards accumulation on every event): replace the
- * accumulation image of this tile and set the frame counter. */
+ * accumulation image of this tile and set the frame counter.  Alpha is stored as 1 whatever the source holds (the
+ * reference always stores 1, compute.glsl:129; inside a pipelined launch the library uses alpha as a frame tag). */
 PT_API int pt_write_result(pt_handle h, const float *src_rgba32f, size_t row_pitch_bytes, int frame_index);
 
 PT_API int pt_get_frame_index(pt_handle h, int *out_frame_index);
@@ -158,9 +200,13 @@ PT_API int pt_read_environment(pt_handle h, float *dst_rgba32f, int *out_face_si
 /* Device pointer + byte size of this tile's accumulation image (for zero-copy wrapping, e.g. the RCCL gather at
  * present time in multi-GPU runs). */
 PT_API int pt_result_device_ptr(pt_handle h, void **out_device_ptr, size_t *out_bytes);
-/* Render into caller-owned device memory (>= rows*width*16 bytes) instead of the internal image; NULL restores. */
+/* Render into caller-owned device memory (>= rows*width*16 bytes) instead of the internal image; NULL restores.
+ * The buffer's RGB contents are taken as the accumulation so far (zero them for a fresh render: frame 0 multiplies
+ * them by 0, and 0 * NaN is NaN as in the reference); its alpha channel is set to 1 at bind time (stream-ordered). */
 PT_API int pt_bind_result_buffer(pt_handle h, void *device_ptr, size_t bytes);
-/* Use an existing hipStream_t (passed as void*) instead of the handle's own stream; NULL restores. */
+/* Use an existing hipStream_t (passed as void*) instead of the handle's own stream; NULL restores.  With a caller
+ * stream every pt_render is enqueued on THAT stream before it returns (one launch per frame, no deferral, no
+ * internal helper streams), so synchronising the stream is enough to observe the image. */
 PT_API int pt_set_stream(pt_handle h, void *hip_stream);
 /* hipEvent pair recorded on the handle's stream: elapsed GPU milliseconds between begin and end. */
 PT_API int pt_timer_begin(pt_handle h);

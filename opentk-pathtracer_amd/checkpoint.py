@@ -57,8 +57,8 @@ def read_checkpoint_file(path):
 def save_checkpoint(path, tracer) -> None:
     """Dump `tracer`'s tile (all of the image on one GPU) with everything needed to validate a later load."""
     write_checkpoint_file(path, tracer.Result, width=tracer.Width, height=tracer.Height, y0=tracer.y0, rows=tracer.rows,
-                          band_rows=getattr(tracer, "band_rows", 0), band_world=getattr(tracer, "band_world", 1),
-                          band_rank=getattr(tracer, "band_rank", 0), frame_index=tracer.FrameIndex,
+                          band_rows=tracer.band_rows, band_world=tracer.band_world, band_rank=tracer.band_rank,
+                          frame_index=tracer.FrameIndex,
                           ray_depth=tracer.RayDepth, spp=tracer.SPP, focal_length=tracer.FocalLength,
                           aperture=tracer.ApertureDiameter)
 
@@ -67,7 +67,11 @@ def load_checkpoint(path, tracer, strict: bool = True) -> dict:
     """Restore image + frame index into `tracer`.  The tile geometry must match; with `strict` the integrator parameters
     must match too (an image accumulated with other parameters is not a sample of the same estimator)."""
     hdr, img = read_checkpoint_file(path)
-    geo = dict(width=tracer.Width, height=tracer.Height, y0=tracer.y0, rows=tracer.rows)
+    # the whole tile geometry must match: under block-cyclic ownership every rank has y0 = 0 and often the same row
+    # count, so band height / world size / rank are what tell one rank's rows from another's
+    geo = dict(width=tracer.Width, height=tracer.Height, y0=tracer.y0, rows=tracer.rows, band_rows=tracer.band_rows)
+    if tracer.band_rows:
+        geo.update(band_world=tracer.band_world, band_rank=tracer.band_rank)
     for k, v in geo.items():
         if hdr[k] != v:
             raise CheckpointError(f"checkpoint {k} = {hdr[k]} but the renderer has {v}")

@@ -4,88 +4,19 @@
 // /root/reference/OpenTK-PathTracer/src/Render/PathTracer.cs:9-141, plus the two UBOs MainWindow owns,
 // src/MainWindow.cs:195-201) and the HIP plumbing around the kernels of pt_kernels.hip.
 // There is deliberately NO CPU fallback: without a HIP device every entry point fails with PT_E_NO_DEVICE.
-#include "../../include/mi355pt.h"
-
-#include <hip/hip_runtime.h>
+#include "pt_renderer.hpp"
 
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <new>
-#include <string>
-
-#include "pt_kernels.hpp"
 
 namespace {
-
 thread_local std::string g_create_error;
-
-struct HandleMagic {
-    static constexpr uint32_t kAlive = 0x4d335054u; // "M3PT"
-};
-
 } // namespace
 
-struct pt_renderer {
-    uint32_t magic = HandleMagic::kAlive;
-    int device = 0;
-    int width = 0, height = 0;
-    int y0 = 0, rows = 0;
-    int bandRows = 0, bandWorld = 1, bandRank = 0; // block-cyclic row ownership (pt_set_interleaved_tile)
-    int numSpheres = 0, numCuboids = 0, rayDepth = 1, spp = 1;
-    float focalLength = 0.0f, apertureDiameter = 0.0f;
-    int frame = 0; // thisRenderNumFrame, PathTracer.cs:113
-    int variant = 0;
-
-    unsigned char basic[PT_BASIC_DATA_UBO_SIZE] = {0};      // host shadow of UBO 0 (travels as kernel argument)
-    unsigned char atmoUbo[PT_ATMOSPHERE_UBO_SIZE] = {0};    // host shadow of UBO 2
-
-    float *dObjects = nullptr; // 26,624 B device copy of UBO 1
-    float *dLut = nullptr;     // 256-entry sRGB table
-    unsigned int *dQueue = nullptr; // global chunk-ticket counter of the persistent kernel (never reset: epoch scheme)
-    int queueChunk = 8;             // tiles per global ticket (PT_QUEUE_CHUNK overrides, for tuning runs)
-    unsigned long long *dTimeline = nullptr; // tuning only (pt_debug_timeline)
-    // Frame pipelining: consecutive pt_render calls are collected and launched as ONE batch kernel (see pt_kernels.hip)
-    // when nothing observable happens in between; every other entry point launches what is pending first.
-    int pendingFrames = 0;          // frames accepted by pt_render, not launched yet
-    int maxBatch = 64;              // PT_FRAME_BATCH=1 turns batching off (every pt_render launches at once)
-    int batchWorkgroupsPerCU = 6;   // grid of the batch kernel (PT_BATCH_WG, tuning)
-    bool batchLaunched = false;     // a batch kernel ran since the last error-word check
-    hipEvent_t mainDone = nullptr;  // recorded behind the last integrator launch on the main stream
-    bool mainInFlight = false;      // ... and not yet seen complete
-    bool stripeInFlight[4] = {false, false, false, false}; // same for the stripe streams (stripeDone events)
-    int drainCompaction = -1;       // donate threshold in live paths (<= 32), 0 = off, -1 = auto (see pt_render); env PT_DRAIN_COMPACTION
-    int numCUs = 256;
-    void *dEnv = nullptr;      // current environment cube
-    size_t envBytes = 0;
-    int envSize = 0, envFormat = PT_ENV_RGBA32F;
-
-    float4 *dAccum = nullptr;  // internal accumulation image (rows x width)
-    size_t accumCapacity = 0;  // in pixels
-    float4 *boundAccum = nullptr; // caller-owned target (pt_bind_result_buffer)
-    void *dRgba8 = nullptr;    // post-processed RGBA8 image of the tile (pt_present_rgba8)
-    size_t rgba8Capacity = 0;  // in pixels
-    size_t boundBytes = 0;
-
-    hipStream_t ownStream = nullptr, stream = nullptr;
-    // Stripes: one frame = `stripes` persistent kernels over contiguous row ranges of the tile, each on its own
-    // stream, so that one stripe's frame-end drain overlaps the other stripe's main phase.
-    static constexpr int kMaxStripes = 4;
-    hipStream_t stripeStream[kMaxStripes] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t stripeDone[kMaxStripes] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t inputsReady = nullptr;
-    bool stripePending[kMaxStripes] = {false, false, false, false};
-    unsigned int stripeQueueBase[kMaxStripes] = {0, 0, 0, 0};
-    hipEvent_t evBegin = nullptr, evEnd = nullptr;
-    std::string error;
-
-    float4 *accum() const { return boundAccum ? boundAccum : dAccum; }
-    size_t tilePixels() const { return (size_t)rows * (size_t)width; }
-};
-
-namespace {
+namespace ptimpl {
 
 int fail(pt_handle h, int code, const std::string &msg)
 {
@@ -100,22 +31,21 @@ int hip_fail(pt_handle h, hipError_t e, const char *what)
                 std::string(what) + ": " + hipGetErrorString(e));
 }
 
-#define PT_CHECK_HANDLE(h)                                                                                             \
-    do {                                                                                                               \
-        if (!(h) || (h)->magic != HandleMagic::kAlive) return fail(nullptr, PT_E_BAD_HANDLE, "bad handle");           \
-    } while (0)
-
-#define PT_HIP(h, call)                                                                                                \
-    do {                                                                                                               \
-        hipError_t e_ = (call);                                                                                        \
-        if (e_ != hipSuccess) return hip_fail((h), e_, #call);                                                         \
-    } while (0)
-
 int bind_device(pt_handle h)
 {
     PT_HIP(h, hipSetDevice(h->device));
     return PT_OK;
 }
+
+} // namespace ptimpl
+
+using ptimpl::bind_device;
+using ptimpl::fail;
+using ptimpl::flush_frames;
+using ptimpl::hip_fail;
+using ptimpl::join_stripes;
+
+namespace {
 
 // GL 4.5 section 8.24 sRGB decode, evaluated in double and rounded once (same table as the oracle's).
 void make_srgb_lut(float *lut)
@@ -127,15 +57,16 @@ void make_srgb_lut(float *lut)
     }
 }
 
-// Make the main stream wait for every stripe kernel still in flight (before anything that reads their output or
-// overwrites their inputs).
-int flush_frames(pt_handle h);
+} // namespace
 
+namespace ptimpl {
+// Launch what pt_render deferred, then make the main stream wait for every stripe kernel still in flight (before
+// anything that reads their output or overwrites their inputs).
 int join_stripes(pt_handle h)
 {
     if (h->pendingFrames > 0)
         if (int rc = flush_frames(h)) return rc;
-    for (int j = 0; j < pt_renderer::kMaxStripes; j++) {
+    for (int j = 0; j < kMaxStripes; j++) {
         if (h->stripePending[j]) {
             PT_HIP(h, hipStreamWaitEvent(h->stream, h->stripeDone[j], 0));
             h->stripePending[j] = false;
@@ -143,6 +74,23 @@ int join_stripes(pt_handle h)
     }
     return PT_OK;
 }
+
+// Frame pipelining: did any resolve give up waiting for its pixel's previous frame?  Call with h->stream synchronised.
+int check_handover(pt_handle h)
+{
+    if (!h->batchLaunched) return PT_OK;
+    unsigned int err = 0;
+    PT_HIP(h, hipMemcpy(&err, h->dQueue + 1, sizeof(err), hipMemcpyDeviceToHost));
+    h->batchLaunched = false;
+    if (err) {
+        PT_HIP(h, hipMemset(h->dQueue + 1, 0, sizeof(err)));
+        return fail(h, PT_E_HIP, "frame pipelining: a pixel's previous frame never arrived (result is not trustworthy)");
+    }
+    return PT_OK;
+}
+} // namespace ptimpl
+
+namespace {
 
 int ensure_accum(pt_handle h)
 {
@@ -181,7 +129,7 @@ PT_API int pt_device_count(void)
 
 PT_API const char *pt_last_error(pt_handle h)
 {
-    if (h && h->magic == HandleMagic::kAlive) return h->error.c_str();
+    if (h && h->magic == ptimpl::kAlive) return h->error.c_str();
     return g_create_error.c_str();
 }
 
@@ -190,6 +138,8 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     if (!out) return fail(nullptr, PT_E_BAD_ARGUMENT, "out == NULL");
     *out = nullptr;
     if (width <= 0 || height <= 0) return fail(nullptr, PT_E_BAD_ARGUMENT, "width/height must be positive");
+    if (width > PT_MAX_IMAGE_DIM || height > PT_MAX_IMAGE_DIM)
+        return fail(nullptr, PT_E_OUT_OF_RANGE, "width/height exceed PT_MAX_IMAGE_DIM (32767)");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -227,12 +177,14 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     PT_CREATE_HIP(hipSetDevice(device_id));
     PT_CREATE_HIP(hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking));
     h->stream = h->ownStream;
-    for (int j = 0; j < pt_renderer::kMaxStripes; j++) {
+    for (int j = 0; j < ptimpl::kMaxStripes; j++) {
         PT_CREATE_HIP(hipStreamCreateWithFlags(&h->stripeStream[j], hipStreamNonBlocking));
         PT_CREATE_HIP(hipEventCreateWithFlags(&h->stripeDone[j], hipEventDisableTiming));
     }
     PT_CREATE_HIP(hipEventCreateWithFlags(&h->inputsReady, hipEventDisableTiming));
     PT_CREATE_HIP(hipEventCreateWithFlags(&h->mainDone, hipEventDisableTiming));
+    PT_CREATE_HIP(hipEventCreateWithFlags(&h->gatherReady, hipEventDisableTiming));
+    PT_CREATE_HIP(hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking));
     PT_CREATE_HIP(hipEventCreate(&h->evBegin));
     PT_CREATE_HIP(hipEventCreate(&h->evEnd));
     PT_CREATE_HIP(hipMalloc((void **)&h->dObjects, PT_GAME_OBJECTS_UBO_SIZE));
@@ -264,12 +216,17 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
 PT_API int pt_destroy(pt_handle h)
 {
     PT_CHECK_HANDLE(h);
+    if (h->isGroup()) return ptimpl::group_destroy(h);
     h->pendingFrames = 0; // frames nobody can observe any more are not worth launching
     (void)hipSetDevice(h->device);
-    for (int j = 0; j < pt_renderer::kMaxStripes; j++)
+    if (h->copyStream) (void)hipStreamSynchronize(h->copyStream);
+    ptimpl::free_slots(h);
+    if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
+    if (h->gatherReady) (void)hipEventDestroy(h->gatherReady);
+    for (int j = 0; j < ptimpl::kMaxStripes; j++)
         if (h->stripeStream[j]) (void)hipStreamSynchronize(h->stripeStream[j]);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (int j = 0; j < pt_renderer::kMaxStripes; j++) {
+    for (int j = 0; j < ptimpl::kMaxStripes; j++) {
         if (h->stripeDone[j]) (void)hipEventDestroy(h->stripeDone[j]);
         if (h->stripeStream[j]) (void)hipStreamDestroy(h->stripeStream[j]);
     }
@@ -293,8 +250,11 @@ PT_API int pt_destroy(pt_handle h)
 PT_API int pt_set_size(pt_handle h, int width, int height)
 {
     PT_CHECK_HANDLE(h);
-    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (width <= 0 || height <= 0) return fail(h, PT_E_BAD_ARGUMENT, "width/height must be positive");
+    if (width > PT_MAX_IMAGE_DIM || height > PT_MAX_IMAGE_DIM)
+        return fail(h, PT_E_OUT_OF_RANGE, "width/height exceed PT_MAX_IMAGE_DIM (32767)");
+    if (h->isGroup()) return ptimpl::group_set_size(h, width, height);
+    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (int rc = bind_device(h)) return rc;
     h->width = width;
     h->height = height;
@@ -309,6 +269,7 @@ PT_API int pt_set_size(pt_handle h, int width, int height)
 PT_API int pt_set_tile(pt_handle h, int y0, int rows)
 {
     PT_CHECK_HANDLE(h);
+    if (h->isGroup()) return fail(h, PT_E_BAD_ARGUMENT, "a group handle owns its tiling (pt_multi_set_partition)");
     if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (y0 < 0 || rows <= 0 || y0 + rows > h->height) return fail(h, PT_E_BAD_ARGUMENT, "tile outside the image");
     if (int rc = bind_device(h)) return rc;
@@ -323,6 +284,7 @@ PT_API int pt_set_tile(pt_handle h, int y0, int rows)
 PT_API int pt_set_interleaved_tile(pt_handle h, int rank, int world, int band_rows)
 {
     PT_CHECK_HANDLE(h);
+    if (h->isGroup()) return fail(h, PT_E_BAD_ARGUMENT, "a group handle owns its tiling (pt_multi_set_partition)");
     if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (world < 1 || rank < 0 || rank >= world || band_rows < 8 || (band_rows & 7))
         return fail(h, PT_E_BAD_ARGUMENT, "need 0 <= rank < world and band_rows a positive multiple of 8");
@@ -344,9 +306,22 @@ PT_API int pt_set_interleaved_tile(pt_handle h, int rank, int world, int band_ro
     return clear_accum(h);
 }
 
+// group handles: replicate a call to every part; the first failure is reported on the group handle
+#define PT_FAN_OUT(h, call)                                                                                            \
+    do {                                                                                                               \
+        if ((h)->isGroup()) {                                                                                          \
+            for (pt_handle part : (h)->parts) {                                                                        \
+                int rc_ = (call);                                                                                      \
+                if (rc_ != PT_OK) return fail((h), rc_, part->error);                                                  \
+            }                                                                                                          \
+            return PT_OK;                                                                                              \
+        }                                                                                                              \
+    } while (0)
+
 PT_API int pt_reset(pt_handle h)
 {
     PT_CHECK_HANDLE(h);
+    PT_FAN_OUT(h, pt_reset(part));
     if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     h->frame = 0; // PathTracer.cs:139 — frame 0 weights the old contents by 0, so no clear is needed
     return PT_OK;
@@ -356,10 +331,14 @@ PT_API int pt_set_params(pt_handle h, int num_spheres, int num_cuboids, int ray_
                          float aperture_diameter)
 {
     PT_CHECK_HANDLE(h);
+    PT_FAN_OUT(h, pt_set_params(part, num_spheres, num_cuboids, ray_depth, spp, focal_length, aperture_diameter));
     if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (num_spheres < 0 || num_spheres > PT_MAX_SPHERES || num_cuboids < 0 || num_cuboids > PT_MAX_CUBOIDS)
         return fail(h, PT_E_OUT_OF_RANGE, "object counts exceed the GameObjectsUBO arrays (256 spheres / 64 cuboids)");
     if (ray_depth < 0 || spp < 1) return fail(h, PT_E_BAD_ARGUMENT, "ray_depth must be >= 0 and spp >= 1");
+    // the kernels carry bounce / sample counters in 12-bit fields of their path records
+    if (ray_depth > PT_MAX_RAY_DEPTH || spp > PT_MAX_SPP)
+        return fail(h, PT_E_OUT_OF_RANGE, "ray_depth / spp exceed PT_MAX_RAY_DEPTH / PT_MAX_SPP (4095)");
     h->numSpheres = num_spheres;
     h->numCuboids = num_cuboids;
     h->rayDepth = ray_depth;
@@ -372,6 +351,7 @@ PT_API int pt_set_params(pt_handle h, int num_spheres, int num_cuboids, int ray_
 PT_API int pt_upload_basic_data(pt_handle h, int byte_offset, int size, const void *src)
 {
     PT_CHECK_HANDLE(h);
+    PT_FAN_OUT(h, pt_upload_basic_data(part, byte_offset, size, src));
     if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (!src) return fail(h, PT_E_BAD_ARGUMENT, "src == NULL");
     if (byte_offset < 0 || size < 0 || (long long)byte_offset + size > PT_BASIC_DATA_UBO_SIZE)
@@ -383,6 +363,7 @@ PT_API int pt_upload_basic_data(pt_handle h, int byte_offset, int size, const vo
 PT_API int pt_upload_game_objects(pt_handle h, int byte_offset, int size, const void *src)
 {
     PT_CHECK_HANDLE(h);
+    PT_FAN_OUT(h, pt_upload_game_objects(part, byte_offset, size, src));
     if (!src) return fail(h, PT_E_BAD_ARGUMENT, "src == NULL");
     if (byte_offset < 0 || size < 0 || (long long)byte_offset + size > PT_GAME_OBJECTS_UBO_SIZE)
         return fail(h, PT_E_OUT_OF_RANGE, "GameObjectsUBO range outside [0,26624)");
@@ -397,6 +378,7 @@ PT_API int pt_upload_game_objects(pt_handle h, int byte_offset, int size, const 
 PT_API int pt_set_environment(pt_handle h, int face_size, int format, const void *const faces[6])
 {
     PT_CHECK_HANDLE(h);
+    PT_FAN_OUT(h, pt_set_environment(part, face_size, format, faces));
     if (face_size <= 0 || face_size > 16384) return fail(h, PT_E_BAD_ARGUMENT, "face_size out of range");
     if (format != PT_ENV_RGBA32F && format != PT_ENV_SRGB8_A8) return fail(h, PT_E_BAD_ARGUMENT, "unknown format");
     if (!faces) return fail(h, PT_E_BAD_ARGUMENT, "faces == NULL");
@@ -462,6 +444,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     // stripes of the persistent kernel with k+1 workgroups per CU; everything else = one kernel on the main stream
     int stripes = 1, kernelVariant = h->variant;
     if (h->variant == 0 && n > 1) { stripes = 1; kernelVariant = 10 + h->batchWorkgroupsPerCU - 1; h->batchLaunched = true; }
+    else if (h->variant == 0 && h->externalStream()) { stripes = 1; kernelVariant = 14; } // everything ON the caller's stream
     else if (h->variant == 0) { stripes = 2; kernelVariant = 14; }
     else if (h->variant >= 20 && h->variant < 50) { stripes = h->variant / 10; kernelVariant = 10 + h->variant % 10; }
     if (h->rows < 16 * stripes) stripes = 1; // tiny tiles: not worth splitting
@@ -520,13 +503,33 @@ bool gpu_busy(pt_handle h)
         if (hipEventQuery(h->mainDone) == hipErrorNotReady) busy = true;
         else h->mainInFlight = false;
     }
-    for (int j = 0; j < pt_renderer::kMaxStripes; j++) {
+    for (int j = 0; j < ptimpl::kMaxStripes; j++) {
         if (!h->stripeInFlight[j]) continue;
         if (hipEventQuery(h->stripeDone[j]) == hipErrorNotReady) busy = true;
         else h->stripeInFlight[j] = false;
     }
     return busy;
 }
+
+int ensure_rgba8(pt_handle h)
+{
+    size_t need = h->tilePixels();
+    if (need > h->rgba8Capacity) {
+        if (h->dRgba8) {
+            PT_HIP(h, hipStreamSynchronize(h->stream));
+            PT_HIP(h, hipFree(h->dRgba8));
+        }
+        h->dRgba8 = nullptr;
+        h->rgba8Capacity = 0;
+        PT_HIP(h, hipMalloc(&h->dRgba8, need * 4));
+        h->rgba8Capacity = need;
+    }
+    return PT_OK;
+}
+
+} // namespace
+
+namespace ptimpl {
 
 int flush_frames(pt_handle h)
 {
@@ -536,18 +539,92 @@ int flush_frames(pt_handle h)
     return launch_frames(h, h->frame - n, n);
 }
 
-} // namespace
+// PostProcessing/fragment.glsl:17-26 over this handle's rows into `dst`, ordered behind every frame rendered so far
+int tone_map_into(pt_handle h, void *dst)
+{
+    if (int rc = join_stripes(h)) return rc;
+    PT_HIP(h, pt::launch_postprocess(h->accum(), dst, h->tilePixels(), h->stream));
+    return PT_OK;
+}
+
+int ensure_slot_events(pt_handle h, int slot)
+{
+    PresentSlot &s = h->slots[slot];
+    if (!s.toneMapped) PT_HIP(h, hipEventCreateWithFlags(&s.toneMapped, hipEventDisableTiming));
+    if (!s.copied) PT_HIP(h, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+    return PT_OK;
+}
+
+int ensure_slot_device(pt_handle h, int slot, size_t pixels)
+{
+    PresentSlot &s = h->slots[slot];
+    if (pixels > s.devPixels) {
+        if (s.dRgba8) {
+            if (s.copied && s.inFlight) PT_HIP(h, hipEventSynchronize(s.copied)); // a copy may still read the old buffer
+            PT_HIP(h, hipStreamSynchronize(h->stream));
+            PT_HIP(h, hipFree(s.dRgba8));
+        }
+        s.dRgba8 = nullptr;
+        s.devPixels = 0;
+        PT_HIP(h, hipMalloc(&s.dRgba8, pixels * 4));
+        s.devPixels = pixels;
+    }
+    return PT_OK;
+}
+
+int ensure_slot_host(pt_handle h, int slot, size_t pixels)
+{
+    PresentSlot &s = h->slots[slot];
+    if (!s.hostErr) PT_HIP(h, hipHostMalloc((void **)&s.hostErr, sizeof(unsigned int), hipHostMallocDefault));
+    if (pixels > s.hostPixels) {
+        if (s.host) {
+            if (s.copied && s.inFlight) PT_HIP(h, hipEventSynchronize(s.copied));
+            PT_HIP(h, hipHostFree(s.host));
+        }
+        s.host = nullptr;
+        s.hostPixels = 0;
+        s.valid = false;
+        PT_HIP(h, hipHostMalloc((void **)&s.host, pixels * 4, hipHostMallocDefault));
+        s.hostPixels = pixels;
+    }
+    return PT_OK;
+}
+
+void free_slots(pt_handle h)
+{
+    for (PresentSlot &s : h->slots) {
+        if (s.dRgba8) (void)hipFree(s.dRgba8);
+        if (s.host) (void)hipHostFree(s.host);
+        if (s.hostErr) (void)hipHostFree(s.hostErr);
+        if (s.toneMapped) (void)hipEventDestroy(s.toneMapped);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        s = PresentSlot();
+    }
+}
+
+} // namespace ptimpl
 
 extern "C" {
 
 PT_API int pt_render(pt_handle h, int *out_total_samples)
 {
     PT_CHECK_HANDLE(h);
+    if (h->isGroup()) {
+        int total = 0;
+        for (pt_handle part : h->parts) {
+            int rc = pt_render(part, &total);
+            if (rc != PT_OK) return fail(h, rc, part->error);
+        }
+        h->frame = h->parts[0]->frame;
+        if (out_total_samples) *out_total_samples = total;
+        return PT_OK;
+    }
     if (!h->dEnv) return fail(h, PT_E_NO_ENVIRONMENT, "pt_render called before pt_set_environment / pt_atmosphere_render");
     if (h->boundAccum && h->boundBytes < h->tilePixels() * sizeof(float4))
         return fail(h, PT_E_BAD_ARGUMENT, "bound result buffer is smaller than the tile");
-    // Only the default kernel pipelines frames; the A/B variants launch at once.
-    const bool batchable = h->variant == 0 && h->maxBatch > 1 && h->dTimeline == nullptr;
+    // Only the default kernel pipelines frames; the A/B variants launch at once.  On a caller-owned stream nothing is
+    // deferred: the contract there is that the frame is enqueued on that stream when pt_render returns.
+    const bool batchable = h->variant == 0 && h->maxBatch > 1 && h->dTimeline == nullptr && !h->externalStream();
     h->pendingFrames++;
     h->frame++; // PathTracer.cs:117 post-increment
     if (out_total_samples) *out_total_samples = h->frame * h->spp; // PathTracer.cs:112
@@ -564,12 +641,13 @@ PT_API int pt_read_result(pt_handle h, float *dst, size_t row_pitch_bytes)
     size_t rowBytes = (size_t)h->width * 16;
     if (row_pitch_bytes == 0) row_pitch_bytes = rowBytes;
     if (row_pitch_bytes < rowBytes) return fail(h, PT_E_BAD_ARGUMENT, "row pitch smaller than a row");
+    if (h->isGroup()) return ptimpl::group_read_result(h, dst, row_pitch_bytes);
     if (int rc = bind_device(h)) return rc;
     if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, hipMemcpy2DAsync(dst, row_pitch_bytes, h->accum(), rowBytes, rowBytes, (size_t)h->rows,
                                hipMemcpyDeviceToHost, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
-    return PT_OK;
+    return ptimpl::check_handover(h);
 }
 
 PT_API int pt_write_result(pt_handle h, const float *src, size_t row_pitch_bytes, int frame_index)
@@ -579,31 +657,18 @@ PT_API int pt_write_result(pt_handle h, const float *src, size_t row_pitch_bytes
     size_t rowBytes = (size_t)h->width * 16;
     if (row_pitch_bytes == 0) row_pitch_bytes = rowBytes;
     if (row_pitch_bytes < rowBytes) return fail(h, PT_E_BAD_ARGUMENT, "row pitch smaller than a row");
+    if (h->isGroup()) return ptimpl::group_write_result(h, src, row_pitch_bytes, frame_index);
     if (int rc = bind_device(h)) return rc;
     if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, hipMemcpy2DAsync(h->accum(), rowBytes, src, row_pitch_bytes, rowBytes, (size_t)h->rows,
                                hipMemcpyHostToDevice, h->stream));
+    // alpha is the reference's constant 1 (compute.glsl:129) whatever the file held: inside a pipelined launch alpha
+    // carries the frame tag, so a restored 2.0 must never reach the kernel
+    PT_HIP(h, pt::launch_set_alpha(h->accum(), h->tilePixels(), h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     h->frame = frame_index;
     return PT_OK;
 }
-
-namespace {
-int run_postprocess(pt_handle h)
-{
-    size_t need = h->tilePixels();
-    if (need > h->rgba8Capacity) {
-        if (h->dRgba8) PT_HIP(h, hipFree(h->dRgba8));
-        h->dRgba8 = nullptr;
-        h->rgba8Capacity = 0;
-        PT_HIP(h, hipMalloc(&h->dRgba8, need * 4));
-        h->rgba8Capacity = need;
-    }
-    if (int rc = join_stripes(h)) return rc;
-    PT_HIP(h, pt::launch_postprocess(h->accum(), h->dRgba8, need, h->stream));
-    return PT_OK;
-}
-} // namespace
 
 PT_API int pt_present_rgba8(pt_handle h, uint8_t *dst, size_t row_pitch_bytes)
 {
@@ -612,21 +677,77 @@ PT_API int pt_present_rgba8(pt_handle h, uint8_t *dst, size_t row_pitch_bytes)
     size_t rowBytes = (size_t)h->width * 4;
     if (row_pitch_bytes == 0) row_pitch_bytes = rowBytes;
     if (row_pitch_bytes < rowBytes) return fail(h, PT_E_BAD_ARGUMENT, "row pitch smaller than a row");
+    if (h->isGroup()) return ptimpl::group_present_rgba8(h, dst, row_pitch_bytes);
     if (int rc = bind_device(h)) return rc;
-    if (int rc = run_postprocess(h)) return rc;
+    if (int rc = ensure_rgba8(h)) return rc;
+    if (int rc = ptimpl::tone_map_into(h, h->dRgba8)) return rc;
     PT_HIP(h, hipMemcpy2DAsync(dst, row_pitch_bytes, h->dRgba8, rowBytes, rowBytes, (size_t)h->rows, hipMemcpyDeviceToHost,
                                h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
-    return PT_OK;
+    return ptimpl::check_handover(h);
 }
 
 PT_API int pt_postprocess_device(pt_handle h, void **out_device_ptr, size_t *out_bytes)
 {
     PT_CHECK_HANDLE(h);
+    if (h->isGroup()) return fail(h, PT_E_BAD_ARGUMENT, "pt_postprocess_device is not available on a group handle");
     if (int rc = bind_device(h)) return rc;
-    if (int rc = run_postprocess(h)) return rc;
+    if (int rc = ensure_rgba8(h)) return rc;
+    if (int rc = ptimpl::tone_map_into(h, h->dRgba8)) return rc;
     if (out_device_ptr) *out_device_ptr = h->dRgba8;
     if (out_bytes) *out_bytes = h->tilePixels() * 4;
+    return PT_OK;
+}
+
+PT_API int pt_present_rgba8_async(pt_handle h, int slot)
+{
+    PT_CHECK_HANDLE(h);
+    if (slot < 0 || slot >= PT_PRESENT_SLOTS) return fail(h, PT_E_BAD_ARGUMENT, "slot must be 0..PT_PRESENT_SLOTS-1");
+    if (h->isGroup()) return ptimpl::group_present_async(h, slot);
+    if (int rc = bind_device(h)) return rc;
+    ptimpl::PresentSlot &s = h->slots[slot];
+    const size_t pixels = h->tilePixels();
+    if (int rc = ptimpl::ensure_slot_events(h, slot)) return rc;
+    if (int rc = ptimpl::ensure_slot_device(h, slot, pixels)) return rc;
+    if (int rc = ptimpl::ensure_slot_host(h, slot, pixels)) return rc;
+    if (int rc = join_stripes(h)) return rc;
+    // the slot's previous copy must have left the device image before it is overwritten (device-side wait only)
+    if (s.inFlight) PT_HIP(h, hipStreamWaitEvent(h->stream, s.copied, 0));
+    PT_HIP(h, pt::launch_postprocess(h->accum(), s.dRgba8, pixels, h->stream));
+    PT_HIP(h, hipEventRecord(s.toneMapped, h->stream));
+    // later frames only wait for the tone-map pass (stream order); the PCIe copy runs beside them on the copy stream
+    PT_HIP(h, hipStreamWaitEvent(h->copyStream, s.toneMapped, 0));
+    PT_HIP(h, hipMemcpyAsync(s.host, s.dRgba8, pixels * 4, hipMemcpyDeviceToHost, h->copyStream));
+    PT_HIP(h, hipMemcpyAsync(s.hostErr, h->dQueue + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, h->copyStream));
+    PT_HIP(h, hipEventRecord(s.copied, h->copyStream));
+    s.inFlight = true;
+    s.valid = false;
+    s.frame = h->frame;
+    s.rows = h->rows;
+    s.width = h->width;
+    return PT_OK;
+}
+
+PT_API int pt_present_wait(pt_handle h, int slot, const uint8_t **out_host_rgba8, size_t *out_row_pitch_bytes,
+                           int *out_frame_index)
+{
+    PT_CHECK_HANDLE(h);
+    if (slot < 0 || slot >= PT_PRESENT_SLOTS) return fail(h, PT_E_BAD_ARGUMENT, "slot must be 0..PT_PRESENT_SLOTS-1");
+    ptimpl::PresentSlot &s = h->slots[slot];
+    if (!s.inFlight && !s.valid) return fail(h, PT_E_BAD_ARGUMENT, "nothing was presented into this slot");
+    if (int rc = bind_device(h)) return rc;
+    if (s.inFlight) {
+        PT_HIP(h, hipEventSynchronize(s.copied));
+        s.inFlight = false;
+        s.valid = true;
+        if (s.hostErr && *s.hostErr) {
+            *s.hostErr = 0;
+            return fail(h, PT_E_HIP, "frame pipelining: a pixel's previous frame never arrived (result is not trustworthy)");
+        }
+    }
+    if (out_host_rgba8) *out_host_rgba8 = s.host;
+    if (out_row_pitch_bytes) *out_row_pitch_bytes = (size_t)s.width * 4;
+    if (out_frame_index) *out_frame_index = s.frame;
     return PT_OK;
 }
 
@@ -634,31 +755,24 @@ PT_API int pt_get_frame_index(pt_handle h, int *out)
 {
     PT_CHECK_HANDLE(h);
     if (!out) return fail(h, PT_E_BAD_ARGUMENT, "out == NULL");
-    *out = h->frame;
+    *out = h->isGroup() ? h->parts[0]->frame : h->frame;
     return PT_OK;
 }
 
 PT_API int pt_synchronize(pt_handle h)
 {
     PT_CHECK_HANDLE(h);
+    PT_FAN_OUT(h, pt_synchronize(part));
     if (int rc = bind_device(h)) return rc;
     if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, hipStreamSynchronize(h->stream));
-    if (h->batchLaunched) { // frame pipelining: did any resolve give up waiting for its pixel's previous frame?
-        unsigned int err = 0;
-        PT_HIP(h, hipMemcpy(&err, h->dQueue + 1, sizeof(err), hipMemcpyDeviceToHost));
-        h->batchLaunched = false;
-        if (err) {
-            PT_HIP(h, hipMemset(h->dQueue + 1, 0, sizeof(err)));
-            return fail(h, PT_E_HIP, "frame pipelining: a pixel's previous frame never arrived (result is not trustworthy)");
-        }
-    }
-    return PT_OK;
+    return ptimpl::check_handover(h);
 }
 
 PT_API int pt_atmosphere_upload_data(pt_handle h, int byte_offset, int size, const void *src)
 {
     PT_CHECK_HANDLE(h);
+    PT_FAN_OUT(h, pt_atmosphere_upload_data(part, byte_offset, size, src));
     if (!src) return fail(h, PT_E_BAD_ARGUMENT, "src == NULL");
     if (byte_offset < 0 || size < 0 || (long long)byte_offset + size > PT_ATMOSPHERE_UBO_SIZE)
         return fail(h, PT_E_OUT_OF_RANGE, "AtmosphericDataUBO range outside [0,464)");
@@ -670,6 +784,8 @@ PT_API int pt_atmosphere_render(pt_handle h, int size, int i_steps, int j_steps,
                                 float light_intensity)
 {
     PT_CHECK_HANDLE(h);
+    // every device of a group computes its own copy of the cube (deterministic kernel: the copies are identical)
+    PT_FAN_OUT(h, pt_atmosphere_render(part, size, i_steps, j_steps, light_pos, light_intensity));
     if (size <= 0 || size > 8192 || i_steps < 0 || j_steps < 0 || !light_pos)
         return fail(h, PT_E_BAD_ARGUMENT, "bad atmosphere parameters");
     if (int rc = bind_device(h)) return rc;
@@ -703,6 +819,10 @@ PT_API int pt_atmosphere_render(pt_handle h, int size, int i_steps, int j_steps,
 PT_API int pt_read_environment(pt_handle h, float *dst, int *out_face_size)
 {
     PT_CHECK_HANDLE(h);
+    if (h->isGroup()) {
+        int rc = pt_read_environment(h->parts[0], dst, out_face_size);
+        return rc == PT_OK ? rc : fail(h, rc, h->parts[0]->error);
+    }
     if (!h->dEnv) return fail(h, PT_E_NO_ENVIRONMENT, "no environment set");
     if (out_face_size) *out_face_size = h->envSize;
     if (!dst) return PT_OK; // size query
@@ -727,6 +847,11 @@ PT_API int pt_read_environment(pt_handle h, float *dst, int *out_face_size)
 PT_API int pt_result_device_ptr(pt_handle h, void **out_ptr, size_t *out_bytes)
 {
     PT_CHECK_HANDLE(h);
+    if (h->isGroup()) return ptimpl::group_result_device_ptr(h, out_ptr, out_bytes);
+    // whatever pt_render deferred is launched and joined into the handle's stream first: work the caller orders behind
+    // that stream (or behind pt_synchronize) then sees every frame rendered so far
+    if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc;
     if (out_ptr) *out_ptr = h->accum();
     if (out_bytes) *out_bytes = h->tilePixels() * sizeof(float4);
     return PT_OK;
@@ -735,18 +860,22 @@ PT_API int pt_result_device_ptr(pt_handle h, void **out_ptr, size_t *out_bytes)
 PT_API int pt_bind_result_buffer(pt_handle h, void *device_ptr, size_t bytes)
 {
     PT_CHECK_HANDLE(h);
+    if (h->isGroup()) return fail(h, PT_E_BAD_ARGUMENT, "pt_bind_result_buffer is not available on a group handle");
     if (device_ptr && bytes < h->tilePixels() * sizeof(float4))
         return fail(h, PT_E_BAD_ARGUMENT, "buffer smaller than rows*width*16 bytes");
     if (int rc = bind_device(h)) return rc;
     if (int rc = join_stripes(h)) return rc;
     h->boundAccum = (float4 *)device_ptr;
     h->boundBytes = device_ptr ? bytes : 0;
+    // alpha doubles as the frame tag inside pipelined launches: whatever the caller's memory holds, it starts as 1
+    if (device_ptr) PT_HIP(h, pt::launch_set_alpha(h->boundAccum, h->tilePixels(), h->stream));
     return PT_OK;
 }
 
 PT_API int pt_set_stream(pt_handle h, void *hip_stream)
 {
     PT_CHECK_HANDLE(h);
+    if (h->isGroup()) return fail(h, PT_E_BAD_ARGUMENT, "pt_set_stream is not available on a group handle");
     if (int rc = bind_device(h)) return rc;
     if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -757,6 +886,7 @@ PT_API int pt_set_stream(pt_handle h, void *hip_stream)
 PT_API int pt_timer_begin(pt_handle h)
 {
     PT_CHECK_HANDLE(h);
+    PT_FAN_OUT(h, pt_timer_begin(part));
     if (int rc = bind_device(h)) return rc;
     if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, hipEventRecord(h->evBegin, h->stream));
@@ -767,6 +897,7 @@ PT_API int pt_timer_end(pt_handle h, float *out_ms)
 {
     PT_CHECK_HANDLE(h);
     if (!out_ms) return fail(h, PT_E_BAD_ARGUMENT, "out == NULL");
+    if (h->isGroup()) return ptimpl::group_timer_end(h, out_ms);
     if (int rc = bind_device(h)) return rc;
     if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, hipEventRecord(h->evEnd, h->stream));
@@ -779,6 +910,7 @@ PT_API int pt_timer_end(pt_handle h, float *out_ms)
 extern "C" __attribute__((visibility("default"))) int pt_debug_timeline(pt_handle h, unsigned long long *host_out, int max_waves)
 {
     PT_CHECK_HANDLE(h);
+    if (h->isGroup()) return fail(h, PT_E_BAD_ARGUMENT, "not available on a group handle");
     if (int rc = bind_device(h)) return rc;
     if (int rc = join_stripes(h)) return rc;
     if (!h->dTimeline) {
@@ -795,6 +927,7 @@ PT_API int pt_set_frame_batch(pt_handle h, int max_frames)
 {
     PT_CHECK_HANDLE(h);
     if (max_frames < 1 || max_frames > 64) return fail(h, PT_E_BAD_ARGUMENT, "max_frames must be 1..64");
+    PT_FAN_OUT(h, pt_set_frame_batch(part, max_frames));
     if (int rc = flush_frames(h)) return rc;
     h->maxBatch = max_frames;
     return PT_OK;
@@ -803,10 +936,19 @@ PT_API int pt_set_frame_batch(pt_handle h, int max_frames)
 PT_API int pt_set_variant(pt_handle h, int variant)
 {
     PT_CHECK_HANDLE(h);
+    PT_FAN_OUT(h, pt_set_variant(part, variant));
     if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (int rc = bind_device(h)) return rc;
     if (int rc = join_stripes(h)) return rc; // a different stripe partition must not overlap frames in flight
     h->variant = variant;
+    return PT_OK;
+}
+
+PT_API int pt_device_count_of(pt_handle h, int *out_n_devices)
+{
+    PT_CHECK_HANDLE(h);
+    if (!out_n_devices) return fail(h, PT_E_BAD_ARGUMENT, "out == NULL");
+    *out_n_devices = h->isGroup() ? (int)h->parts.size() : 1;
     return PT_OK;
 }
 

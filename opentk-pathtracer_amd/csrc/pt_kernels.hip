@@ -845,6 +845,50 @@ hipError_t launch_clear(float4 *p, size_t n, hipStream_t stream)
     return hipGetLastError();
 }
 
+__global__ void pt_set_alpha_kernel(float4 *p, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i].w = 1.0f;
+}
+
+hipError_t launch_set_alpha(float4 *p, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pt_set_alpha_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- multi-GPU gather
+// Un-band the parts' compact rows (see AssembleArgs).  One thread per pixel, 16-byte or 4-byte elements, fully
+// coalesced on both sides (a row is contiguous in the stage and in the image).
+template <typename T>
+__global__ __launch_bounds__(256) void pt_assemble_bands_kernel(const AssembleArgs a)
+{
+    const size_t n = (size_t)a.width * a.height;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const int y = (int)(i / a.width), x = (int)(i - (size_t)y * a.width);
+        const int band = y / a.bandRows, g = band % a.world, lb = band / a.world;
+        const size_t ly = (size_t)lb * a.bandRows + (size_t)(y - band * a.bandRows); // row inside part g's compact storage
+        ((T *)a.out)[i] = ((const T *)a.stage)[a.partOffset[g] + ly * a.width + x];
+    }
+}
+
+hipError_t launch_assemble_bands(const AssembleArgs &a, hipStream_t stream)
+{
+    const size_t n = (size_t)a.width * a.height;
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (a.bytesPerPixel == 16) hipLaunchKernelGGL(pt_assemble_bands_kernel<float4>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(pt_assemble_bands_kernel<uchar4>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 __global__ void pt_env_to_float_kernel(const void *env, int size, int format, const float *lut, float4 *out)
 {
     size_t n = (size_t)6 * size * size;

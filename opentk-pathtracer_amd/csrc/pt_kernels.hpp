@@ -59,6 +59,18 @@ struct AtmoArgs {
 hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int *ticketsConsumed);
 hipError_t launch_atmosphere(const AtmoArgs &a, hipStream_t stream);
 hipError_t launch_clear(float4 *p, size_t n, hipStream_t stream);
+// alpha := 1 over n pixels (pt_write_result / pt_bind_result_buffer: alpha is the frame tag inside pipelined launches)
+hipError_t launch_set_alpha(float4 *p, size_t n, hipStream_t stream);
+// Multi-GPU gather, second step (group handles with block-cyclic bands): `stage` holds the compact rows of part 0, 1, ...
+// (part g at pixel offset partOffset[g]); out[y] = row y of the width x height image.  bytesPerPixel = 16 (RGBA32F) or 4
+// (RGBA8).  HBM-bound copy: bytesPerPixel read + written per pixel.
+struct AssembleArgs {
+    const void *stage;
+    void *out;
+    int width, height, bandRows, world, bytesPerPixel;
+    unsigned long long partOffset[16]; // PT_MAX_GROUP_DEVICES
+};
+hipError_t launch_assemble_bands(const AssembleArgs &a, hipStream_t stream);
 // ACES + gamma of PostProcessing/fragment.glsl: n RGBA32F pixels -> n RGBA8 pixels
 hipError_t launch_postprocess(const float4 *accum, void *outRgba8, size_t n, hipStream_t stream);
 // linearise any environment into RGBA32F for read-back

@@ -1,0 +1,149 @@
+// pt_renderer.hpp — host-side state behind a pt_handle, shared by mi355pt.cpp (one renderer on one GPU) and
+// mi355pt_multi.cpp (a group of renderers, one per GPU, row-tiled; gather over xGMI at read / present time).
+//
+// What the reference keeps in the C# class PathTracer (/root/reference/OpenTK-PathTracer/src/Render/PathTracer.cs:9-141)
+// plus the two UBOs MainWindow owns (src/MainWindow.cs:195-201), and the HIP plumbing around the kernels of
+// pt_kernels.hip.  There is deliberately NO CPU fallback anywhere behind this struct.
+#pragma once
+#include "../../include/mi355pt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "pt_kernels.hpp"
+
+namespace ptimpl {
+constexpr uint32_t kAlive = 0x4d335054u; // "M3PT"
+constexpr int kMaxStripes = 4;
+
+// One image of the non-blocking present path (pt_present_rgba8_async / pt_present_wait).
+struct PresentSlot {
+    void *dRgba8 = nullptr;       // device RGBA8 image: this handle's rows (compact), or the whole image on a group handle
+    size_t devPixels = 0;         // capacity of dRgba8
+    uint8_t *host = nullptr;      // pinned host image (absent on the parts of a group: only the group handle copies to the host)
+    size_t hostPixels = 0;
+    unsigned int *hostErr = nullptr; // pinned copy of the frame-pipelining error word, taken with the image
+    hipEvent_t toneMapped = nullptr; // recorded behind the tone-map pass on the handle's stream
+    hipEvent_t copied = nullptr;     // recorded behind the device-to-host copy on the copy stream
+    bool inFlight = false;        // a copy from dRgba8 / into host was enqueued and not yet waited for
+    bool valid = false;           // host holds an image (after pt_present_wait)
+    int frame = 0, rows = 0, width = 0;
+};
+} // namespace ptimpl
+
+struct pt_renderer {
+    uint32_t magic = ptimpl::kAlive;
+    int device = 0;
+    int width = 0, height = 0;
+    int y0 = 0, rows = 0;
+    int bandRows = 0, bandWorld = 1, bandRank = 0; // block-cyclic row ownership (pt_set_interleaved_tile)
+    int numSpheres = 0, numCuboids = 0, rayDepth = 1, spp = 1;
+    float focalLength = 0.0f, apertureDiameter = 0.0f;
+    int frame = 0; // thisRenderNumFrame, PathTracer.cs:113
+    int variant = 0;
+
+    unsigned char basic[PT_BASIC_DATA_UBO_SIZE] = {0};   // host shadow of UBO 0 (travels as kernel argument)
+    unsigned char atmoUbo[PT_ATMOSPHERE_UBO_SIZE] = {0}; // host shadow of UBO 2
+
+    float *dObjects = nullptr;      // 26,624 B device copy of UBO 1
+    float *dLut = nullptr;          // 256-entry sRGB table
+    unsigned int *dQueue = nullptr; // global chunk-ticket counter of the persistent kernel (never reset: epoch scheme)
+    int queueChunk = 8;             // tiles per global ticket (PT_QUEUE_CHUNK overrides, for tuning runs)
+    unsigned long long *dTimeline = nullptr; // tuning only (pt_debug_timeline)
+    // Frame pipelining: consecutive pt_render calls are collected and launched as ONE batch kernel (see pt_kernels.hip)
+    // when nothing observable happens in between; every other entry point launches what is pending first.
+    int pendingFrames = 0;        // frames accepted by pt_render, not launched yet
+    int maxBatch = 64;            // PT_FRAME_BATCH=1 turns batching off (every pt_render launches at once)
+    int batchWorkgroupsPerCU = 6; // grid of the batch kernel (PT_BATCH_WG, tuning)
+    bool batchLaunched = false;   // a batch kernel ran since the last error-word check
+    hipEvent_t mainDone = nullptr; // recorded behind the last integrator launch on the main stream
+    bool mainInFlight = false;     // ... and not yet seen complete
+    bool stripeInFlight[ptimpl::kMaxStripes] = {false, false, false, false}; // same for the stripe streams
+    int drainCompaction = -1;      // donate threshold in live paths (<= 32), 0 = off, -1 = auto; env PT_DRAIN_COMPACTION
+    int numCUs = 256;
+    void *dEnv = nullptr; // current environment cube
+    size_t envBytes = 0;
+    int envSize = 0, envFormat = PT_ENV_RGBA32F;
+
+    float4 *dAccum = nullptr;     // internal accumulation image (rows x width)
+    size_t accumCapacity = 0;     // in pixels
+    float4 *boundAccum = nullptr; // caller-owned target (pt_bind_result_buffer)
+    void *dRgba8 = nullptr;       // post-processed RGBA8 image of the tile (pt_present_rgba8)
+    size_t rgba8Capacity = 0;     // in pixels
+    size_t boundBytes = 0;
+
+    hipStream_t ownStream = nullptr, stream = nullptr;
+    // Stripes: one frame = `stripes` persistent kernels over contiguous row ranges of the tile, each on its own
+    // stream, so that one stripe's frame-end drain overlaps the other stripe's main phase.
+    hipStream_t stripeStream[ptimpl::kMaxStripes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t stripeDone[ptimpl::kMaxStripes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t inputsReady = nullptr;
+    bool stripePending[ptimpl::kMaxStripes] = {false, false, false, false};
+    unsigned int stripeQueueBase[ptimpl::kMaxStripes] = {0, 0, 0, 0};
+    hipEvent_t evBegin = nullptr, evEnd = nullptr;
+
+    // non-blocking present
+    hipStream_t copyStream = nullptr;
+    ptimpl::PresentSlot slots[PT_PRESENT_SLOTS];
+
+    // group handle (pt_create_multi): parts[i] renders its share on device_ids[i]; this struct then only carries the root
+    // device's streams, the gather buffers and the present slots
+    std::vector<pt_renderer *> parts;
+    int groupBand = 16;             // 0 = contiguous row blocks
+    hipEvent_t gatherReady = nullptr; // (parts) recorded on the part's stream when its rows may be copied
+    void *dGatherFull = nullptr;      // (group) assembled image on the root device (RGBA32F or RGBA8)
+    size_t gatherFullBytes = 0;
+    void *dGatherStage = nullptr;     // (group) the parts' compact rows side by side, before un-banding
+    size_t gatherStageBytes = 0;
+    void *dAsyncStage = nullptr;      // (group) the same for the copy stream (asynchronous present)
+    size_t asyncStageBytes = 0;
+
+    std::string error;
+
+    bool isGroup() const { return !parts.empty(); }
+    bool externalStream() const { return stream != ownStream; }
+    float4 *accum() const { return boundAccum ? boundAccum : dAccum; }
+    size_t tilePixels() const { return (size_t)rows * (size_t)width; }
+};
+
+namespace ptimpl {
+
+int fail(pt_handle h, int code, const std::string &msg);
+int hip_fail(pt_handle h, hipError_t e, const char *what);
+
+#define PT_CHECK_HANDLE(h)                                                                                             \
+    do {                                                                                                               \
+        if (!(h) || (h)->magic != ptimpl::kAlive) return ptimpl::fail(nullptr, PT_E_BAD_HANDLE, "bad handle");        \
+    } while (0)
+
+#define PT_HIP(h, call)                                                                                                \
+    do {                                                                                                               \
+        hipError_t e_ = (call);                                                                                        \
+        if (e_ != hipSuccess) return ptimpl::hip_fail((h), e_, #call);                                                 \
+    } while (0)
+
+int bind_device(pt_handle h);
+int flush_frames(pt_handle h);  // launch the frames pt_render deferred
+int join_stripes(pt_handle h);  // flush + make h->stream wait for every helper stream
+int check_handover(pt_handle h); // frame-pipelining error word (call after the stream has been synchronised)
+// tone map this handle's rows into `dst` (RGBA8, compact rows) on h->stream, behind every frame rendered so far
+int tone_map_into(pt_handle h, void *dst);
+// slot plumbing shared by the single and the group path
+int ensure_slot_device(pt_handle h, int slot, size_t pixels);
+int ensure_slot_host(pt_handle h, int slot, size_t pixels);
+int ensure_slot_events(pt_handle h, int slot);
+void free_slots(pt_handle h);
+
+// group handles (mi355pt_multi.cpp)
+int group_destroy(pt_handle g);
+int group_set_size(pt_handle g, int width, int height);
+int group_read_result(pt_handle g, float *dst, size_t row_pitch_bytes);
+int group_write_result(pt_handle g, const float *src, size_t row_pitch_bytes, int frame_index);
+int group_present_rgba8(pt_handle g, uint8_t *dst, size_t row_pitch_bytes);
+int group_present_async(pt_handle g, int slot);
+int group_result_device_ptr(pt_handle g, void **out_ptr, size_t *out_bytes);
+int group_timer_end(pt_handle g, float *out_ms);
+
+} // namespace ptimpl

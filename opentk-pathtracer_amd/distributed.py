@@ -79,6 +79,9 @@ def attach_tile(tracer, height: int, rank: int, world: int, device=None, band_ro
         tracer.SetTile(y0, rows)
         pad = max_rows(height, world)
     buf = torch.zeros((pad, tracer.Width, 4), dtype=torch.float32, device=device if device is not None else "cuda")
+    # the zero-fill ran on torch's stream; the library renders on its own streams: finish it before the buffer is bound
+    if buf.is_cuda:
+        torch.cuda.current_stream(buf.device).synchronize()
     tracer.BindResultBuffer(buf.data_ptr(), buf.numel() * 4)
     return buf
 

@@ -309,7 +309,9 @@ public:
         std::vector<float> img((size_t)width_ * height_ * 4);
         bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "PTCKPT1\0", 8) == 0 && std::fread(ints, 4, 10, f) == 10 &&
                   std::fread(lens, 4, 2, f) == 2;
-        ok = ok && ints[0] == width_ && ints[1] == height_ && ints[2] == 0 && ints[3] == height_ && ints[7] >= 0 &&
+        // this class renders whole images: a checkpoint of one rank's rows (contiguous block or block-cyclic bands,
+        // ints[4..6] = band rows / world / rank) is not a checkpoint of this renderer
+        ok = ok && ints[0] == width_ && ints[1] == height_ && ints[2] == 0 && ints[3] == height_ && ints[4] == 0 && ints[7] >= 0 &&
              ints[8] == rayDepth_ && ints[9] == spp_ && lens[0] == focalLength_ && lens[1] == apertureDiameter_;
         ok = ok && std::fread(img.data(), 4, img.size(), f) == img.size() && std::fgetc(f) == EOF;
         std::fclose(f);

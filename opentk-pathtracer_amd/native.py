@@ -18,12 +18,13 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("MI355PT_LIB") or os.path.join(HERE, "libmi355pt.so")  # MI355PT_LIB: A/B tuning builds
 HEADER = os.path.join(REPO, "include", "mi355pt.h")
-SOURCES = ["pt_kernels.hip", "mi355pt.cpp"]
+SOURCES = ["pt_kernels.hip", "mi355pt.cpp", "mi355pt_multi.cpp"]
 # -ffp-contract=off / -fno-fast-math are part of the pt-f32 arithmetic contract (csrc/pt_math.hpp)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared",
                "-fvisibility=hidden"]
 
 PT_OK = 0
+PT_MAX_IMAGE_DIM, PT_MAX_RAY_DEPTH, PT_MAX_SPP, PT_PRESENT_SLOTS = 32767, 4095, 4095, 3
 PT_E_BAD_HANDLE, PT_E_BAD_ARGUMENT, PT_E_OUT_OF_RANGE, PT_E_NO_ENVIRONMENT, PT_E_HIP, PT_E_NO_DEVICE, PT_E_OOM = \
     -1, -2, -3, -4, -5, -6, -7
 PT_ENV_RGBA32F, PT_ENV_SRGB8_A8 = 0, 1
@@ -150,6 +151,11 @@ def load() -> C.CDLL:
         "pt_set_variant": [vp, C.c_int],
         "pt_set_frame_batch": [vp, C.c_int],
         "pt_device_count": [],
+        "pt_create_multi": [ip, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+        "pt_multi_set_partition": [vp, C.c_int],
+        "pt_device_count_of": [vp, ip],
+        "pt_present_rgba8_async": [vp, C.c_int],
+        "pt_present_wait": [vp, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), ip],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

@@ -53,11 +53,19 @@ class UniformBuffer:
 
 class PathTracer:
     def __init__(self, environmentMap, width: int, height: int, rayDepth: int, spp: int, focalLength: float,
-                 apertureDiamater: float, device: int = 0):
+                 apertureDiamater: float, device: int = 0, devices=None):
+        """`devices` = list of HIP device ids: ONE renderer row-tiled over those GPUs inside the library
+        (pt_create_multi; the gather over xGMI happens inside Result / Present).  Otherwise one GPU (`device`)."""
         self._lib = native.load()
         h = C.c_void_p()
-        check(self._lib.pt_create(device, width, height, C.byref(h)))
+        if devices is not None:
+            ids = (C.c_int * len(devices))(*devices)
+            check(self._lib.pt_create_multi(ids, len(devices), width, height, C.byref(h)))
+        else:
+            check(self._lib.pt_create(device, width, height, C.byref(h)))
         self._h = h
+        self.devices = list(devices) if devices is not None else [device]
+        self.band_rows, self.band_world, self.band_rank = 0, 1, 0
         self.Width, self.Height = width, height
         self._numSpheres = self._numCuboids = 0
         self._rayDepth, self._spp = rayDepth, spp
@@ -179,6 +187,24 @@ class PathTracer:
         out = np.empty((self.rows, self.Width, 4), dtype=np.uint8)
         check(self._lib.pt_present_rgba8(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), 0), self._h)
         return out
+
+    def PresentAsync(self, slot: int) -> None:
+        """Non-blocking present (pt_present_rgba8_async): tone map + device-to-host copy of the image as it is now into
+        the library's pinned slot; Render() calls that follow overlap the copy."""
+        check(self._lib.pt_present_rgba8_async(self._h, slot), self._h)
+
+    def PresentWait(self, slot: int):
+        """-> (image, frame_index): (rows, Width, 4) uint8 VIEW of the slot's pinned host image (valid until the next
+        PresentAsync on that slot) and the number of frames it shows."""
+        ptr, pitch, frame = C.POINTER(C.c_uint8)(), C.c_size_t(), C.c_int()
+        check(self._lib.pt_present_wait(self._h, slot, C.byref(ptr), C.byref(pitch), C.byref(frame)), self._h)
+        assert pitch.value == self.Width * 4
+        img = np.ctypeslib.as_array(ptr, shape=(self.rows, self.Width, 4))
+        return img, frame.value
+
+    def SetPartition(self, band_rows: int) -> None:
+        """Group handles: block-cyclic bands of `band_rows` image rows per device (0 = contiguous row blocks)."""
+        check(self._lib.pt_multi_set_partition(self._h, band_rows), self._h)
 
     def PostProcessDevice(self):
         p, n = C.c_void_p(), C.c_size_t()

@@ -118,7 +118,10 @@ C2 = Workload("C2_default_1080p_d8", "default", 1920, 1080, 8, "sky_f32_32")
 C3 = Workload("C3_stress256_1080p_d8", "stress256", 1920, 1080, 8, "sky_f32_32")
 C4 = Workload("C4_default_4k_d8", "default", 3840, 2160, 8, "sky_f32_32")
 C5 = Workload("C5_glass_1080p_d32", "glass", 1920, 1080, 32, "atmosphere_32")
-FULL_SIZE = [C1, C2, C3, C5]
+# the workload bench.py times at N = 1 (default scene + the reference's default ATMOSPHERE environment, MainWindow.cs:174-175,189),
+# with the cube computed by the reference's own AtmosphericScattering/compute.glsl (64^2 keeps the committed cube small)
+C2_ATMO = Workload("C2_default_1080p_d8_atmo", "default", 1920, 1080, 8, "atmosphere_64")
+FULL_SIZE = [C1, C2, C3, C5, C2_ATMO]
 
 # ---- small full-frame parity cases -----------------------------------------------------------------------------
 SMALL_FRAMES = [

@@ -40,3 +40,29 @@ def native_lib(pkg):
     if not os.path.exists(pkg.native.LIB_PATH):
         graft.build()
     return pkg.native.load()
+
+
+# ---- layer-2 parity report: every test that compares against reference-generated fixtures records what it ACHIEVED
+# (not just pass/fail); the table is printed in the terminal summary, also under -q, so that the GPU test record carries
+# the fidelity numbers.
+_PARITY_ROWS = []
+
+
+def record_parity(what: str, stats: dict, threshold: float) -> None:
+    _PARITY_ROWS.append((what, stats, threshold))
+
+
+@pytest.fixture
+def parity_report():
+    return record_parity
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not _PARITY_ROWS:
+        return
+    tr = terminalreporter
+    tr.write_sep("-", "layer-2 parity vs reference fixtures (achieved / required)")
+    tr.write_line(f"{'fixture':52s} {'within band':>12s} {'required':>9s} {'bit-identical':>14s} {'mean rel err':>13s} {'mean abs err':>13s}")
+    for what, st, thr in _PARITY_ROWS:
+        tr.write_line(f"{what:52s} {100 * st['within']:11.3f}% {100 * thr:8.2f}% {100 * st['bit_identical']:13.2f}% "
+                      f"{st['mean_rel_err']:13.2e} {st['mean_abs_err']:13.2e}")

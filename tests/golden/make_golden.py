@@ -51,6 +51,7 @@ def gen_envs():
     atmo32 = ref.run_atmosphere(32, ubo, lp, 15.0, 50, 15)
     envs = {k: configs.make_env(k) for k in ("sky_f32_32", "sky_srgb_32", "tiny_2", "tiny_4")}
     envs["atmosphere_32"] = atmo32
+    envs["atmosphere_64"] = ref.run_atmosphere(64, ubo, lp, 15.0, 50, 15)  # env of the bench workload's pinned fixture
     save("envs", **envs)
 
 
@@ -88,9 +89,11 @@ def gen_envonly():
              expected=out[0, ..., :3].copy())
 
 
-def gen_sparse():
+def gen_sparse(only=None):
     print("sparse full-resolution fixtures (4096 seeded pixels of the full frame):")
     for w in configs.FULL_SIZE:
+        if only and w.name not in only:
+            continue
         sc, basic, objs, env, kw = configs.inputs(w)
         out, log = ref.run_pathtracer(w.width, w.height, basic, objs, env, num_frames=1, return_log=True, **kw)
         print("   ", log.strip())
@@ -239,7 +242,19 @@ def gen_converged():
          env_key=np.array(w.env), iparams=ip, fparams=fp, expected=out[0, ..., :3].copy())
 
 
-GROUPS = {"converged": gen_converged, "post": gen_post, "envs": gen_envs, "micro": gen_micro, "frames": gen_frames, "envonly": gen_envonly, "sparse": gen_sparse,
+def gen_bench_fixture():
+    """Only what round 2 added (keeps every older fixture byte-identical): the atmosphere_64 cube + the sparse fixture of
+    the exact workload bench.py times."""
+    p = os.path.join(HERE, "envs.npz")
+    envs = dict(np.load(p))
+    if "atmosphere_64" not in envs:
+        envs["atmosphere_64"] = ref.run_atmosphere(64, pkg.camera.atmospheric_data_ubo(), pkg.camera.atmosphere_light_pos(0.5), 15.0, 50, 15)
+        save("envs", **envs)
+        configs._envs = None
+    gen_sparse(only={configs.C2_ATMO.name})
+
+
+GROUPS = {"bench": gen_bench_fixture, "converged": gen_converged, "post": gen_post, "envs": gen_envs, "micro": gen_micro, "frames": gen_frames, "envonly": gen_envonly, "sparse": gen_sparse,
           "atmo": gen_atmo}
 
 if __name__ == "__main__":

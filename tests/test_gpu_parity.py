@@ -227,22 +227,21 @@ def test_randomised_scenes_cameras_and_parameters(pkg, native_lib):
 
 # ------------------------------------------------------------------------------------------------ (2) HIP vs reference fixtures
 @pytest.mark.parametrize("name", fixtures.names("frame_"))
-def test_hip_matches_reference_fixtures(pkg, native_lib, name):
+def test_hip_matches_reference_fixtures(pkg, native_lib, name, parity_report):
+    """Layer 2: the HIP path against the reference GLSL's own output (llvmpipe fixtures).  Each fixture has its OWN pass
+    mark: the agreement measured for it (tests/golden/agreement.json) minus 0.3 percentage points (tests/tolerances.py)."""
     fx = fixtures.load(name)
     got = fixtures.hip_frames(pkg, fx)
     ref = fx["expected"]
+    # sRGB8 environments: llvmpipe decodes texels with a cubic approximation (fixtures.llvmpipe_srgb_lut); the product uses
+    # the exact GL 4.5 formula, so that fixture is compared with a band that covers the approximation (0.6 %)
     srgb = fx["env"].dtype == np.uint8
     for k in range(ref.shape[0]):
-        both_nan = np.isnan(ref[k]).any(-1) & np.isnan(got[k]).any(-1)
-        if srgb:
-            # llvmpipe decodes sRGB8 with a cubic approximation (fixtures.llvmpipe_srgb_lut); the product uses the
-            # exact GL 4.5 formula, so this fixture is compared with a band that covers the approximation (0.6 %)
-            ok = (np.abs(ref[k] - got[k]) <= 8e-3 * np.maximum(1.0, np.abs(ref[k]))).all(-1) | both_nan
-        else:
-            ok = tol.within(ref[k], got[k]) | both_nan
-        assert ok.mean() >= tol.PIXEL_FRACTION, f"{name} #{k}: {100 * ok.mean():.2f}% within tolerance"
-        fin = np.isfinite(ref[k]).all(-1) & np.isfinite(got[k]).all(-1)
-        assert abs(ref[k][fin].mean() - got[k][fin].mean()) <= (6e-3 if srgb else tol.MEAN_REL_TOL) * abs(ref[k][fin].mean())
+        st = tol.agreement(ref[k], got[k], srgb_band=srgb)
+        need = tol.min_fraction(name, k)
+        parity_report(f"HIP {name} #{k}", st, need)
+        assert st["within"] >= need, f"{name} #{k}: {100 * st['within']:.3f}% within tolerance, need {100 * need:.2f}%"
+        assert st["mean_rel_err"] <= (tol.SRGB_MEAN_REL_TOL if srgb else tol.MEAN_REL_TOL)
 
 
 @pytest.mark.parametrize("name", [n for n in fixtures.names("envonly_") if "srgb" not in n])
@@ -255,9 +254,10 @@ def test_hip_environment_sampler_matches_reference(pkg, native_lib, name):
 
 
 @pytest.mark.parametrize("name", fixtures.names("sparse_"))
-def test_full_size_frames_vs_reference_sparse_pixels(pkg, native_lib, oracle, name):
-    """BASELINE configs C1/C2/C3/C5 at FULL resolution on the GPU: the 4096 reference pixels must agree within the
-    stated tolerance, and the same pixels must equal the oracle bit for bit."""
+def test_full_size_frames_vs_reference_sparse_pixels(pkg, native_lib, oracle, name, parity_report):
+    """BASELINE configs C1/C2/C3/C5 — and C2 with the reference's atmosphere environment, the exact workload bench.py
+    times — at FULL resolution on the GPU: the 4096 reference pixels must agree within the fixture's own pass mark, and
+    the same pixels must equal the oracle bit for bit."""
     fx = fixtures.load(name)
     pt = fixtures.hip_tracer(pkg, fx)
     pt.Render()
@@ -265,13 +265,51 @@ def test_full_size_frames_vs_reference_sparse_pixels(pkg, native_lib, oracle, na
     pt.Dispose()
     xy = fx["xy"]
     got = img[xy[:, 1], xy[:, 0], :3]
-    ok = tol.within(fx["expected"], got)
-    assert ok.mean() >= tol.PIXEL_FRACTION, f"{name}: {100 * ok.mean():.2f}%"
+    st, need = tol.agreement(fx["expected"], got), tol.min_fraction(name)
+    parity_report(f"HIP {name}", st, need)
+    assert st["within"] >= need, f"{name}: {100 * st['within']:.3f}%, need {100 * need:.2f}%"
     full_mean = img[..., :3].mean(axis=(0, 1), dtype=np.float64)
     assert np.all(np.abs(full_mean - fx["frame_mean"]) <= tol.MEAN_REL_TOL * np.abs(fx["frame_mean"]))
     want = oracle.render_pixels(fx["width"], fx["height"], fx["basic"], fx["objects"], fx["env"], xy, frame=0,
                                 **fixtures.kwargs(fx))
     assert_bit_exact(img[xy[:, 1], xy[:, 0]], want, name)
+
+
+def test_large_srgb_cube_sparse_pixels_equal_oracle(pkg, native_lib, oracle):
+    """The reference's OTHER environment shape: a 2048^2 x 6 SRGB8_A8 cube (MainWindow.cs:177-187; 100.7 MB, synthetic
+    content).  Texel indices reach 6 * 2048^2 = 25.2 M: 1080p frame on the GPU, 8192 seeded pixels against the oracle, bit
+    for bit (the 32-bit tap index math of the sampler is what a small cube never exercises)."""
+    env = pkg.envmap.synthetic_sky_srgb8(2048)
+    assert env.shape == (6, 2048, 2048, 4) and env.dtype == np.uint8
+    w = configs.Workload("sky2048", "default", 1920, 1080, 8, "unused")
+    sc = configs.make_scene("default")
+    basic = pkg.camera.basic_data_ubo(pkg.camera.Camera(), w.width, w.height)
+    kw = dict(num_spheres=sc.num_spheres, num_cuboids=sc.num_cuboids, ray_depth=8, spp=1, focal_length=20.0, aperture=0.14)
+    pt = pkg.PathTracer(env, w.width, w.height, 8, 1, 20.0, 0.14)
+    pt.UploadScene(sc)
+    pt.UploadBasicData(basic)
+    pt.Render()
+    pt.Render()
+    img = pt.Result
+    pt.Dispose()
+    rng = np.random.RandomState(77)
+    xy = np.stack([rng.randint(0, w.width, 8192), rng.randint(0, w.height, 8192)], axis=1).astype(np.int32)
+    f0 = oracle.render_pixels(w.width, w.height, basic, sc.ubo_bytes(), env, xy, frame=0, **kw)
+    want = oracle.render_pixels(w.width, w.height, basic, sc.ubo_bytes(), env, xy, frame=1, last=f0, **kw)
+    got = img[xy[:, 1], xy[:, 0]]
+    assert_bit_exact(got, want, "2048^2 sRGB8 cube, two frames")
+    # and the environment alone (empty scene, pinhole): every pixel is a cube lookup, taps all over the six faces
+    for look in ((-32.2, 0.8), (135.0, -35.26), (0.0, -89.0)):
+        cam = pkg.camera.Camera(look_x=look[0], look_y=look[1])
+        b2 = pkg.camera.basic_data_ubo(cam, 640, 360)
+        pt = pkg.PathTracer(env, 640, 360, 2, 1, 20.0, 0.0)
+        pt.UploadBasicData(b2)
+        pt.Render()
+        got = pt.Result
+        pt.Dispose()
+        want = oracle.render(640, 360, b2, bytes(26624), env, num_spheres=0, num_cuboids=0, ray_depth=2, spp=1,
+                             focal_length=20.0, aperture=0.0, num_frames=1)
+        assert_bit_exact(got, want, f"2048^2 sRGB8 cube, environment only, look {look}")
 
 
 # ------------------------------------------------------------------------------------------------ (3) properties at full size

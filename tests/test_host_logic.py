@@ -114,7 +114,7 @@ def test_row_blocks_cover_image(pkg):
 # ------------------------------------------------------------------------------------------------ C ABI (no GPU here)
 def test_c_abi_exports_every_declared_symbol(pkg, native_lib):
     declared = pkg.native.declared_symbols()
-    assert len(declared) >= 26
+    assert len(declared) >= 35
     raw = C.CDLL(pkg.native.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/mi355pt.h but not exported"
@@ -138,6 +138,19 @@ def test_c_abi_argument_checks_without_device(pkg, native_lib):
     assert native_lib.pt_create(0, 64, 64, None) == pkg.native.PT_E_BAD_ARGUMENT
     assert native_lib.pt_destroy(None) == pkg.native.PT_E_BAD_HANDLE
     assert native_lib.pt_render(None, None) == pkg.native.PT_E_BAD_HANDLE
+    # round 2: limits and the group constructor reject bad arguments before touching a device
+    N = pkg.native
+    assert native_lib.pt_create(0, 64, N.PT_MAX_IMAGE_DIM + 1, C.byref(C.c_void_p())) == N.PT_E_OUT_OF_RANGE
+    assert native_lib.pt_create_multi(None, 2, 64, 64, C.byref(C.c_void_p())) == N.PT_E_BAD_ARGUMENT
+    ids = (C.c_int * 3)(0, 1, 2)
+    assert native_lib.pt_create_multi(ids, 0, 64, 64, C.byref(C.c_void_p())) == N.PT_E_BAD_ARGUMENT
+    assert native_lib.pt_create_multi(ids, 17, 64, 64, C.byref(C.c_void_p())) == N.PT_E_BAD_ARGUMENT
+    assert native_lib.pt_create_multi(ids, 3, 64, 2, C.byref(C.c_void_p())) == N.PT_E_BAD_ARGUMENT
+    assert native_lib.pt_present_rgba8_async(None, 0) == N.PT_E_BAD_HANDLE
+    assert native_lib.pt_present_wait(None, 0, None, None, None) == N.PT_E_BAD_HANDLE
+    assert native_lib.pt_multi_set_partition(None, 16) == N.PT_E_BAD_HANDLE
+    if native_lib.pt_device_count() == 0:  # the group constructor has no CPU fallback either
+        assert native_lib.pt_create_multi(ids, 3, 64, 64, C.byref(C.c_void_p())) == N.PT_E_NO_DEVICE
 
 
 def test_product_never_imports_the_oracle(pkg):
@@ -184,6 +197,7 @@ class _FakeTracer:
 
     def __init__(self, w=7, h=5, rows=5, y0=0, frame=3):
         self.Width, self.Height, self.y0, self.rows = w, h, y0, rows
+        self.band_rows, self.band_world, self.band_rank = 0, 1, 0
         self.RayDepth, self.SPP, self.FocalLength, self.ApertureDiameter = 8, 1, 20.0, 0.14
         self.FrameIndex = frame
         rng = np.random.RandomState(1)
@@ -218,6 +232,24 @@ def test_checkpoint_file_round_trip_and_validation(pkg, tmp_path):
     open(str(tmp_path / "bad.ptck"), "wb").write(b"NOTACKPT" + bytes(48))
     with pytest.raises(ck.CheckpointError, match="magic"):
         ck.read_checkpoint_file(str(tmp_path / "bad.ptck"))
+    # block-cyclic ownership: every rank has y0 = 0 and (often) the same row count — rank, world size and band height
+    # are what identify the rows
+    banded = _FakeTracer()
+    banded.band_rows, banded.band_world, banded.band_rank = 8, 2, 1
+    bpath = str(tmp_path / "banded.ptck")
+    ck.save_checkpoint(bpath, banded)
+    same = _FakeTracer()
+    same.band_rows, same.band_world, same.band_rank = 8, 2, 1
+    assert ck.load_checkpoint(bpath, same)["band_rank"] == 1
+    for attr, val, what in (("band_rank", 0, "band_rank"), ("band_world", 4, "band_world"), ("band_rows", 16, "band_rows"),
+                            ("band_rows", 0, "band_rows")):
+        wrong = _FakeTracer()
+        wrong.band_rows, wrong.band_world, wrong.band_rank = 8, 2, 1
+        setattr(wrong, attr, val)
+        with pytest.raises(ck.CheckpointError, match=what):
+            ck.load_checkpoint(bpath, wrong)
+    with pytest.raises(ck.CheckpointError, match="band_rows"):
+        ck.load_checkpoint(path, same)  # a whole-image checkpoint into a banded renderer
     data = open(path, "rb").read()
     open(str(tmp_path / "short.ptck"), "wb").write(data[:-16])
     with pytest.raises(ck.CheckpointError, match="payload"):

@@ -196,7 +196,7 @@ def test_exact_srgb_decode_differs_from_llvmpipe_only_slightly(oracle):
 
 # ------------------------------------------------------------------------------------------------ full small frames
 @pytest.mark.parametrize("name", fixtures.names("frame_"))
-def test_small_frames_match_reference(oracle, name):
+def test_small_frames_match_reference(oracle, name, parity_report):
     fx = fixtures.load(name)
     srgb = fx["env"].dtype == np.uint8
     if srgb:
@@ -208,10 +208,12 @@ def test_small_frames_match_reference(oracle, name):
     ref = fx["expected"]
     assert got.shape == ref.shape
     for k in range(ref.shape[0]):
-        both_nan = np.isnan(ref[k]).any(-1) & np.isnan(got[k]).any(-1)
-        ok = tol.within(ref[k], got[k]) | both_nan
-        frac = ok.mean()
-        assert frac >= tol.PIXEL_FRACTION, f"{name} frame#{k}: only {100 * frac:.2f}% of pixels within tolerance"
+        st = tol.agreement(ref[k], got[k])
+        # (the sRGB fixture runs with llvmpipe's own decode table injected, so it is held to the narrow band here)
+        need = 0.99 if srgb else tol.min_fraction(name, k)
+        parity_report(f"oracle {name} #{k}", st, need)
+        frac = st["within"]
+        assert frac >= need, f"{name} frame#{k}: only {100 * frac:.3f}% of pixels within tolerance, need {100 * need:.2f}%"
         fin = np.isfinite(ref[k]).all(-1) & np.isfinite(got[k]).all(-1)
         m_ref, m_got = ref[k][fin].mean(), got[k][fin].mean()
         assert abs(m_ref - m_got) <= tol.MEAN_REL_TOL * abs(m_ref), f"{name}: mean {m_got} vs {m_ref}"
@@ -221,14 +223,15 @@ def test_small_frames_match_reference(oracle, name):
 
 # ------------------------------------------------------------------------------------------------ BASELINE configs, sparse
 @pytest.mark.parametrize("name", fixtures.names("sparse_"))
-def test_full_resolution_sparse_pixels(oracle, name):
+def test_full_resolution_sparse_pixels(oracle, name, parity_report):
     """C1/C2/C3/C5 at FULL size: 4096 seeded pixels of the reference's full frame (pixels are independent)."""
     fx = fixtures.load(name)
     got = oracle.render_pixels(fx["width"], fx["height"], fx["basic"], fx["objects"], fx["env"], fx["xy"], frame=0,
                                **fixtures.kwargs(fx))[..., :3]
     ref = fx["expected"]
-    ok = tol.within(ref, got)
-    assert ok.mean() >= tol.PIXEL_FRACTION, f"{name}: {100 * ok.mean():.2f}% within tolerance"
+    st, need = tol.agreement(ref, got), tol.min_fraction(name)
+    parity_report(f"oracle {name}", st, need)
+    assert st["within"] >= need, f"{name}: {100 * st['within']:.3f}% within tolerance, need {100 * need:.2f}%"
     assert abs(ref.mean() - got.mean()) <= tol.MEAN_REL_TOL * abs(ref.mean())
 
 

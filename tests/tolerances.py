@@ -5,23 +5,69 @@
    sin/cos/exp/pow/inversesqrt/normalize and fma contraction implementation-defined, and the integrator branches on
    RNG draws compared with computed floats (compute.glsl:169,201,208,234,247), so a last-bit difference flips a
    branch in a small fraction of pixels.  The claim is therefore two-part:
-     (a) at least PIXEL_FRACTION of the pixels agree within  REL_TOL * max(1, |reference|)  per channel;
+     (a) at least min_fraction(fixture, k) of the pixels agree within  REL_TOL * max(1, |reference|)  per channel;
      (b) the image means agree within MEAN_REL_TOL (no bias).
-   Measured on the committed fixtures: 98.4 % .. 100 % of pixels inside the band (worst: 256-sphere scene).
+   The pass mark of (a) is PER FIXTURE: the fraction measured for that fixture (tests/golden/agreement.json, written by
+   tests/golden/measure_agreement.py from the oracle, which the HIP path equals bit for bit) minus MARGIN = 0.3
+   percentage points — 99.2-99.9 % for the default / glass / random-material scenes, 98.0 % for the 256-sphere scene
+   (263 brute-force candidates per bounce: more near-ties).  A fixture without a measurement falls back to PIXEL_FRACTION.
+   Every test reports the achieved numbers in the terminal summary (tests/conftest.py).
 """
+import json
+import os
+
 REL_TOL = 1e-4
-PIXEL_FRACTION = 0.975
+PIXEL_FRACTION = 0.975   # fallback only (fixtures newer than agreement.json)
+MARGIN = 0.003           # 0.3 percentage points below the measured agreement
 MEAN_REL_TOL = 2e-3
+# llvmpipe decodes sRGB8 texels with a cubic approximation (<= 0.6 % off the GL formula, fixtures.llvmpipe_srgb_lut); the
+# product uses the exact GL 4.5 table, so sRGB-environment fixtures are compared inside this wider band
+SRGB_REL_TOL = 8e-3
+SRGB_MEAN_REL_TOL = 6e-3
 # environment-only frames (no chaotic branching): every pixel must agree
 ENV_REL_TOL = 5e-5
 # function-level micro fixtures (absolute)
 MICRO_ABS_TOL = 2e-5
 
+_AGREEMENT = None
 
-def within(ref, got):
-    """per-pixel boolean: all channels inside REL_TOL * max(1,|ref|)"""
+
+def measured(name: str):
+    global _AGREEMENT
+    if _AGREEMENT is None:
+        p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "agreement.json")
+        _AGREEMENT = json.load(open(p)) if os.path.exists(p) else {}
+    return _AGREEMENT.get(name)
+
+
+def min_fraction(name: str, k: int = 0) -> float:
+    m = measured(name)
+    if not m or k >= len(m):
+        return PIXEL_FRACTION
+    return m[k]["within"] - MARGIN
+
+
+def within(ref, got, rel_tol=REL_TOL):
+    """per-pixel boolean: all channels inside rel_tol * max(1,|ref|)"""
     import numpy as np
     ref = np.asarray(ref, dtype=np.float64)
     got = np.asarray(got, dtype=np.float64)
-    tol = REL_TOL * np.maximum(1.0, np.abs(ref))
+    tol = rel_tol * np.maximum(1.0, np.abs(ref))
     return (np.abs(ref - got) <= tol).all(axis=-1)
+
+
+def agreement(ref, got, srgb_band=False) -> dict:
+    """The numbers every layer-2 test reports: fraction of pixels inside the band (NaN == NaN counts as agreeing: the
+    reference produces NaN pixels by design), fraction bit-identical, relative error of the image mean,
+    mean absolute error over finite pixels."""
+    import numpy as np
+    ref = np.asarray(ref, dtype=np.float32)
+    got = np.asarray(got, dtype=np.float32)
+    both_nan = np.isnan(ref).any(-1) & np.isnan(got).any(-1)
+    ok = within(ref, got, SRGB_REL_TOL if srgb_band else REL_TOL) | both_nan
+    same = (ref.view(np.uint32) == got.view(np.uint32)).all(-1)
+    fin = np.isfinite(ref).all(-1) & np.isfinite(got).all(-1)
+    rm, gm = float(ref[fin].mean(dtype=np.float64)), float(got[fin].mean(dtype=np.float64))
+    return {"within": float(ok.mean()), "bit_identical": float(same.mean()),
+            "mean_rel_err": abs(rm - gm) / max(abs(rm), 1e-30),
+            "mean_abs_err": float(np.abs(ref[fin].astype(np.float64) - got[fin]).mean())}
