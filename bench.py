@@ -13,18 +13,27 @@ timed region, which ends with pt_timer_end + pt_synchronize.  Defaults: 960 step
 warm-up steps the GPU is kept busy for --clock-warmup-ms (80 ms, reported in the JSON line) because it needs ~40 ms of
 load to reach its steady clock — that time is neither a step nor timed, and the accumulation restarts at frame 0 after it.
 
-N = 1 runs BASELINE.json configs[1]: default scene (48 spheres + 7 cuboids), 1920x1080, 8 bounces, 1 spp, the
-reference's default environment (256^2 RGBA32F atmosphere cube, computed by the atmosphere kernel).
-N > 1 is WEAK scaling: the 16:9 image grows to ~N x 2.07 Mpixel (N=4 is BASELINE configs[3]'s 3840x2160) and is
-tiled across ranks in block-cyclic 16-row bands (balanced: floor rows cost ~2x sky rows), no data-path collective; the
-RCCL gather happens only at present time and is timed separately (`present_ms`).  value = all pixels x spp x steps / max-over-ranks wall time.
+Workload = BASELINE.json's metric ("@1080p 8-bounce default scene, 1/2/4/8 GPU"):
+  N = 1  BASELINE configs[1] (--config C2): default scene (48 spheres + 7 cuboids), 1920x1080, 8 bounces, 1 spp, the
+         reference's default environment (256^2 RGBA32F atmosphere cube, computed by the atmosphere kernel).
+  N > 1  the SAME 1920x1080 image row-tiled over the N GPUs (STRONG scaling, "scaling": "strong"): one process per GPU,
+         block-cyclic 16-row bands (floor rows cost ~2x sky rows), no data-path collective; the RCCL gather happens only at
+         present time and is timed separately (`present_ms`).  value = all pixels x spp x steps / max-over-ranks wall time.
+         The same run then measures BASELINE configs[3] — ONE 3840x2160 image over the N GPUs — and reports it inside the
+         same JSON line as "configs3_4k" (the driver's contract is one line).
+  --config C3 | C5 select BASELINE configs[2] (256-sphere scene) / configs[4] (glass scene, 32 bounces); --weak grows the
+  image with N (~N x 2.07 Mpixel) instead; --strong-4k makes configs[3] the headline workload.
 
 The JSON line also carries
   roofline     : the integrator kernel against the HBM roof, from ALGORITHMIC bytes (32 B per pixel per frame: one
                  float4 load + one float4 store of the accumulation image) and the kernel's average duration measured
                  with HIP events on the stream it runs on;  `valu` gives the roof that actually binds (fp32 vector ALU);
+                 `traffic` / `valu_issue` come from the PMC passes committed under profiles/ and are dropped (null + a
+                 note) when those passes were taken with different kernel sources than the library now built;
   cpu_baseline : the C restatement (oracle/, "port") timed on this box's host cores on a bounded sample of the same
-                 workload — rank 0, N = 1 only.  The oracle is used here ONLY as the thing timed, never by the GPU path.
+                 workload (all threads, and one thread) — rank 0, N = 1 only — plus the REFERENCE'S OWN GLSL on Mesa
+                 llvmpipe as recorded in the build container (profiles/reference_llvmpipe.json; llvmpipe does not exist on
+                 the GPU box).  The oracle is used here ONLY as the thing timed, never by the GPU path.
 """
 from __future__ import annotations
 
@@ -45,9 +54,12 @@ FP32_VALU_PEAK_TF = 157.3  # same guide: peak FP32 vector
 ALGO_BYTES_PER_PIXEL_FRAME = 32  # SURVEY.md section 8d / BASELINE.md section 4
 
 WEAK_SIZES = {1: (1920, 1080), 2: (2720, 1530), 4: (3840, 2160), 8: (5440, 3060)}
+# BASELINE.json configs by name: (scene, depth, env, BASELINE index)
+CONFIGS = {"C2": ("default", 8, "atmosphere256", 1), "C3": ("stress256", 8, "atmosphere256", 2), "C5": ("glass", 32, "atmosphere256", 4)}
+BAND = 16  # block-cyclic 16-row bands across ranks: row cost varies ~2x between sky and floor rows
 
 
-def image_size(n_gpus: int) -> tuple[int, int]:
+def weak_image_size(n_gpus: int) -> tuple[int, int]:
     if n_gpus in WEAK_SIZES:
         return WEAK_SIZES[n_gpus]
     w = int(round(1920 * n_gpus ** 0.5 / 16)) * 16
@@ -59,24 +71,22 @@ def flops_per_sample(mean_bounces: float, ns: int, nc: int) -> float:
     return 100.0 + mean_bounces * (17.0 * ns + 24.0 * nc + 120.0)
 
 
-def _load_profile_number(file_name: str, workload_key: str):
+def load_profile_number(file_name: str, workload_key: str, csrc_hash: str):
+    """A per-step number measured by the rocprofv3 PMC passes committed under profiles/ -> (value or None, note or None).
+    Entries are stamped with the hash of the kernel sources they were measured on (tools/summarize_profile.py); a stale
+    entry is NOT used."""
     p = os.path.join(ROOT, "profiles", file_name)
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get(workload_key)
-        except Exception:
-            return None
-    return None
-
-
-def load_traffic(workload_key: str):
-    """Measured HBM bytes per step from the rocprofv3 PMC passes committed under profiles/ (or None)."""
-    return _load_profile_number("traffic.json", workload_key)
-
-
-def load_valu_insts(workload_key: str):
-    """Measured VALU wave-instructions per step (SQ_INSTS_VALU, same PMC passes) or None."""
-    return _load_profile_number("valu_insts.json", workload_key)
+    if not os.path.exists(p):
+        return None, None
+    try:
+        e = json.load(open(p)).get(workload_key)
+    except Exception:
+        return None, None
+    if e is None:
+        return None, None
+    if not isinstance(e, dict) or e.get("csrc_hash") != csrc_hash:
+        return None, f"profiles/{file_name} holds a measurement of other kernel sources for this workload: not used"
+    return e["value"], None
 
 
 # VALU issue roof: the 157.3 TFLOP/s FP32 vector peak = 1024 SIMDs x 32 lanes x 2 flops x 2.4 GHz, i.e. at best one
@@ -86,9 +96,9 @@ def load_valu_insts(workload_key: str):
 VALU_ISSUE_PEAK_GINST = 1024 * 2.4 / 2.0
 
 
-def cpu_baseline(pkg, scene, basic, env, width, height, depth, spp):
+def cpu_baseline(pkg, scene, basic, env, width, height, depth, spp, workload_name):
     """Time the oracle ("port") on the host cores on a bounded sample: whole frames of the same workload until
-    ~10 s have elapsed (at least one frame)."""
+    ~10 s have elapsed (at least one frame) on all threads, then a thin row block on ONE thread (~3 s)."""
     oracle = graft.load_oracle().Oracle()
     cores = os.cpu_count() or 1
     kw = dict(num_spheres=scene.num_spheres, num_cuboids=scene.num_cuboids, ray_depth=depth, spp=spp)
@@ -103,12 +113,42 @@ def cpu_baseline(pkg, scene, basic, env, width, height, depth, spp):
         dt = time.perf_counter() - t0
         if dt > 10.0 or frames >= 64:
             break
+    # one thread: row blocks spread over the image (rows differ ~2x in cost), until ~3 s have elapsed
+    rows1, t1, k = 0, time.perf_counter(), 0
+    starts = [int(height * f) // 8 * 8 for f in (0.5, 0.1, 0.9, 0.3, 0.7, 0.2, 0.8, 0.4, 0.6, 0.0)]
+    while True:
+        y0 = min(starts[k % len(starts)] + 8 * (k // len(starts)), height - 8)
+        oracle.render(width, height, basic, objs, env, y0=y0, rows=8, threads=1, **kw)
+        rows1 += 8
+        k += 1
+        dt1 = time.perf_counter() - t1
+        if dt1 > 3.0 or k >= 400:
+            break
     _, st = oracle.render(width, height, basic, objs, env, y0=0, rows=height, threads=cores, want_stats=True, **kw)
-    return {
+    out = {
         "value": round(width * height * spp * frames / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": f"{frames} full frame(s) of the same workload ({width}x{height}, {depth} bounces, {spp} spp) in {dt:.1f} s, "
                   f"oracle/pt_oracle.c row-parallel on {cores} threads",
-    }, st["bounces"] / max(1, st["samples"])
+        "one_thread": {"value": round(width * rows1 * spp / dt1 / 1e6, 4), "unit": "Msamples/s", "cores": 1,
+                       "sample": f"{rows1} rows ({k} blocks of 8 spread over the image) of one frame in {dt1:.1f} s"},
+    }
+    # the reference's own code on a CPU: its GLSL on llvmpipe, recorded in the build container (no llvmpipe on the GPU box)
+    p = os.path.join(ROOT, "profiles", "reference_llvmpipe.json")
+    if os.path.exists(p):
+        try:
+            rec = json.load(open(p))
+            run = rec["runs"].get(workload_name)
+            if run:
+                out["reference_glsl_llvmpipe"] = {
+                    "value": run["all_threads"]["msamples_per_s"], "unit": "Msamples/s", "cores": run["all_threads"]["threads"],
+                    "ms_per_frame": run["all_threads"]["ms_per_frame"],
+                    "one_thread": {"value": run["one_thread"]["msamples_per_s"], "ms_per_frame": run["one_thread"]["ms_per_frame"]},
+                    "kind": "reference", "measured": "NOT in this run: recorded in the build container (8 vCPUs, "
+                                                     f"{rec['provenance']['cpu']}), {rec['what']}",
+                    "workload": workload_name}
+        except Exception:
+            pass
+    return out, st["bounces"] / max(1, st["samples"])
 
 
 def main():
@@ -116,23 +156,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=960)
     ap.add_argument("--warmup", type=int, default=320)
-    ap.add_argument("--scene", default="default", choices=["default", "stress256", "glass"])
-    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="BASELINE.json config preset (scene, depth, env); default C2")
+    ap.add_argument("--scene", default=None, choices=["default", "stress256", "glass"])
+    ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--spp", type=int, default=1)
-    ap.add_argument("--env", default="atmosphere256", choices=["atmosphere256", "sky2048", "sky64"])
+    ap.add_argument("--env", default=None, choices=["atmosphere256", "sky2048", "sky64"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--frame-batch", type=int, default=64,
                     help="frames one launch may pipeline (pt_set_frame_batch; 1 = one launch per Render())")
     ap.add_argument("--clock-warmup-ms", type=float, default=80.0,
                     help="wall time of untimed rendering before the W warm-up steps (GPU clock ramp); 0 = none")
     ap.add_argument("--strong-4k", action="store_true",
-                    help="BASELINE configs[3]: ONE 3840x2160 image row-tiled over the N GPUs (strong scaling) instead of the "
-                         "weak-scaling image that grows with N")
+                    help="make BASELINE configs[3] the headline workload: ONE 3840x2160 image row-tiled over the N GPUs")
+    ap.add_argument("--weak", action="store_true", help="N > 1: grow the 16:9 image to ~N x 2.07 Mpixel (weak scaling)")
+    ap.add_argument("--no-4k", action="store_true", help="N > 1: skip the extra configs[3] measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: all ranks use cuda:0 and rendezvous over gloo (validates the N>1 logic on a 1-GPU box; "
                          "RCCL cannot put two ranks on one device)")
     args = ap.parse_args()
+    preset = CONFIGS[args.config or "C2"]
+    scene_name = args.scene or preset[0]
+    depth = args.depth if args.depth is not None else preset[1]
+    env_name = args.env or preset[2]
+    is_preset = (scene_name, depth, env_name) == preset[:3] and args.spp == 1
+    baseline_index = preset[3] if is_preset else None
 
     pkg = graft.load_package()
     if not os.path.exists(pkg.native.LIB_PATH):  # fresh checkout without built artefacts: hipcc is part of the image
@@ -158,99 +206,128 @@ def main():
     torch.cuda.set_device(local)
     import torch.distributed as dist
 
-    W, H = (3840, 2160) if args.strong_4k else image_size(world)  # --strong-4k: BASELINE configs[3], one 4K image over N GPUs
-    scene = {"default": pkg.scene.default_scene, "stress256": pkg.scene.stress_scene, "glass": pkg.scene.glass_scene}[args.scene]()
+    scene = {"default": pkg.scene.default_scene, "stress256": pkg.scene.stress_scene, "glass": pkg.scene.glass_scene}[scene_name]()
     cam = pkg.camera.Camera()
-    basic = pkg.camera.basic_data_ubo(cam, W, H)
-
-    pt = pkg.PathTracer(None, W, H, args.depth, args.spp, 20.0, 0.14, device=local)
-    pt.SetVariant(args.variant)
-    pt.SetFrameBatch(args.frame_batch)
-    # frames one launch renders: consecutive Render() calls of the default spp=1 kernel are pipelined inside one launch
+    csrc_hash = pkg.native.csrc_hash()
     frames_per_launch = args.frame_batch if args.variant == 0 else 1
-    if args.env == "atmosphere256":   # MainWindow.cs:174-175,189
-        pt.EnvironmentMap = pkg.AtmosphericScatterer(256, pkg.camera.atmospheric_data_ubo(), pkg.camera.atmosphere_light_pos(0.5), pt)
-    elif args.env == "sky2048":       # MainWindow.cs:177-187 shape, synthetic content
-        pt.EnvironmentMap = pkg.envmap.synthetic_sky_srgb8(2048)
-    else:
-        pt.EnvironmentMap = pkg.envmap.synthetic_sky_rgba32f(64)
-    pt.UploadScene(scene)
-    pt.UploadBasicData(basic)
-    BAND = 16  # block-cyclic 16-row bands across ranks: row cost varies ~2x between sky and floor rows
-    tile = D.attach_tile(pt, H, rank, world, device=torch.device("cuda", local), band_rows=BAND)
-    rows = pt.rows
 
-    def gather_image():
-        if args.share_gpu and world > 1:  # gloo cannot gather CUDA tensors: stage through the host
-            out = D.present(tile.cpu(), H, rank, world, band_rows=BAND)
-            return out.cuda() if out is not None else None
-        return D.present(tile, H, rank, world, band_rows=BAND)
+    def measure(W, H, steps, warmup, clock_warmup_ms):
+        """One workload: create the renderer for this rank's rows of the W x H image, warm up, time `steps` Render() calls
+        (barrier + synchronize on both sides, max over ranks), gather once.  -> dict (rank 0) with the raw measurements."""
+        basic = pkg.camera.basic_data_ubo(cam, W, H)
+        pt = pkg.PathTracer(None, W, H, depth, args.spp, 20.0, 0.14, device=local)
+        pt.SetVariant(args.variant)
+        pt.SetFrameBatch(args.frame_batch)
+        if env_name == "atmosphere256":   # MainWindow.cs:174-175,189
+            pt.EnvironmentMap = pkg.AtmosphericScatterer(256, pkg.camera.atmospheric_data_ubo(), pkg.camera.atmosphere_light_pos(0.5), pt)
+        elif env_name == "sky2048":       # MainWindow.cs:177-187 shape, synthetic content
+            pt.EnvironmentMap = pkg.envmap.synthetic_sky_srgb8(2048)
+        else:
+            pt.EnvironmentMap = pkg.envmap.synthetic_sky_rgba32f(64)
+        pt.UploadScene(scene)
+        pt.UploadBasicData(basic)
+        tile = D.attach_tile(pt, H, rank, world, device=torch.device("cuda", local), band_rows=BAND)
+        rows = pt.rows
 
-    def sync_all():
-        pt.Synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        def gather_image():
+            if args.share_gpu and world > 1:  # gloo cannot gather CUDA tensors: stage through the host
+                out = D.present(tile.cpu(), H, rank, world, band_rows=BAND)
+                return out.cuda() if out is not None else None
+            return D.present(tile, H, rank, world, band_rows=BAND)
 
-    # Clock warm-up (NOT counted as steps): the GPU needs ~40 ms of load to leave its idle clock; render for a fixed wall
-    # time, then restart the accumulation so that the W warm-up steps and the K timed steps start from frame 0.
-    if args.clock_warmup_ms > 0:
-        t_w = time.perf_counter()
-        while (time.perf_counter() - t_w) * 1e3 < args.clock_warmup_ms:
-            for _ in range(16):
-                pt.Render()
+        def sync_all():
             pt.Synchronize()
-        pt.ResetRenderer()
-    for _ in range(args.warmup):
-        pt.Render()
-    if world > 1:  # first RCCL call (communicator setup) outside the timed region; also validates the gather
-        gather_image()
-    sync_all()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
 
-    t0 = time.perf_counter()
-    pt.TimerBegin()
-    for _ in range(args.steps):
-        pt.Render()
-    kernel_ms_total = pt.TimerEnd()   # HIP events on the kernel's own stream; also drains it
-    sync_all()
-    elapsed = time.perf_counter() - t0
+        # Clock warm-up (NOT counted as steps): the GPU needs ~40 ms of load to leave its idle clock; render for a fixed
+        # wall time, then restart the accumulation so that the W warm-up steps and the K timed steps start from frame 0.
+        if clock_warmup_ms > 0:
+            t_w = time.perf_counter()
+            while (time.perf_counter() - t_w) * 1e3 < clock_warmup_ms:
+                for _ in range(16):
+                    pt.Render()
+                pt.Synchronize()
+            pt.ResetRenderer()
+        for _ in range(warmup):
+            pt.Render()
+        pt.Synchronize()  # every warm-up frame has reached the tile before torch / RCCL read it
+        if world > 1:  # first RCCL call (communicator setup) outside the timed region; also validates the gather
+            gather_image()
+        sync_all()
 
-    t1 = time.perf_counter()
-    full = gather_image()
-    torch.cuda.synchronize()
-    present_ms = (time.perf_counter() - t1) * 1e3
+        t0 = time.perf_counter()
+        pt.TimerBegin()
+        for _ in range(steps):
+            pt.Render()
+        kernel_ms_total = pt.TimerEnd()   # HIP events on the kernel's own stream; also drains it
+        sync_all()
+        elapsed = time.perf_counter() - t0
 
-    times = torch.tensor([elapsed, kernel_ms_total / 1e3], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
-    if world > 1:
-        dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    elapsed_max, kernel_s_max = (float(v) for v in times.cpu())
+        t1 = time.perf_counter()
+        full = gather_image()
+        torch.cuda.synchronize()
+        present_ms = (time.perf_counter() - t1) * 1e3
+
+        times = torch.tensor([elapsed, kernel_ms_total / 1e3], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
+        if world > 1:
+            dist.all_reduce(times, op=dist.ReduceOp.MAX)
+        elapsed_max, kernel_s_max = (float(v) for v in times.cpu())
+        res = None
+        if rank == 0:
+            assert full is not None and tuple(full.shape) == (H, W, 4)
+            res = {"W": W, "H": H, "rows": rows, "steps": steps, "elapsed": elapsed_max, "kernel_s": kernel_s_max, "present_ms": present_ms,
+                   "checks": {"finite": bool(torch.isfinite(full).all().item()), "alpha_one": bool((full[..., 3] == 1).all().item()),
+                              "mean_radiance": round(float(full[..., :3].mean().item()), 5)},
+                   "basic": basic, "env_cpu": (pt.ReadEnvironment() if env_name != "sky2048" else None)}
+        del full
+        pt.Dispose()
+        return res
+
+    if args.strong_4k:
+        W, H, scaling = 3840, 2160, "strong"
+    elif args.weak:
+        (W, H), scaling = weak_image_size(world), "weak"
+    else:
+        W, H, scaling = 1920, 1080, "strong"  # the metric's image, split N ways (N = 1: the whole image on one GPU)
+    m = measure(W, H, args.steps, args.warmup, args.clock_warmup_ms)
+    m4k = None
+    if world > 1 and not (args.strong_4k or args.weak or args.no_4k):
+        # BASELINE configs[3]: ONE 3840x2160 image over the N GPUs, same run, shorter (the clocks are warm)
+        steps4k = max(64, (args.steps // 4) // 64 * 64)
+        m4k = measure(3840, 2160, steps4k, max(64, (args.warmup // 4) // 64 * 64), 0.0)
 
     if rank == 0:
-        assert full is not None and tuple(full.shape) == (H, W, 4)
-        checks = {"finite": bool(torch.isfinite(full).all().item()), "alpha_one": bool((full[..., 3] == 1).all().item()),
-                  "mean_radiance": round(float(full[..., :3].mean().item()), 5)}
+        W, H, rows = m["W"], m["H"], m["rows"]
         samples = W * H * args.spp * args.steps
-        ms_per_step = elapsed_max * 1e3 / args.steps
-        kernel_ms = kernel_s_max * 1e3 / args.steps
-        algo_bytes = ALGO_BYTES_PER_PIXEL_FRAME * W * rows  # per launch on one GPU (rank 0's row block)
+        ms_per_step = m["elapsed"] * 1e3 / args.steps
+        kernel_ms = m["kernel_s"] * 1e3 / args.steps
+        algo_bytes = ALGO_BYTES_PER_PIXEL_FRAME * W * rows  # per frame on one GPU (rank 0's rows)
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        wl_key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{args.spp}_{args.env}_g{world}" + (f"_variant{args.variant}" if args.variant else "") + (f"_fb{args.frame_batch}" if args.frame_batch != 64 else "") + ("_strong4k" if args.strong_4k else "")
+        wl_key = f"{scene_name}_{W}x{H}_d{depth}_spp{args.spp}_{env_name}_g{world}" + (f"_variant{args.variant}" if args.variant else "") + (f"_fb{args.frame_batch}" if args.frame_batch != 64 else "") + ("_strong4k" if args.strong_4k else "") + ("_weak" if args.weak and world > 1 else "")
+        if world == 1:
+            where = "one GPU" + (f" (BASELINE configs[{baseline_index}])" if baseline_index is not None and (W, H) == (1920, 1080) else "")
+        else:
+            where = (f"ONE image row-tiled over {world} GPUs, {rows} rows per GPU in block-cyclic {BAND}-row bands"
+                     + (" (BASELINE configs[3])" if (W, H) == (3840, 2160) and baseline_index == 1 else "")
+                     + (" (the metric's 1080p image, strong scaling)" if (W, H) == (1920, 1080) and baseline_index == 1 else ""))
+        traffic, traffic_note = load_profile_number("traffic.json", wl_key, csrc_hash)
         out = {
             "metric": "Msamples/sec + ms/frame @1080p 8-bounce default scene, 1/2/4/8 GPU",
-            "value": round(samples / elapsed_max / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong" if args.strong_4k else "weak",
+            "value": round(samples / m["elapsed"] / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene} scene ({scene.num_spheres} spheres + {scene.num_cuboids} cuboids), {W}x{H}, "
-                                   f"{args.depth} bounces, {args.spp} spp, progressive accumulate, env {args.env}, "
-                                   + (f"{rows} rows per GPU in block-cyclic {BAND}-row bands" if world > 1
-                                      else "one GPU (BASELINE configs[1])"),
-                       "image": [W, H], "ray_depth": args.depth, "spp": args.spp, "parallelism": f"rowbands{world}",
-                       "kernel_variant": args.variant},
+            "config": {"workload": f"{scene_name} scene ({scene.num_spheres} spheres + {scene.num_cuboids} cuboids), {W}x{H}, "
+                                   f"{depth} bounces, {args.spp} spp, progressive accumulate, env {env_name}, {where}",
+                       "image": [W, H], "ray_depth": depth, "spp": args.spp, "parallelism": f"rowbands{world}",
+                       "kernel_variant": args.variant, "csrc_hash": csrc_hash},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         # measured HBM bytes per LAUNCH (calibrated PMC passes, profiles/traffic.json holds bytes per frame)
-                         "traffic": (load_traffic(wl_key) * frames_per_launch if load_traffic(wl_key) else None),
-                         "traffic_per_frame": load_traffic(wl_key),
+                         # measured HBM bytes per LAUNCH (calibrated PMC passes; profiles/traffic.json holds bytes per frame)
+                         "traffic": (traffic * frames_per_launch if traffic else None),
+                         "traffic_per_frame": traffic,
+                         "traffic_ratio_to_algorithmic": (round(traffic / algo_bytes, 3) if traffic else None),
                          "kernel": "pt_integrate_persistent_kernel", "kernel_ms": round(kernel_ms, 5),
                          "launches_per_step": (1.0 / frames_per_launch if frames_per_launch > 1 else
                                                (2 if args.variant == 0 else (args.variant // 10 if 20 <= args.variant < 50 else 1))),
@@ -262,23 +339,39 @@ def main():
                                  "= frames_per_launch x kernel_ms; achieved = algorithmic_bytes_per_launch / that duration). "
                                  "--frame-batch 1 launches every frame on its own (2 overlapping row-stripe launches). "
                                  "The path is fp32-VALU bound, see `valu_issue`"},
-            "present_ms": round(present_ms, 3),
+            "present_ms": round(m["present_ms"], 3),
             "clock_warmup_ms": args.clock_warmup_ms,
-            "checks": checks,
+            "checks": m["checks"],
         }
-        vi = load_valu_insts(wl_key)
+        if traffic_note:
+            out["roofline"]["traffic_note"] = traffic_note
+        vi, vi_note = load_profile_number("valu_insts.json", wl_key, csrc_hash)
         if vi:
             rate = vi / (kernel_ms * 1e-3) / 1e9
             out["roofline"]["valu_issue"] = {"wave_insts_per_step": vi, "achieved": round(rate, 1), "peak": round(VALU_ISSUE_PEAK_GINST, 1),
                                               "unit": "G wave-instructions/s", "frac": round(rate / VALU_ISSUE_PEAK_GINST, 4),
                                               "note": "the binding roof: SQ_INSTS_VALU per step (rocprofv3 PMC pass committed under "
-                                                      "profiles/) / kernel time, against one wave64 VALU instruction per 2 clocks "
-                                                      "per SIMD (the rate behind the 157.3 TFLOP/s FP32 vector peak); a pure "
-                                                      "v_fma_f32 stream sustains 2.63 clocks (tools/ubench2.hip)"}
+                                                      "profiles/, same kernel sources: csrc_hash) / kernel time, against one wave64 VALU "
+                                                      "instruction per 2 clocks per SIMD (the rate behind the 157.3 TFLOP/s FP32 vector "
+                                                      "peak); a pure v_fma_f32 stream sustains 2.63 clocks (tools/ubench2.hip)"}
+        elif vi_note:
+            out["roofline"]["valu_issue"] = None
+            out["roofline"]["valu_issue_note"] = vi_note
+        if m4k is not None:
+            k4 = m4k["kernel_s"] * 1e3 / m4k["steps"]
+            a4 = ALGO_BYTES_PER_PIXEL_FRAME * 3840 * m4k["rows"] / (k4 * 1e-3) / 1e9
+            out["configs3_4k"] = {
+                "workload": f"{scene_name} scene, 3840x2160, {depth} bounces, {args.spp} spp, ONE image row-tiled over {world} GPUs "
+                            f"({m4k['rows']} rows per GPU, block-cyclic {BAND}-row bands), RCCL gather at present (BASELINE configs[3])",
+                "value": round(3840 * 2160 * args.spp * m4k["steps"] / m4k["elapsed"] / 1e6, 2), "unit": "Msamples/s",
+                "ms_per_step": round(m4k["elapsed"] * 1e3 / m4k["steps"], 5), "steps": m4k["steps"], "scaling": "strong",
+                "kernel_ms": round(k4, 5), "present_ms": round(m4k["present_ms"], 3), "checks": m4k["checks"],
+                "roofline_frac_hbm": round(a4 / HBM_PEAK_GBS, 5)}
         mean_bounces = None
         if world == 1 and not args.no_cpu_baseline:
-            env_cpu = pt.ReadEnvironment() if args.env != "sky2048" else pkg.envmap.synthetic_sky_srgb8(2048)
-            out["cpu_baseline"], mean_bounces = cpu_baseline(pkg, scene, basic, env_cpu, W, H, args.depth, args.spp)
+            env_cpu = m["env_cpu"] if env_name != "sky2048" else pkg.envmap.synthetic_sky_srgb8(2048)
+            wl_name = {("default", 8, "atmosphere256"): "C2_default_1080p_d8_atmo"}.get((scene_name, depth, env_name)) if (W, H) == (1920, 1080) and args.spp == 1 else None
+            out["cpu_baseline"], mean_bounces = cpu_baseline(pkg, scene, m["basic"], env_cpu, W, H, depth, args.spp, wl_name)
         if mean_bounces is not None:
             fl = flops_per_sample(mean_bounces, scene.num_spheres, scene.num_cuboids)
             tf = fl * (W * rows * args.spp) / (kernel_ms * 1e-3) / 1e12
@@ -287,7 +380,6 @@ def main():
                                        "frac": round(tf / FP32_VALU_PEAK_TF, 4)}
         print(json.dumps(out), flush=True)
 
-    pt.Dispose()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

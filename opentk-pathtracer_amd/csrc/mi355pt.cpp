@@ -79,13 +79,21 @@ int join_stripes(pt_handle h)
 int check_handover(pt_handle h)
 {
     if (!h->batchLaunched) return PT_OK;
-    unsigned int err = 0;
-    PT_HIP(h, hipMemcpy(&err, h->dQueue + 1, sizeof(err), hipMemcpyDeviceToHost));
     h->batchLaunched = false;
-    if (err) {
-        PT_HIP(h, hipMemset(h->dQueue + 1, 0, sizeof(err)));
+    if (h->hostErrWord && *(volatile unsigned int *)h->hostErrWord) {
+        *(volatile unsigned int *)h->hostErrWord = 0;
         return fail(h, PT_E_HIP, "frame pipelining: a pixel's previous frame never arrived (result is not trustworthy)");
     }
+    return PT_OK;
+}
+
+// Stripe streams are created on first use: HIP multiplexes streams onto a few hardware queues (4 by default), and an idle
+// extra stream would make the copy stream of the non-blocking present share a queue with a stripe (in-order: the stripe's
+// kernel would wait behind the copy).  The default frame uses 2 stripes: main + 2 stripes + copy = 4 streams.
+int ensure_stripe(pt_handle h, int j)
+{
+    if (!h->stripeStream[j]) PT_HIP(h, hipStreamCreateWithFlags(&h->stripeStream[j], hipStreamNonBlocking));
+    if (!h->stripeDone[j]) PT_HIP(h, hipEventCreateWithFlags(&h->stripeDone[j], hipEventDisableTiming));
     return PT_OK;
 }
 } // namespace ptimpl
@@ -177,10 +185,6 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     PT_CREATE_HIP(hipSetDevice(device_id));
     PT_CREATE_HIP(hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking));
     h->stream = h->ownStream;
-    for (int j = 0; j < ptimpl::kMaxStripes; j++) {
-        PT_CREATE_HIP(hipStreamCreateWithFlags(&h->stripeStream[j], hipStreamNonBlocking));
-        PT_CREATE_HIP(hipEventCreateWithFlags(&h->stripeDone[j], hipEventDisableTiming));
-    }
     PT_CREATE_HIP(hipEventCreateWithFlags(&h->inputsReady, hipEventDisableTiming));
     PT_CREATE_HIP(hipEventCreateWithFlags(&h->mainDone, hipEventDisableTiming));
     PT_CREATE_HIP(hipEventCreateWithFlags(&h->gatherReady, hipEventDisableTiming));
@@ -192,6 +196,9 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     PT_CREATE_HIP(hipMalloc((void **)&h->dLut, 256 * sizeof(float)));
     PT_CREATE_HIP(hipMalloc((void **)&h->dQueue, 64 * sizeof(unsigned int)));
     PT_CREATE_HIP(hipMemsetAsync(h->dQueue, 0, 64 * sizeof(unsigned int), h->stream));
+    PT_CREATE_HIP(hipHostMalloc((void **)&h->hostErrWord, sizeof(unsigned int), hipHostMallocMapped));
+    *h->hostErrWord = 0;
+    PT_CREATE_HIP(hipHostGetDevicePointer((void **)&h->devErrWord, h->hostErrWord, 0));
     {
         hipDeviceProp_t prop;
         PT_CREATE_HIP(hipGetDeviceProperties(&prop, device_id));
@@ -235,6 +242,7 @@ PT_API int pt_destroy(pt_handle h)
     if (h->dObjects) (void)hipFree(h->dObjects);
     if (h->dLut) (void)hipFree(h->dLut);
     if (h->dQueue) (void)hipFree(h->dQueue);
+    if (h->hostErrWord) (void)hipHostFree(h->hostErrWord);
     if (h->dEnv) (void)hipFree(h->dEnv);
     if (h->dAccum) (void)hipFree(h->dAccum);
     if (h->dRgba8) (void)hipFree(h->dRgba8);
@@ -438,6 +446,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     a.localRow0 = 0;
     a.numCUs = h->numCUs;
     a.queueChunk = h->queueChunk;
+    a.errorWord = h->devErrWord;
     a.timeline = h->dTimeline;
 
     // variant -> (kernel variant, stripes): 0 = default (2 stripes x 5 workgroups/CU); 20+k / 30+k / 40+k = 2 / 3 / 4
@@ -483,6 +492,9 @@ int launch_frames(pt_handle h, int firstFrame, int n)
             a.tilesY = (a.rows + 7) / 8;
             a.queue = h->dQueue + 16 * j;
             a.queueBase = h->stripeQueueBase[j];
+            if (int rc = ptimpl::ensure_stripe(h, j)) return rc;
+            h->stripeRow0[j] = r0;
+            h->stripeRows[j] = r1 - r0;
             PT_HIP(h, hipStreamWaitEvent(h->stripeStream[j], h->inputsReady, 0));
             unsigned int tickets = 0;
             PT_HIP(h, pt::launch_integrate(a, h->stripeStream[j], &tickets));
@@ -575,7 +587,6 @@ int ensure_slot_device(pt_handle h, int slot, size_t pixels)
 int ensure_slot_host(pt_handle h, int slot, size_t pixels)
 {
     PresentSlot &s = h->slots[slot];
-    if (!s.hostErr) PT_HIP(h, hipHostMalloc((void **)&s.hostErr, sizeof(unsigned int), hipHostMallocDefault));
     if (pixels > s.hostPixels) {
         if (s.host) {
             if (s.copied && s.inFlight) PT_HIP(h, hipEventSynchronize(s.copied));
@@ -595,7 +606,6 @@ void free_slots(pt_handle h)
     for (PresentSlot &s : h->slots) {
         if (s.dRgba8) (void)hipFree(s.dRgba8);
         if (s.host) (void)hipHostFree(s.host);
-        if (s.hostErr) (void)hipHostFree(s.hostErr);
         if (s.toneMapped) (void)hipEventDestroy(s.toneMapped);
         if (s.copied) (void)hipEventDestroy(s.copied);
         s = PresentSlot();
@@ -710,15 +720,31 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
     if (int rc = ptimpl::ensure_slot_events(h, slot)) return rc;
     if (int rc = ptimpl::ensure_slot_device(h, slot, pixels)) return rc;
     if (int rc = ptimpl::ensure_slot_host(h, slot, pixels)) return rc;
-    if (int rc = join_stripes(h)) return rc;
-    // the slot's previous copy must have left the device image before it is overwritten (device-side wait only)
-    if (s.inFlight) PT_HIP(h, hipStreamWaitEvent(h->stream, s.copied, 0));
-    PT_HIP(h, pt::launch_postprocess(h->accum(), s.dRgba8, pixels, h->stream));
-    PT_HIP(h, hipEventRecord(s.toneMapped, h->stream));
-    // later frames only wait for the tone-map pass (stream order); the PCIe copy runs beside them on the copy stream
-    PT_HIP(h, hipStreamWaitEvent(h->copyStream, s.toneMapped, 0));
+    if (int rc = flush_frames(h)) return rc;
+    bool striped = false;
+    for (int j = 0; j < ptimpl::kMaxStripes; j++) striped = striped || h->stripePending[j];
+    if (striped) {
+        // The last frame was launched as row stripes on their own streams.  Tone-map every stripe's rows ON ITS stream:
+        // stripe A's next frame then only waits for stripe A's own frame + tone map, never for the other stripe's drain
+        // (joining into the main stream here would put a device-wide barrier between consecutive displayed frames).
+        for (int j = 0; j < ptimpl::kMaxStripes; j++) {
+            if (!h->stripePending[j]) continue;
+            // the slot's previous copy must have left the device image before it is overwritten (device-side wait only)
+            if (s.inFlight) PT_HIP(h, hipStreamWaitEvent(h->stripeStream[j], s.copied, 0));
+            const size_t first = (size_t)h->stripeRow0[j] * h->width, count = (size_t)h->stripeRows[j] * h->width;
+            PT_HIP(h, pt::launch_postprocess(h->accum() + first, (char *)s.dRgba8 + first * 4, count, h->stripeStream[j]));
+            PT_HIP(h, hipEventRecord(h->stripeDone[j], h->stripeStream[j])); // "stripe done" now includes its tone map
+            PT_HIP(h, hipStreamWaitEvent(h->copyStream, h->stripeDone[j], 0));
+        }
+    } else {
+        if (int rc = join_stripes(h)) return rc;
+        if (s.inFlight) PT_HIP(h, hipStreamWaitEvent(h->stream, s.copied, 0));
+        PT_HIP(h, pt::launch_postprocess(h->accum(), s.dRgba8, pixels, h->stream));
+        PT_HIP(h, hipEventRecord(s.toneMapped, h->stream));
+        // later frames only wait for the tone-map pass (stream order); the PCIe copy runs beside them on the copy stream
+        PT_HIP(h, hipStreamWaitEvent(h->copyStream, s.toneMapped, 0));
+    }
     PT_HIP(h, hipMemcpyAsync(s.host, s.dRgba8, pixels * 4, hipMemcpyDeviceToHost, h->copyStream));
-    PT_HIP(h, hipMemcpyAsync(s.hostErr, h->dQueue + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, h->copyStream));
     PT_HIP(h, hipEventRecord(s.copied, h->copyStream));
     s.inFlight = true;
     s.valid = false;
@@ -740,8 +766,8 @@ PT_API int pt_present_wait(pt_handle h, int slot, const uint8_t **out_host_rgba8
         PT_HIP(h, hipEventSynchronize(s.copied));
         s.inFlight = false;
         s.valid = true;
-        if (s.hostErr && *s.hostErr) {
-            *s.hostErr = 0;
+        if (h->hostErrWord && *(volatile unsigned int *)h->hostErrWord) { // the image's frames are complete: copy stream is behind them
+            *(volatile unsigned int *)h->hostErrWord = 0;
             return fail(h, PT_E_HIP, "frame pipelining: a pixel's previous frame never arrived (result is not trustworthy)");
         }
     }

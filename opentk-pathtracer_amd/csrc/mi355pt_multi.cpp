@@ -275,7 +275,6 @@ int group_present_async(pt_handle g, int slot)
     // gather + un-band + device-to-host copy on the root's COPY stream: the parts render on meanwhile
     if (int rc = gather_on_root(g, src, ready, 4, gs.dRgba8, &g->dAsyncStage, &g->asyncStageBytes, g->copyStream)) return rc;
     PT_HIP(g, hipMemcpyAsync(gs.host, gs.dRgba8, pixels * 4, hipMemcpyDeviceToHost, g->copyStream));
-    *gs.hostErr = 0; // the parts' hand-over words are reported by pt_synchronize / the blocking reads
     PT_HIP(g, hipEventRecord(gs.copied, g->copyStream));
     gs.inFlight = true;
     gs.valid = false;

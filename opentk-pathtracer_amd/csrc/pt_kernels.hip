@@ -694,7 +694,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                     v3 firr = v_add(V(0.0f, 0.0f, 0.0f), rad);
                     const bool force = retries > FRAME_RETRY_LIMIT;
                     if (try_resolve(pix, fj, firr, force)) {
-                        if (force) atomicOr(cold_args()->queue + 1, 1u); // error word next to the ticket counter
+                        if (force) atomicOr(cold_args()->errorWord, 1u); // host-visible error word
                         pix = -1;
                         pending = false;
                     } else {
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             if (pending) {
                 const bool force = retries > FRAME_RETRY_LIMIT;
                 if (try_resolve(pix, fj, irr, force)) {
-                    if (force) atomicOr(cold_args()->queue + 1, 1u);
+                    if (force) atomicOr(cold_args()->errorWord, 1u);
                     pix = -1;
                     pending = false;
                 } else {

@@ -32,6 +32,7 @@ struct FrameArgs {
     int tilesX, tilesY;     // 8x8-pixel tiles covering width x rows
     int variant;            // kernel variant for A/B runs; all variants are bit-identical in output
     unsigned int *queue;    // global chunk-ticket counter of the persistent kernel (monotonic across launches)
+    unsigned int *errorWord; // set to 1 when a frame hand-over of the pipelining gives up (host-visible memory)
     unsigned int queueBase; // value of *queue when this launch starts (every launch consumes exactly numChunks tickets)
     int numCUs;             // compute units of the device (grid sizing of persistent variants)
     int queueChunk;         // tiles per global ticket of the persistent kernel's queue

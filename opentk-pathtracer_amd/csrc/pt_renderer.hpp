@@ -24,7 +24,6 @@ struct PresentSlot {
     size_t devPixels = 0;         // capacity of dRgba8
     uint8_t *host = nullptr;      // pinned host image (absent on the parts of a group: only the group handle copies to the host)
     size_t hostPixels = 0;
-    unsigned int *hostErr = nullptr; // pinned copy of the frame-pipelining error word, taken with the image
     hipEvent_t toneMapped = nullptr; // recorded behind the tone-map pass on the handle's stream
     hipEvent_t copied = nullptr;     // recorded behind the device-to-host copy on the copy stream
     bool inFlight = false;        // a copy from dRgba8 / into host was enqueued and not yet waited for
@@ -50,6 +49,9 @@ struct pt_renderer {
     float *dObjects = nullptr;      // 26,624 B device copy of UBO 1
     float *dLut = nullptr;          // 256-entry sRGB table
     unsigned int *dQueue = nullptr; // global chunk-ticket counter of the persistent kernel (never reset: epoch scheme)
+    // error word of the frame pipelining: ONE page-locked host word the kernels can reach (mapped): it is only ever
+    // written when a hand-over fails, and the host reads it without a copy once the stream is drained
+    unsigned int *hostErrWord = nullptr, *devErrWord = nullptr;
     int queueChunk = 8;             // tiles per global ticket (PT_QUEUE_CHUNK overrides, for tuning runs)
     unsigned long long *dTimeline = nullptr; // tuning only (pt_debug_timeline)
     // Frame pipelining: consecutive pt_render calls are collected and launched as ONE batch kernel (see pt_kernels.hip)
@@ -81,6 +83,7 @@ struct pt_renderer {
     hipEvent_t stripeDone[ptimpl::kMaxStripes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t inputsReady = nullptr;
     bool stripePending[ptimpl::kMaxStripes] = {false, false, false, false};
+    int stripeRow0[ptimpl::kMaxStripes] = {0, 0, 0, 0}, stripeRows[ptimpl::kMaxStripes] = {0, 0, 0, 0}; // rows of the last launch
     unsigned int stripeQueueBase[ptimpl::kMaxStripes] = {0, 0, 0, 0};
     hipEvent_t evBegin = nullptr, evEnd = nullptr;
 
@@ -128,6 +131,7 @@ int bind_device(pt_handle h);
 int flush_frames(pt_handle h);  // launch the frames pt_render deferred
 int join_stripes(pt_handle h);  // flush + make h->stream wait for every helper stream
 int check_handover(pt_handle h); // frame-pipelining error word (call after the stream has been synchronised)
+int ensure_stripe(pt_handle h, int j); // create stripe stream j and its event on first use
 // tone map this handle's rows into `dst` (RGBA8, compact rows) on h->stream, behind every frame rendered so far
 int tone_map_into(pt_handle h, void *dst);
 // slot plumbing shared by the single and the group path

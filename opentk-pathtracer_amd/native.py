@@ -43,6 +43,18 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found: cannot build libmi355pt.so")
 
 
+def csrc_hash() -> str:
+    """Identity of the kernel + host sources and build flags a library is built from (first 12 hex digits of a SHA-1).
+    Profiles committed under profiles/ carry it, and bench.py refuses PMC numbers measured on other sources."""
+    import hashlib
+    h = hashlib.sha1()
+    for name in sorted(os.listdir(CSRC)):
+        h.update(name.encode())
+        h.update(open(os.path.join(CSRC, name), "rb").read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:12]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True

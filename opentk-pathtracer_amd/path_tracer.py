@@ -196,10 +196,19 @@ class PathTracer:
     def PresentWait(self, slot: int):
         """-> (image, frame_index): (rows, Width, 4) uint8 VIEW of the slot's pinned host image (valid until the next
         PresentAsync on that slot) and the number of frames it shows."""
-        ptr, pitch, frame = C.POINTER(C.c_uint8)(), C.c_size_t(), C.c_int()
-        check(self._lib.pt_present_wait(self._h, slot, C.byref(ptr), C.byref(pitch), C.byref(frame)), self._h)
-        assert pitch.value == self.Width * 4
-        img = np.ctypeslib.as_array(ptr, shape=(self.rows, self.Width, 4))
+        st = self.__dict__.setdefault("_present_state", {})
+        if "args" not in st:
+            st["args"] = (C.POINTER(C.c_uint8)(), C.c_size_t(), C.c_int())
+            st["views"] = {}
+        ptr, pitch, frame = st["args"]
+        rc = self._lib.pt_present_wait(self._h, slot, C.byref(ptr), C.byref(pitch), C.byref(frame))
+        if rc:
+            check(rc, self._h)
+        key = (slot, C.addressof(ptr.contents), self.rows, self.Width)
+        img = st["views"].get(key)
+        if img is None:  # one numpy view per pinned slot image (building it costs more than the call itself)
+            assert pitch.value == self.Width * 4
+            img = st["views"][key] = np.ctypeslib.as_array(ptr, shape=(self.rows, self.Width, 4))
         return img, frame.value
 
     def SetPartition(self, band_rows: int) -> None:

@@ -11,6 +11,7 @@ R=/root/repo
 TAG=${1:-r01}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
+python -c "import sys; sys.path.insert(0, '$R'); import __graft_entry__ as g; print(g.load_package().native.csrc_hash())" > $OUT/csrc_hash.txt
 cd /tmp
 BENCH="python $R/bench.py --steps 640 --warmup 320 --no-cpu-baseline ${@:2}"   # multiples of the 64-frame batch: every launch renders 32 frames
 CAL="python $R/bench.py --steps 640 --warmup 320 --no-cpu-baseline --depth 0 ${@:2}"

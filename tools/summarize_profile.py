@@ -12,6 +12,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd, key = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+# the profile is only valid for the kernel sources it was measured on: bench.py compares this stamp with the built library's.
+# profile_round.sh records the hash on the GPU box (gpurun_out/prof_<tag>/csrc_hash.txt); fall back to the current tree.
+_h = os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "csrc_hash.txt")
+CSRC_HASH = open(_h).read().strip() if os.path.exists(_h) else graft.load_package().native.csrc_hash()
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
@@ -49,7 +55,7 @@ known = 16.0 * pixels
 fetch_factor = known / (cal["FETCH_SIZE"] * 1024.0) if cal["FETCH_SIZE"] else None
 write_factor = known / (cal["WRITE_SIZE"] * 1024.0) if cal["WRITE_SIZE"] else None
 summary = {
-    "tag": tag, "workload": key, "launches_per_step": L,
+    "tag": tag, "workload": key, "csrc_hash": CSRC_HASH, "launches_per_step": L,
     "kernel_avg_ns_rocprof": float(kstats[0]["AverageNs"]) if kstats else None,
     "kernel_calls": int(kstats[0]["Calls"]) if kstats else None,
     "frames_per_launch": bench.get("roofline", {}).get("frames_per_launch", 1),
@@ -68,13 +74,13 @@ if pmc.get("FETCH_SIZE") and pmc.get("WRITE_SIZE") and fetch_factor and write_fa
                                                "algorithmic": 32.0 * pixels, "ratio_to_algorithmic": (rd + wr) / (32.0 * pixels)}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     t = json.load(open(tpath)) if os.path.exists(tpath) else {}
-    t[key] = round(rd + wr)
+    t[key] = {"value": round(rd + wr), "csrc_hash": CSRC_HASH}
     json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
 if pmc.get("SQ_INSTS_VALU"):
     # VALU wave-instructions per step: the numerator of bench.py's roofline.valu.issue (peak: tools/ubench2.hip)
     vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
     v = json.load(open(vpath)) if os.path.exists(vpath) else {}
-    v[key] = round(pmc["SQ_INSTS_VALU"])
+    v[key] = {"value": round(pmc["SQ_INSTS_VALU"]), "csrc_hash": CSRC_HASH}
     json.dump(v, open(vpath, "w"), indent=1, sort_keys=True)
 json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
