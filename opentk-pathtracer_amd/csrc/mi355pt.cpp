@@ -66,9 +66,10 @@ int join_stripes(pt_handle h)
 {
     if (h->pendingFrames > 0)
         if (int rc = flush_frames(h)) return rc;
+    h->mainDirty = true; // whoever joins is about to put other work on the main stream: the next striped frame orders behind it
     for (int j = 0; j < kMaxStripes; j++) {
         if (h->stripePending[j]) {
-            PT_HIP(h, hipStreamWaitEvent(h->stream, h->stripeDone[j], 0));
+            if (j > 0) PT_HIP(h, hipStreamWaitEvent(h->stream, h->stripeDone[j], 0)); // (stripe 0 runs on the main stream itself)
             h->stripePending[j] = false;
         }
     }
@@ -87,15 +88,18 @@ int check_handover(pt_handle h)
     return PT_OK;
 }
 
-// Stripe streams are created on first use: HIP multiplexes streams onto a few hardware queues (4 by default), and an idle
-// extra stream would make the copy stream of the non-blocking present share a queue with a stripe (in-order: the stripe's
-// kernel would wait behind the copy).  The default frame uses 2 stripes: main + 2 stripes + copy = 4 streams.
+// Stripe 0 of a striped frame runs on the handle's main stream, stripe j > 0 on helper stream j, created on first use.  HIP
+// multiplexes streams onto a few hardware queues (4 by default) and two streams that share a queue execute in order: the
+// fewer streams the library keeps busy, the smaller the chance that two of its concurrent launches (the two stripes, or a
+// stripe and the present copy) end up behind each other — the default frame needs main + 1 helper (+ the copy stream).
 int ensure_stripe(pt_handle h, int j)
 {
-    if (!h->stripeStream[j]) PT_HIP(h, hipStreamCreateWithFlags(&h->stripeStream[j], hipStreamNonBlocking));
+    if (j > 0 && !h->stripeStream[j]) PT_HIP(h, hipStreamCreateWithFlags(&h->stripeStream[j], hipStreamNonBlocking));
     if (!h->stripeDone[j]) PT_HIP(h, hipEventCreateWithFlags(&h->stripeDone[j], hipEventDisableTiming));
     return PT_OK;
 }
+
+hipStream_t stripe_stream(pt_handle h, int j) { return j == 0 ? h->stream : h->stripeStream[j]; }
 } // namespace ptimpl
 
 namespace {
@@ -479,7 +483,12 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     } else {
         // inputs uploaded on the main stream (scene, environment, clears) must be visible to the stripe streams;
         // a stripe's frame f+1 follows its own frame f in stream order, which is the only dependency between frames
-        PT_HIP(h, hipEventRecord(h->inputsReady, h->stream));
+        // (only when something other than stripe 0's own frames went onto the main stream since the last striped frame:
+        // stripe 0 runs there, and the helper stripes must not wait for ITS previous frame — overlapping one stripe's drain
+        // with the other's main phase is the point of the stripes)
+        const bool orderHelpers = h->mainDirty;
+        if (orderHelpers) PT_HIP(h, hipEventRecord(h->inputsReady, h->stream));
+        h->mainDirty = false;
         for (int j = 0; j < stripes; j++) {
             int r0 = (int)((long long)h->rows * j / stripes), r1 = (int)((long long)h->rows * (j + 1) / stripes);
             r0 &= ~7; // stripe boundaries on 8-row tile boundaries (the last stripe takes the ragged remainder)
@@ -495,11 +504,12 @@ int launch_frames(pt_handle h, int firstFrame, int n)
             if (int rc = ptimpl::ensure_stripe(h, j)) return rc;
             h->stripeRow0[j] = r0;
             h->stripeRows[j] = r1 - r0;
-            PT_HIP(h, hipStreamWaitEvent(h->stripeStream[j], h->inputsReady, 0));
+            hipStream_t st = ptimpl::stripe_stream(h, j);
+            if (j > 0 && orderHelpers) PT_HIP(h, hipStreamWaitEvent(st, h->inputsReady, 0));
             unsigned int tickets = 0;
-            PT_HIP(h, pt::launch_integrate(a, h->stripeStream[j], &tickets));
+            PT_HIP(h, pt::launch_integrate(a, st, &tickets));
             h->stripeQueueBase[j] += tickets;
-            PT_HIP(h, hipEventRecord(h->stripeDone[j], h->stripeStream[j]));
+            PT_HIP(h, hipEventRecord(h->stripeDone[j], st));
             h->stripePending[j] = true;
             h->stripeInFlight[j] = true;
         }
@@ -730,10 +740,11 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
         for (int j = 0; j < ptimpl::kMaxStripes; j++) {
             if (!h->stripePending[j]) continue;
             // the slot's previous copy must have left the device image before it is overwritten (device-side wait only)
-            if (s.inFlight) PT_HIP(h, hipStreamWaitEvent(h->stripeStream[j], s.copied, 0));
+            hipStream_t st = ptimpl::stripe_stream(h, j);
+            if (s.inFlight) PT_HIP(h, hipStreamWaitEvent(st, s.copied, 0));
             const size_t first = (size_t)h->stripeRow0[j] * h->width, count = (size_t)h->stripeRows[j] * h->width;
-            PT_HIP(h, pt::launch_postprocess(h->accum() + first, (char *)s.dRgba8 + first * 4, count, h->stripeStream[j]));
-            PT_HIP(h, hipEventRecord(h->stripeDone[j], h->stripeStream[j])); // "stripe done" now includes its tone map
+            PT_HIP(h, pt::launch_postprocess(h->accum() + first, (char *)s.dRgba8 + first * 4, count, st));
+            PT_HIP(h, hipEventRecord(h->stripeDone[j], st)); // "stripe done" now includes its tone map
             PT_HIP(h, hipStreamWaitEvent(h->copyStream, h->stripeDone[j], 0));
         }
     } else {

@@ -82,6 +82,7 @@ struct pt_renderer {
     hipStream_t stripeStream[ptimpl::kMaxStripes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t stripeDone[ptimpl::kMaxStripes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t inputsReady = nullptr;
+    bool mainDirty = true; // work other than stripe 0's frames was put on the main stream since the last striped frame
     bool stripePending[ptimpl::kMaxStripes] = {false, false, false, false};
     int stripeRow0[ptimpl::kMaxStripes] = {0, 0, 0, 0}, stripeRows[ptimpl::kMaxStripes] = {0, 0, 0, 0}; // rows of the last launch
     unsigned int stripeQueueBase[ptimpl::kMaxStripes] = {0, 0, 0, 0};
@@ -131,7 +132,8 @@ int bind_device(pt_handle h);
 int flush_frames(pt_handle h);  // launch the frames pt_render deferred
 int join_stripes(pt_handle h);  // flush + make h->stream wait for every helper stream
 int check_handover(pt_handle h); // frame-pipelining error word (call after the stream has been synchronised)
-int ensure_stripe(pt_handle h, int j); // create stripe stream j and its event on first use
+int ensure_stripe(pt_handle h, int j); // create stripe stream j (j > 0) and its event on first use
+hipStream_t stripe_stream(pt_handle h, int j); // stripe 0 runs on the main stream
 // tone map this handle's rows into `dst` (RGBA8, compact rows) on h->stream, behind every frame rendered so far
 int tone_map_into(pt_handle h, void *dst);
 // slot plumbing shared by the single and the group path
