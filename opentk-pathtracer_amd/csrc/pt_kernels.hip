@@ -330,31 +330,6 @@ struct DrainControl {        // static LDS, one per workgroup
     unsigned int pad[3];
 };
 
-// ---- row combiner: coalesced read-modify-write of the accumulation image.
-// Paths of one 8x8 tile end after very different numbers of bounces, so resolving every finished path at once means one
-// scattered 16-byte load + store per pixel: every touch fetches (and later partially writes) a whole 128-byte line that
-// the L2 has long evicted — measured 1.96 x the algorithmic 32 B per pixel.  Each wavefront therefore owns a small
-// write-combining buffer in LDS, keyed by the 128-BYTE LINE of the accumulation image (8 consecutive pixels = one row of a
-// tile when the width is a multiple of 8) and the frame of the batch: a finished path only drops its radiance (12 B) into
-// its line's entry and frees its lane at once; an entry is written back when all 8 pixels have arrived (or it has aged),
-// by 8 lanes that load the line, fold the 8 radiances (compute.glsl:125-129) and store it — one full-line read and one
-// full-line write per 8 pixels.  Up to 8 entries go out per pass (64 lanes).  The frame hand-over of the pipelining (alpha
-// tags, see above) is checked per pixel at write-back time; pixels whose previous frame has not arrived stay in the entry,
-// so a lane never idles waiting for another frame any more.  The buffer is 2-way set-associative; a finished path that
-// finds both ways of its set taken falls back to the direct per-lane resolve (try_resolve).  Entries are self-contained
-// (line, frame, radiances), so it does not matter which wavefront writes a pixel back: bit-identical results.
-struct CombEntry {           // 8 bytes of control + 96 bytes of radiances per entry
-    unsigned int key;        // line index = pixel index >> 3; COMB_EMPTY = free
-    unsigned int meta;       // bits 0-7: pixels present, 8-15: pixels resolved elsewhere (direct resolve), 16-21: frame of the batch,
-                             // 22-29: time stamp, 30: a write-back had to wait
-};
-constexpr unsigned int COMB_EMPTY = 0xffffffffu;
-constexpr int COMB_AGE_LIMIT = 10;   // iterations after which an incomplete entry is written back anyway
-constexpr int COMB_RETRY_DELAY = 4;  // iterations between write-back attempts of an entry that waits for its previous frame
-PT_DEV unsigned int comb_frame(unsigned int meta) { return (meta >> 16) & 0x3fu; }
-PT_DEV unsigned int comb_meta(int rfj, int now) { return ((unsigned int)rfj << 16) | (((unsigned int)now & 0xffu) << 22); }
-__host__ __device__ constexpr size_t comb_bytes(int entries) { return (size_t)entries * (sizeof(CombEntry) + 8 * 3 * sizeof(float)); }
-
 //
 // SPP1 (one sample per pixel per frame, the usual case) adds the TILE PASS: the wavefront that refills its ring runs the
 // whole first bounce of the tile's 64 primary rays right there, all lanes together.  Primary rays of one tile are
@@ -363,7 +338,7 @@ __host__ __device__ constexpr size_t comb_bytes(int entries) { return (size_t)en
 // that handful; material / BSDF / environment code runs on coherent lanes too.  Paths that end at the first bounce are
 // resolved immediately, the survivors go to the ring as PathEntry records and are picked up by idle lanes of the
 // generic bounce loop.  Per path the arithmetic is unchanged (same tests in the same order, same RNG draws).
-template <int NWAVES, int MIN_WAVES_PER_SIMD, bool TIMELINE, bool SPP1, bool MATLDS, bool COMB>
+template <int NWAVES, int MIN_WAVES_PER_SIMD, bool TIMELINE, bool SPP1, bool MATLDS>
 __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_persistent_kernel(const FrameArgs a)
 {
     __shared__ __attribute__((aligned(16))) BlockQueue queue; // 16 B: keeps the dynamic-LDS base 16-byte aligned
@@ -397,17 +372,6 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     PathEntry *pring = (PathEntry *)(ringBase + wave * 64 * ENTRY_BYTES); //  SPP1: paths after their first bounce
     PathState *pool = (PathState *)(ringBase + NWAVES * 64 * ENTRY_BYTES);
     const bool compaction = a.drainCompaction != 0;
-    // row combiner of this wavefront (behind the rings and the drain pool): control words, then radiances [entry][pixel][rgb].
-    // Its geometry is re-derived from the kernarg segment where it is used (see cold_args: the bounce loop has no SGPRs to spare).
-    auto comb_entries = [&]() -> CombEntry * {
-        ColdArgs ca = cold_args();
-        return (CombEntry *)((char *)g_lds + ca->combinerOffset + wave * (int)comb_bytes(ca->combinerEntries));
-    };
-    if constexpr (COMB) {
-        if (lane < a.combinerEntries) comb_entries()[lane].key = COMB_EMPTY;
-        __builtin_amdgcn_wave_barrier();
-    }
-    int now = 0; // iteration counter (wave-uniform), the combiner's clock
     const int donateMax = a.drainCompaction < DONATE_MAX ? a.drainCompaction : DONATE_MAX; // a wavefront this thin donates
     const bool leader = lane == 0;
 
@@ -433,7 +397,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     // compute.glsl:125-129 for one finished path of frame `rfj` of the batch.  False = the pixel still holds an older
     // frame (only possible inside a batch): try again in the next iteration.
     // compute.glsl:125-129 for frame `rfj` of the batch: irradiance / SPP folded into the running mean, alpha = 1 (or the
-    // frame tag inside a batch)
+    // frame tag inside a batch).  The uniform inputs are re-read from the kernarg segment here (see cold_args).
     auto fold = [&](float4 last, v3 rirr, int rfj) -> float4 {
         ColdArgs ca = cold_args();
         rirr = v_scale(rirr, f_div_ieee(1.0f, (float)ca->spp));
@@ -441,6 +405,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         const float alpha = rfj == ca->batchFrames - 1 ? 1.0f : FRAME_TAG + (float)rfj; // (one frame per launch: rfj = 0 = last)
         return make_float4(f_mix(last.x, rirr.x, w), f_mix(last.y, rirr.y, w), f_mix(last.z, rirr.z, w), alpha);
     };
+    // False = the pixel still holds an older frame (only possible inside a batch): try again in the next iteration.
     auto try_resolve = [&](int rpix, int rfj, v3 rirr, bool force) -> bool {
         float4 *ptr = a.accum + rpix;
         if (a.batchFrames == 1) {
@@ -452,113 +417,6 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         if (rfj > 0 && !force && last.w != FRAME_TAG + (float)(rfj - 1)) return false;
         store_pixel_sc1(ptr, fold(last, rirr, rfj));
         return true;
-    };
-
-    // ---- row combiner (see the comment above the kernel).  Both functions are wave-level: call them convergently.
-    // combine_insert: lanes with `fin` drop (rpix, rfj, rirr) into the entry of their line; returns true for the lanes that
-    // found a place (the others resolve directly).
-    auto combine_insert = [&](bool fin, int rpix, int rfj, v3 rirr) -> bool {
-        if constexpr (!COMB) return false;
-        if (__ballot(fin) == 0ull) return false;
-        const int combW = cold_args()->combinerEntries;
-        if (combW == 0) return false;
-        CombEntry *cent = comb_entries();
-        float *cirr = (float *)(cent + combW);
-        const unsigned int k = (unsigned int)rpix >> 3, c = (unsigned int)rpix & 7u;
-        const unsigned int h = (k * 0x9E3779B1u) ^ ((unsigned int)rfj * 0x85EBCA6Bu);
-        const int base = 2 * (int)(((unsigned long long)h * (unsigned long long)(combW >> 1)) >> 32);
-        int slot = -1;
-        {   // round 1: find the line's entry, or claim a free way of its set
-            const CombEntry e0 = cent[base], e1 = cent[base + 1];
-            const bool m0 = e0.key == k && comb_frame(e0.meta) == (unsigned int)rfj;
-            const bool m1 = e1.key == k && comb_frame(e1.meta) == (unsigned int)rfj;
-            slot = !fin ? -1 : (m0 ? base : (m1 ? base + 1 : -1));
-            const int way = e0.key == COMB_EMPTY ? 0 : (e1.key == COMB_EMPTY ? 1 : -1);
-            if (fin && slot < 0 && way >= 0 && atomicCAS(&cent[base + way].key, COMB_EMPTY, k) == COMB_EMPTY) {
-                cent[base + way].meta = comb_meta(rfj, now);
-                slot = base + way;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (__ballot(fin && slot < 0) != 0ull) { // round 2: lanes that lost the claim to another lane of the SAME line find it now
-            const CombEntry e0 = cent[base], e1 = cent[base + 1];
-            const bool m0 = e0.key == k && comb_frame(e0.meta) == (unsigned int)rfj;
-            const bool m1 = e1.key == k && comb_frame(e1.meta) == (unsigned int)rfj;
-            if (fin && slot < 0) slot = m0 ? base : (m1 ? base + 1 : -1);
-        }
-        const bool placed = fin && slot >= 0;
-        if (placed) {
-            float *dst = cirr + (slot * 8 + (int)c) * 3;
-            dst[0] = rirr.x; dst[1] = rirr.y; dst[2] = rirr.z;
-            atomicOr(&cent[slot].meta, 1u << c);
-        }
-        __builtin_amdgcn_wave_barrier();
-        return placed;
-    };
-    // combine_flush: write back up to 8 entries (complete ones, aged ones, or — `all` — whatever is there).  `force`
-    // ignores a missing previous frame (after FRAME_RETRY_LIMIT attempts; raises the error word).
-    auto combine_flush = [&](bool all, bool force) -> void {
-        if constexpr (!COMB) return;
-        ColdArgs ca = cold_args();
-        const int combW = ca->combinerEntries;
-        if (combW == 0) return;
-        CombEntry *cent = comb_entries();
-        float *cirr = (float *)(cent + combW);
-        const long long lastPixel = (long long)ca->rows * ca->width - 1;
-        const unsigned int combLastLine = (unsigned int)(lastPixel >> 3), combTailMask = (1u << ((unsigned int)(lastPixel & 7) + 1u)) - 1u;
-        bool want = false;
-        if (lane < combW) {
-            const CombEntry e = cent[lane];
-            if (e.key != COMB_EMPTY) {
-                const unsigned int mask = e.meta & 0xffu, age = ((unsigned int)now - (e.meta >> 22)) & 0xffu;
-                const bool waited = (e.meta >> 30) & 1u;
-                const bool complete = (mask | ((e.meta >> 8) & 0xffu)) == (e.key == combLastLine ? combTailMask : 0xffu);
-                want = all || (complete && (!waited || age >= (unsigned int)COMB_RETRY_DELAY)) || age >= (unsigned int)COMB_AGE_LIMIT;
-            }
-        }
-        unsigned int sel = (unsigned int)__ballot(want);
-        if (sel == 0u) return;
-        const int g = lane >> 3, c = lane & 7;
-        int ei = -1;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (sel == 0u) break;
-            const int ej = (int)__builtin_ctz(sel);
-            sel &= sel - 1u;
-            if (g == j) ei = ej;
-        }
-        bool has = false, done = false;
-        CombEntry e = {COMB_EMPTY, 0u};
-        if (ei >= 0) {
-            e = cent[ei];
-            has = (e.meta >> c) & 1u;
-        }
-        if (has) {
-            const int rfj = (int)comb_frame(e.meta);
-            const float *src = cirr + (ei * 8 + c) * 3;
-            const v3 rirr = V(src[0], src[1], src[2]);
-            float4 *ptr = a.accum + ((size_t)e.key * 8 + (size_t)c);
-            if (a.batchFrames == 1) {
-                *ptr = fold(*ptr, rirr, 0);
-                done = true;
-            } else {
-                const float4 last = load_pixel_sc1(ptr);
-                if (rfj == 0 || force || last.w == FRAME_TAG + (float)(rfj - 1)) {
-                    store_pixel_sc1(ptr, fold(last, rirr, rfj));
-                    done = true;
-                }
-            }
-        }
-        if (done) atomicXor(&cent[ei].meta, (1u << c) | (1u << (c + 8))); // present -> resolved (the bit pair flips 01 -> 10)
-        const unsigned long long waiting = __ballot(has && !done);
-        __builtin_amdgcn_wave_barrier();
-        if (ei >= 0 && c == 0) { // one lane per entry: free it, or note that it has to wait for another frame
-            const unsigned int m = cent[ei].meta;
-            if ((m & 0xffu) == 0u) cent[ei].key = COMB_EMPTY;
-            else if ((waiting >> (g * 8)) & 0xffull) cent[ei].meta = (m & 0x3fffffu) | (((unsigned int)now & 0xffu) << 22) | (1u << 30);
-        }
-        if (force && lane == 0) atomicOr(cold_args()->errorWord, 1u); // a hand-over was given up (host-visible error word)
-        __builtin_amdgcn_wave_barrier();
     };
 
     for (;;) {
@@ -606,45 +464,25 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                                 tcont = bounce_step_t<true, MATLDS>(sc, a.numSpheres, a.numCuboids, env, to, td, tthr, trad, tseed, masks PROF_DUMMY);
                             if (1 >= a.rayDepth) tcont = false;
                             tkeep = tcont;
+                            if (!tcont) { // the path ended at its first bounce: compute.glsl:125-129 right away
+                                v3 tirr = v_add(V(0.0f, 0.0f, 0.0f), trad);
+                                tkeep = !try_resolve(tpix, tfj, tirr, false);
+                            }
                         }
-                        // 1. the paths that continue go to the ring
                         const unsigned long long cm = __ballot(tkeep);
                         if (tkeep) {
                             int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
                             PathEntry e;
-                            e.pix = tpix; e.bounce = 1 | (tfj << 16); e.seed = tseed;
+                            // a path whose resolve has to wait re-enters the bounce loop "at full depth": it is resolved there
+                            e.pix = tpix; e.bounce = (tcont ? 1 : a.rayDepth) | (tfj << 16); e.seed = tseed;
                             e.ro[0] = to.x; e.ro[1] = to.y; e.ro[2] = to.z;
                             e.rd[0] = td.x; e.rd[1] = td.y; e.rd[2] = td.z;
                             e.thr[0] = tthr.x; e.thr[1] = tthr.y; e.thr[2] = tthr.z;
                             e.rad[0] = trad.x; e.rad[1] = trad.y; e.rad[2] = trad.z;
                             pring[slot] = e;
                         }
-                        avail = __builtin_popcountll(cm);
-                        // 2. the paths that ended at their first bounce drop their radiance into the row combiner
-                        // (compute.glsl:125-129 happens at write-back); without a free entry they resolve directly, and if
-                        // that has to wait for the pixel's previous frame they re-enter the bounce loop "at full depth"
-                        // through the ring (they are resolved there)
-                        {
-                            const bool tfin = valid && !tcont;
-                            const v3 tirr = v_add(V(0.0f, 0.0f, 0.0f), trad);
-                            const bool placed = combine_insert(tfin, tpix, tfj, tirr);
-                            bool twait = false;
-                            if (tfin && !placed) twait = !try_resolve(tpix, tfj, tirr, false);
-                            const unsigned long long wm = __ballot(twait);
-                            if (wm != 0ull) {
-                                if (twait) {
-                                    int slot = avail + __builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u));
-                                    PathEntry e;
-                                    e.pix = tpix; e.bounce = a.rayDepth | (tfj << 16); e.seed = tseed;
-                                    e.ro[0] = e.ro[1] = e.ro[2] = 0.0f; e.rd[0] = e.rd[1] = 0.0f; e.rd[2] = 1.0f;
-                                    e.thr[0] = e.thr[1] = e.thr[2] = 1.0f;
-                                    e.rad[0] = trad.x; e.rad[1] = trad.y; e.rad[2] = trad.z;
-                                    pring[slot] = e;
-                                }
-                                avail += __builtin_popcountll(wm);
-                            }
-                        }
                         __builtin_amdgcn_wave_barrier(); // ring entries are read by other lanes of this wave below
+                        avail = __builtin_popcountll(cm);
 #ifdef PT_PROFILE
                         { // slot 6 = the tile pass (taken out of the feed slot)
                             const unsigned long long d_ = __builtin_readcyclecounter() - prof_tile0;
@@ -858,15 +696,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
 #ifdef PT_PROFILE
                 prof_t = __builtin_readcyclecounter();
 #endif
-            }
-            { // finished paths: into the row combiner (the lane is free at once); without a free entry, directly
-                const v3 firr = v_add(V(0.0f, 0.0f, 0.0f), rad);
-                const bool fin = active && pending;
-                const bool placed = combine_insert(fin, pix, fj, firr);
-                if (placed) {
-                    pix = -1;
-                    pending = false;
-                } else if (fin) {
+                if (pending) {
+                    v3 firr = v_add(V(0.0f, 0.0f, 0.0f), rad);
                     const bool force = retries > FRAME_RETRY_LIMIT;
                     if (try_resolve(pix, fj, firr, force)) {
                         if (force) atomicOr(cold_args()->errorWord, 1u); // host-visible error word
@@ -902,14 +733,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
 #ifdef PT_PROFILE
             prof_t = __builtin_readcyclecounter();
 #endif
-        }
-        {
-            const bool fin = active && pending;
-            const bool placed = combine_insert(fin, pix, fj, irr);
-            if (placed) {
-                pix = -1;
-                pending = false;
-            } else if (fin) {
+            if (pending) {
                 const bool force = retries > FRAME_RETRY_LIMIT;
                 if (try_resolve(pix, fj, irr, force)) {
                     if (force) atomicOr(cold_args()->errorWord, 1u);
@@ -922,20 +746,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         }
         if (__ballot(active && pending) != 0ull && __ballot(active && !pending) == 0ull) __builtin_amdgcn_s_sleep(8);
         } // !SPP1
-        combine_flush(false, false);
-        now++;
         PROF_MARK(7) // resolve
-    }
-    // ---- leaving: write back what the row combiner still holds (entries that wait for their pixel's previous frame are
-    // retried with a pause; the bounded retry count + error word rule out a hang, as for the direct resolve)
-    if (COMB && a.combinerEntries != 0) {
-        for (int spins = 0;; spins++) {
-            const unsigned long long occupied = __ballot(lane < a.combinerEntries && comb_entries()[lane].key != COMB_EMPTY);
-            if (occupied == 0ull) break;
-            combine_flush(true, spins > (FRAME_RETRY_LIMIT >> 6));
-            now += COMB_RETRY_DELAY;
-            if (spins > 8) __builtin_amdgcn_s_sleep(8);
-        }
     }
 #ifdef PT_PROFILE
     if (a.timeline && lane == 0)
@@ -947,6 +758,293 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     if (TIMELINE && lane == 0) {
         unsigned long long *t = a.timeline + ((size_t)blockIdx.x * NWAVES + wave) * 4;
         t[0] = tStart; t[1] = tExhausted; t[2] = wall_clock64(); t[3] = nIter;
+    }
+}
+
+// ---- spp > 1: the BATCH PASS kernel.
+// With several samples per pixel per frame the samples of a pixel form a chain: sample s+1 starts from the RNG state sample s
+// ended with (compute.glsl:106-124, one stream per pixel per frame), so a pixel's next primary ray can only be generated
+// when its previous path has ended — after a different number of bounces for every pixel.  Generating it right there
+// (the persistent kernel's spp > 1 path) runs the camera code and a full, unculled first bounce on a few lanes at a time.
+// Here a lane that finishes a sample instead parks the pixel's continuation (pixel, RNG state, radiance so far, sample
+// counter: 28 bytes) in its wavefront's LDS queue and takes other work; when the wavefront next runs out of ring
+// entries it turns up to 64 parked continuations — or a fresh 8x8 tile for sample 0 — into a BATCH PASS: 64 primary rays
+// and their whole first bounce with all lanes together, exactly like the spp = 1 tile pass.  The sphere culling needs no
+// tile structure: cull_spheres() bounds whatever 64 rays the wavefront holds (a wavefront's tiles are neighbours, and all
+// primary rays leave the lens), so every sample's first bounce — 1 / 2.7 of all rays cast — visits a handful of spheres
+// instead of all of them.  A continuation that finds the queue full falls back to the divergent in-lane primary ray.
+// Per pixel nothing changes: same samples in the same order on one RNG stream, irradiance summed in sample order -> the
+// image is bit-identical to every other variant.  Frames are pipelined exactly as in the spp = 1 kernel (alpha tags).
+struct PathEntryM { // 72 bytes: a path after its first bounce, plus what its pixel needs for the samples that follow
+    int pix;        // linear index into accum (the pixel's image coordinates are re-derived from it where a ray is generated)
+    int counters;   // bounces done | sample << 12 | frame of the batch << 24 ; bit 31: no ray yet (generate it in the lane)
+    uint32_t seed;
+    float ro[3], rd[3], thr[3], rad[3], irr[3];
+};
+struct ContEntry {  // 24 bytes: a pixel between two of its samples
+    int pix;
+    uint32_t seed;
+    int sfj;        // sample | frame of the batch << 16
+    float irr[3];
+};
+
+template <bool MATLDS>
+__global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const FrameArgs a)
+{
+    __shared__ __attribute__((aligned(16))) BlockQueue queue;
+    constexpr int NWAVES = 4;
+    const int numTilesFrame = a.tilesX * a.tilesY;
+    const int numTiles = numTilesFrame * a.batchFrames; // (frame, tile) pairs, frame-major
+    if (threadIdx.x == 0) {
+        long long first = (long long)blockIdx.x * a.queueChunk;
+        long long last = first + a.queueChunk < numTiles ? first + a.queueChunk : numTiles;
+        if (first >= numTiles || a.batchFrames > 1) { first = 0; last = 0; } // batches draw every chunk from the global counter
+        queue.pair = ((unsigned long long)last << 32) | (unsigned long long)first;
+        queue.lock = 0u;
+        queue.done = 0u;
+    }
+    SceneLds sc = stage_scene(a); // ends with __syncthreads()
+    EnvRef env{nullptr, (LdsFloats)sc.lut, 0, 0};
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    char *ringBase = (char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, a.materialsInLds != 0);
+    PathEntryM *ring = (PathEntryM *)ringBase + wave * 64;
+    const int CONT_BATCH_MIN = a.contBatchMin; // parked continuations that make a batch pass worth its ~950 instructions
+    const int parkCapacity = a.contCapacity; // per wavefront (whatever LDS is left next to scene and rings, see the launch)
+    ContEntry *cq = (ContEntry *)(ringBase + NWAVES * 64 * (int)sizeof(PathEntryM)) + wave * parkCapacity;
+    // image coordinates of accumulation pixel `p` of this launch: x | global row << 16
+    auto pixel_xy = [&](int p) -> int {
+        ColdArgs ca = cold_args();
+        const int ly = p / ca->width, x = p - ly * ca->width;
+        return x | (global_row_v(ca->bandRows, ca->bandWorld, ca->bandRank, ca->localRow0, ca->y0, ly) << 16);
+    };
+
+    int avail = 0, parked = 0; // wave-uniform: ring entries [0, avail), parked continuations [0, parked)
+    bool exhausted = false;
+    int pix = -1, sample = 0, bounce = 0, fj = 0, retries = 0;
+    bool needRay = false, pending = false;
+    uint32_t seed = 0;
+    v3 ro = V(0, 0, 0), rd = V(0, 0, 1), throughput = V(1, 1, 1), rad = V(0, 0, 0), irr = V(0, 0, 0);
+
+    auto fold = [&](float4 last, v3 rirr, int rfj) -> float4 { // compute.glsl:125-129
+        ColdArgs ca = cold_args();
+        rirr = v_scale(rirr, f_div_ieee(1.0f, (float)ca->spp));
+        const float w = f_div_ieee(1.0f, (float)(ca->frame + rfj + 1));
+        const float alpha = rfj == ca->batchFrames - 1 ? 1.0f : FRAME_TAG + (float)rfj;
+        return make_float4(f_mix(last.x, rirr.x, w), f_mix(last.y, rirr.y, w), f_mix(last.z, rirr.z, w), alpha);
+    };
+    auto try_resolve = [&](int rpix, int rfj, v3 rirr, bool force) -> bool {
+        float4 *ptr = a.accum + rpix;
+        if (a.batchFrames == 1) {
+            *ptr = fold(*ptr, rirr, 0);
+            return true;
+        }
+        float4 last = load_pixel_sc1(ptr);
+        if (rfj > 0 && !force && last.w != FRAME_TAG + (float)(rfj - 1)) return false;
+        store_pixel_sc1(ptr, fold(last, rirr, rfj));
+        return true;
+    };
+
+    for (;;) {
+        bool idle = pix < 0;
+        unsigned long long m = __ballot(idle);
+        for (int pass = 0; pass < 16 && m != 0ull; pass++) {
+            if (avail == 0) {
+                // ---- batch pass: 64 parked continuations, or the next tile's 64 pixels (sample 0)
+                const bool fromQueue = parked >= CONT_BATCH_MIN || (exhausted && parked > 0);
+                int tile = -1;
+                if (!fromQueue) {
+                    if (exhausted) break;
+                    tile = queue_pop_tile(&queue);
+                    if (tile < 0) {
+                        exhausted = true;
+                        continue; // (parked continuations, if any, are next)
+                    }
+                }
+                ColdArgs ca = cold_args();
+                ColdFloats cam = (ColdFloats)ca;
+                const int width = ca->width;
+                const float invW = f_div_ieee(1.0f, (float)width), invH = f_div_ieee(1.0f, (float)ca->height);
+                bool valid = false;
+                int tpix = 0, tpxy = 0, tsample = 0, tfj = 0;
+                uint32_t tseed = 0;
+                v3 tirr = V(0.0f, 0.0f, 0.0f);
+                if (fromQueue) {
+                    const int n = parked < 64 ? parked : 64;
+                    valid = lane < n;
+                    if (valid) {
+                        const ContEntry e = cq[parked - n + lane];
+                        tpix = e.pix; tpxy = pixel_xy(e.pix); tseed = e.seed;
+                        tsample = e.sfj & 0xffff; tfj = e.sfj >> 16;
+                        tirr = V(e.irr[0], e.irr[1], e.irr[2]);
+                    }
+                    parked -= n;
+                    __builtin_amdgcn_wave_barrier(); // the entries are read before this pass parks new ones in their place
+                } else {
+                    const int tilesX = ca->tilesX;
+                    tfj = tile / numTilesFrame;
+                    tile -= tfj * numTilesFrame;
+                    const int tx = tile % tilesX, ty = tile / tilesX;
+                    const int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+                    valid = x < width && ly < ca->rows;
+                    if (valid) {
+                        const int gy = global_row_v(ca->bandRows, ca->bandWorld, ca->bandRank, ca->localRow0, ca->y0, ly);
+                        tpix = ly * width + x;
+                        tpxy = x | (gy << 16);
+                        tseed = pixel_seed(x, gy, ca->frame + tfj);
+                    }
+                }
+                v3 to = V(0.0f, 0.0f, 0.0f), td = V(0.0f, 0.0f, 1.0f), tthr = V(1.0f, 1.0f, 1.0f), trad = V(0.0f, 0.0f, 0.0f);
+                if (valid) primary_ray_cam(cam, invW, invH, tpxy & 0xffff, tpxy >> 16, tseed, to, td);
+                unsigned long long masks[4];
+                cull_spheres(sc, a.numSpheres, valid, to, td, masks);
+                bool tcont = false;
+                if (valid) {
+                    if (0 < a.rayDepth) tcont = bounce_step_t<true, MATLDS>(sc, a.numSpheres, a.numCuboids, env, to, td, tthr, trad, tseed, masks);
+                    if (1 >= a.rayDepth) tcont = false;
+                }
+                // 1. paths that continue go to the ring
+                const unsigned long long cm = __ballot(tcont);
+                if (tcont) {
+                    const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+                    PathEntryM e;
+                    e.pix = tpix; e.counters = 1 | (tsample << 12) | (tfj << 24); e.seed = tseed;
+                    e.ro[0] = to.x; e.ro[1] = to.y; e.ro[2] = to.z;
+                    e.rd[0] = td.x; e.rd[1] = td.y; e.rd[2] = td.z;
+                    e.thr[0] = tthr.x; e.thr[1] = tthr.y; e.thr[2] = tthr.z;
+                    e.rad[0] = trad.x; e.rad[1] = trad.y; e.rad[2] = trad.z;
+                    e.irr[0] = tirr.x; e.irr[1] = tirr.y; e.irr[2] = tirr.z;
+                    ring[slot] = e;
+                }
+                avail = __builtin_popcountll(cm);
+                // 2. samples that ended at their first bounce: irradiance += Radiance (compute.glsl:122); more samples to go ->
+                // park the continuation; the pixel's last sample -> compute.glsl:125-129
+                const bool tfin = valid && !tcont;
+                if (tfin) {
+                    tirr = v_add(tirr, trad);
+                    tsample++;
+                }
+                const bool tmore = tfin && tsample < a.spp;
+                const unsigned long long pm = __ballot(tmore);
+                bool toRing = false; // overflow of the queue / a resolve that has to wait: through the ring, handled in the lane
+                int ringCounters = 0;
+                if (pm != 0ull) {
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
+                    const int room = parkCapacity - parked;
+                    if (tmore && rank < room) {
+                        ContEntry e;
+                        e.pix = tpix; e.seed = tseed; e.sfj = tsample | (tfj << 16);
+                        e.irr[0] = tirr.x; e.irr[1] = tirr.y; e.irr[2] = tirr.z;
+                        cq[parked + rank] = e;
+                    } else if (tmore) {
+                        toRing = true;
+                        ringCounters = (tsample << 12) | (tfj << 24) | (int)0x80000000; // no ray yet
+                    }
+                    const int n = __builtin_popcountll(pm);
+                    parked += n < room ? n : room;
+                }
+                if (tfin && !tmore && !try_resolve(tpix, tfj, tirr, false)) {
+                    toRing = true;
+                    ringCounters = a.rayDepth | (tsample << 12) | (tfj << 24); // "at full depth": resolved in the bounce loop
+                }
+                const unsigned long long wm = __ballot(toRing);
+                if (wm != 0ull) {
+                    if (toRing) {
+                        const int slot = avail + __builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u));
+                        PathEntryM e;
+                        e.pix = tpix; e.counters = ringCounters; e.seed = tseed;
+                        e.ro[0] = e.ro[1] = e.ro[2] = 0.0f; e.rd[0] = e.rd[1] = 0.0f; e.rd[2] = 1.0f;
+                        e.thr[0] = e.thr[1] = e.thr[2] = 1.0f;
+                        e.rad[0] = e.rad[1] = e.rad[2] = 0.0f;
+                        e.irr[0] = tirr.x; e.irr[1] = tirr.y; e.irr[2] = tirr.z;
+                        ring[slot] = e;
+                    }
+                    avail += __builtin_popcountll(wm);
+                }
+                __builtin_amdgcn_wave_barrier(); // ring / queue entries are read by other lanes of this wave below
+                if (avail == 0) continue;
+            }
+            // ---- idle lanes pop paths (top down)
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (idle && rank < avail) {
+                const PathEntryM e = ring[avail - 1 - rank];
+                pix = e.pix;
+                bounce = e.counters & 0xfff;
+                sample = (e.counters >> 12) & 0xfff;
+                fj = (e.counters >> 24) & 0x7f;
+                needRay = e.counters < 0;
+                pending = false;
+                retries = 0;
+                seed = e.seed;
+                ro = V(e.ro[0], e.ro[1], e.ro[2]);
+                rd = V(e.rd[0], e.rd[1], e.rd[2]);
+                throughput = V(e.thr[0], e.thr[1], e.thr[2]);
+                rad = V(e.rad[0], e.rad[1], e.rad[2]);
+                irr = V(e.irr[0], e.irr[1], e.irr[2]);
+                if (!needRay && bounce >= a.rayDepth && sample >= a.spp) pending = true; // a resolve that had to wait
+            }
+            const int n = __builtin_popcountll(m);
+            avail = n < avail ? avail - n : 0;
+            idle = pix < 0;
+            m = __ballot(idle);
+        }
+        const bool active = pix >= 0;
+        if (__ballot(active) == 0ull) {
+            if (exhausted && avail == 0 && parked == 0) break;
+            continue;
+        }
+        if (active && needRay) { // fallback (queue was full): the next sample's primary ray, generated in the lane
+            const int pxy = pixel_xy(pix);
+            primary_ray(a, pxy & 0xffff, pxy >> 16, seed, ro, rd);
+            throughput = V(1.0f, 1.0f, 1.0f);
+            rad = V(0.0f, 0.0f, 0.0f);
+            bounce = 0;
+            needRay = false;
+        }
+        bool wantPark = false;
+        if (active && !pending) {
+            bool cont = false;
+            if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr);
+            bounce++;
+            if (!cont || bounce >= a.rayDepth) {
+                irr = v_add(irr, rad); // compute.glsl:122
+                sample++;
+                if (sample < a.spp) wantPark = true;
+                else pending = true; // the pixel's last sample: fold into the accumulation image
+            }
+        }
+        // ---- park the pixels whose sample ended; the lane is free for other work
+        const unsigned long long pm = __ballot(wantPark);
+        if (pm != 0ull) {
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
+            const int room = parkCapacity - parked;
+            if (wantPark && rank < room) {
+                ContEntry e;
+                e.pix = pix; e.seed = seed; e.sfj = sample | (fj << 16);
+                e.irr[0] = irr.x; e.irr[1] = irr.y; e.irr[2] = irr.z;
+                cq[parked + rank] = e;
+                pix = -1;
+            } else if (wantPark) {
+                needRay = true;
+            }
+            const int n = __builtin_popcountll(pm);
+            parked += n < room ? n : room;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (pix >= 0 && pending) {
+            const bool force = retries > FRAME_RETRY_LIMIT;
+            if (try_resolve(pix, fj, irr, force)) {
+                if (force) atomicOr(cold_args()->errorWord, 1u);
+                pix = -1;
+                pending = false;
+            } else {
+                retries++;
+            }
+        }
+        { // nothing but waiting paths left in this wavefront: do not hammer the pixel
+            const bool act = pix >= 0;
+            if (__ballot(act && pending) != 0ull && __ballot(act && !pending) == 0ull && parked < CONT_BATCH_MIN && avail == 0)
+                __builtin_amdgcn_s_sleep(8);
+        }
     }
 }
 
@@ -971,7 +1069,6 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
 {
     FrameArgs a = args;
     a.materialsInLds = 1;
-    a.combinerEntries = 0;
     *ticketsConsumed = 0;
     int tiles = a.tilesX * a.tilesY;
     size_t lds = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, true);
@@ -991,18 +1088,24 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         if (nwg > numChunks) nwg = numChunks;
         if (nwg < 1) nwg = 1;
         const bool spp1 = a.spp == 1; // tile-pass kernels (the ring holds 60-byte paths instead of 40-byte primary rays)
-        // Row combiner (coalesced accumulation read-modify-write), an experiment kept for A/B runs: PT_COMBINER=<entries>
-        // (even, <= 32) selects the kernel instances compiled with it; 16 entries per wavefront fit next to the staged scene
-        // and the rings without costing a resident workgroup.
-        // Line indices are 32-bit keys: images beyond 2^35 bytes of accumulation fall back to the direct resolve.
-        static const int combinerEnv = std::getenv("PT_COMBINER") ? std::atoi(std::getenv("PT_COMBINER")) : -1;
-        int combW = combinerEnv > 0 ? (combinerEnv & ~1) : 0; // default: off (measured: less traffic, less throughput — DESIGN.md)
-        if (combW > 32) combW = 32;
-        if ((long long)a.rows * a.width >= (1ll << 31) || !spp1) combW = 0;
-        a.combinerEntries = combW;
-        a.combinerOffset = 0; // filled in below, once the scene layout (materials in LDS or not) is decided
-        const size_t queues = (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) : sizeof(RingEntry)) + (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0) // no pool without drain compaction
-                              + (size_t)waves * comb_bytes(combW);
+        // spp > 1: the batch-pass kernel (every sample's first bounce coherent and culled), unless drain compaction is asked
+        // for (single-launch frames of the A/B variants and of caller-owned streams keep the in-lane sample chain)
+        static const bool noBatchPass = std::getenv("PT_NO_BATCH_PASS") != nullptr; // A/B runs
+        const bool useBatchPass = !spp1 && a.drainCompaction == 0 && !noBatchPass;
+        // the continuation queues take what a 5-per-CU workgroup has left next to the scene and the rings (<= 128 entries per wavefront)
+        int park = 0;
+        if (useBatchPass) {
+            // (31 KB per workgroup: measured, a 32.3 KB workgroup no longer fits five times into the CU's 160 KB)
+            const long long left = 31ll * 1024 - (long long)lds - (long long)waves * 64 * (long long)sizeof(PathEntryM);
+            park = (int)(left / (long long)(waves * sizeof(ContEntry))) & ~7;
+            if (const char *pc = std::getenv("PT_PARK_CAPACITY")) park = std::atoi(pc) & ~7; // A/B runs
+            if (park > 128) park = 128;
+            if (park < 64) park = 64; // (then the scene's materials leave LDS below)
+        }
+        a.contCapacity = park;
+        a.contBatchMin = std::getenv("PT_PARK_MIN") ? std::atoi(std::getenv("PT_PARK_MIN")) : 40;
+        const size_t queues = useBatchPass ? (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry))
+                              : (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) : sizeof(RingEntry)) + (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0); // no pool without drain compaction
         size_t ldsTotal = lds + queues;
         // materials leave LDS when they would cost a resident workgroup (160 KB per CU; 64 B of static LDS per workgroup)
         const size_t ldsPerCU = 160 * 1024, fixedLds = 64;
@@ -1010,22 +1113,21 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         size_t wgFull = ldsPerCU / (ldsTotal + fixedLds), wgLean = ldsPerCU / (ldsLean + fixedLds);
         if (wgFull > (size_t)blocksPerCU) wgFull = (size_t)blocksPerCU;
         if (wgLean > (size_t)blocksPerCU) wgLean = (size_t)blocksPerCU;
-        static const bool forceLean = std::getenv("PT_FORCE_LEAN_LDS") != nullptr; // tuning: materials always from the UBO copy
+        static const bool forceLean = std::getenv("PT_FORCE_LEAN_LDS") != nullptr; // A/B runs: materials always from the UBO copy
         if (wgLean > wgFull || forceLean) {
             a.materialsInLds = 0;
             ldsTotal = ldsLean;
         }
-        a.combinerOffset = (int)(ldsTotal - (size_t)waves * comb_bytes(combW)); // the combiners are the tail of the dynamic LDS
-#define PT_LAUNCH_PERSISTENT(TL, S1, ML, CB) \
-    hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, (S1 ? 6 : 5), TL, S1, ML, CB>), dim3(nwg), dim3(256), ldsTotal, stream, a)
+#define PT_LAUNCH_PERSISTENT(TL, S1, ML) \
+    hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, (S1 ? 6 : 5), TL, S1, ML>), dim3(nwg), dim3(256), ldsTotal, stream, a)
         const bool matLds = a.materialsInLds != 0;
-        if (combW != 0 && spp1 && matLds) PT_LAUNCH_PERSISTENT(false, true, true, true); // row combiner (experiment, PT_COMBINER)
-        else if (combW != 0 && spp1) PT_LAUNCH_PERSISTENT(false, true, false, true);
-        else if (a.timeline && spp1 && matLds) PT_LAUNCH_PERSISTENT(true, true, true, false); // per-wavefront timestamps (tools/timeline.py)
-        else if (spp1 && matLds) PT_LAUNCH_PERSISTENT(false, true, true, false);
-        else if (spp1) PT_LAUNCH_PERSISTENT(false, true, false, false);
-        else if (matLds) PT_LAUNCH_PERSISTENT(false, false, true, false);
-        else PT_LAUNCH_PERSISTENT(false, false, false, false);
+        if (a.timeline && spp1 && matLds) PT_LAUNCH_PERSISTENT(true, true, true); // per-wavefront timestamps (tools/timeline.py)
+        else if (spp1 && matLds) PT_LAUNCH_PERSISTENT(false, true, true);
+        else if (spp1) PT_LAUNCH_PERSISTENT(false, true, false);
+        else if (useBatchPass && matLds) hipLaunchKernelGGL(pt_integrate_multisample_kernel<true>, dim3(nwg), dim3(256), ldsTotal, stream, a);
+        else if (useBatchPass) hipLaunchKernelGGL(pt_integrate_multisample_kernel<false>, dim3(nwg), dim3(256), ldsTotal, stream, a);
+        else if (matLds) PT_LAUNCH_PERSISTENT(false, false, true);
+        else PT_LAUNCH_PERSISTENT(false, false, false);
 #undef PT_LAUNCH_PERSISTENT
         // every workgroup draws tickets until its first failing one: (numChunks - nwg) successful + nwg failing
         // (a pipelined batch draws every chunk dynamically: numChunks successful + nwg failing)

@@ -38,8 +38,8 @@ struct FrameArgs {
     int queueChunk;         // tiles per global ticket of the persistent kernel's queue
     int drainCompaction;    // 0 = off; else a draining wavefront with at most this many live paths donates them (<= 48)
     int batchFrames;        // frames rendered by this launch (>= 1): frame, frame+1, ... over the same tiles (see the kernel's frame pipelining)
-    int combinerEntries;    // set by the launch: entries of each wavefront's row combiner (coalesced accumulation read-modify-write); 0 = off
-    int combinerOffset;     // set by the launch: byte offset of wavefront 0's combiner inside the dynamic LDS
+    int contCapacity;       // set by the launch (spp > 1 batch-pass kernel): parked continuations per wavefront
+    int contBatchMin;       // ... and how many of them make a batch pass worth running
     int materialsInLds;     // set by the launch: 1 = the 64-byte materials are staged in LDS, 0 = read from `objects` (large scenes)
     unsigned long long *timeline; // optional (tuning): per wavefront {start, queue exhausted, end, iterations} timestamps
 };
