@@ -345,6 +345,9 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     __shared__ __attribute__((aligned(16))) DrainControl drain; // 32 B
     const int numTilesFrame = a.tilesX * a.tilesY;
     const int numTiles = numTilesFrame * a.batchFrames;         // (frame, tile) pairs, frame-major
+    __shared__ float frameWeight[SPP1 ? MAX_BATCH_FRAMES : 1];  // 1 / (frame + j + 1): running-mean weight of the batch's frame j
+    if (SPP1 && (int)threadIdx.x < a.batchFrames && threadIdx.x < MAX_BATCH_FRAMES)
+        frameWeight[threadIdx.x] = f_div_ieee(1.0f, (float)(a.frame + (int)threadIdx.x + 1));
     if (threadIdx.x == 0) {
         // One frame per launch: the workgroup's first chunk is static (chunk index = workgroup index).  A pipelined batch
         // hands out EVERY chunk through the global counter instead: frames depend on each other per pixel, and a workgroup
@@ -400,8 +403,13 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     // frame tag inside a batch).  The uniform inputs are re-read from the kernarg segment here (see cold_args).
     auto fold = [&](float4 last, v3 rirr, int rfj) -> float4 {
         ColdArgs ca = cold_args();
-        rirr = v_scale(rirr, f_div_ieee(1.0f, (float)ca->spp));
-        const float w = f_div_ieee(1.0f, (float)(ca->frame + rfj + 1));
+        float w;
+        if constexpr (SPP1) { // irradiance / 1 is exact (x * 1.0f == x bit for bit): skipped; weight from the per-batch table
+            w = frameWeight[rfj];
+        } else {
+            rirr = v_scale(rirr, f_div_ieee(1.0f, (float)ca->spp));
+            w = f_div_ieee(1.0f, (float)(ca->frame + rfj + 1));
+        }
         const float alpha = rfj == ca->batchFrames - 1 ? 1.0f : FRAME_TAG + (float)rfj; // (one frame per launch: rfj = 0 = last)
         return make_float4(f_mix(last.x, rirr.x, w), f_mix(last.y, rirr.y, w), f_mix(last.z, rirr.z, w), alpha);
     };

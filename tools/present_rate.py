@@ -52,7 +52,18 @@ def nonblocking(i):
         checksum[0] += int(img[0, 0, 0])       # touch the image like a consumer would
 def drain_nb():
     pt.PresentWait((a.frames - 1) & 1)
-rate("render + pt_present_rgba8_async / pt_present_wait (double-buffered)", nonblocking, drain=lambda: None)
+rate("render + async present, two slots (wait for the other slot's frame)", nonblocking, drain=lambda: None)
+seen = [False, False]
+def nonblocking_reuse(i):
+    # the recommended double-buffered order: wait for a slot only when it is about to be reused (it holds frame i - 2:
+    # long landed), so the host never waits for a copy that is still in flight and stays two frames ahead of the display
+    pt.Render()
+    if seen[i & 1]:
+        img, idx = pt.PresentWait(i & 1)
+        checksum[0] += int(img[0, 0, 0])
+    pt.PresentAsync(i & 1)
+    seen[i & 1] = True
+rate("render + async present, two slots (wait for a slot before reusing it)", nonblocking_reuse)
 def nonblocking3(i):
     pt.Render()
     pt.PresentAsync(i % 3)
