@@ -253,6 +253,17 @@ struct PathEntry {
     float ro[3], rd[3], thr[3], rad[3];
 };
 
+// spp = 1, frame pipelining: a finished path whose pixel still holds an older frame used to keep its lane until the
+// previous frame's resolve arrived.  It now PARKS the result (pixel, frame of the batch, radiance: 20 bytes) in its
+// wavefront's LDS list and frees the lane; the list is retried by the wavefront's first lanes once per iteration.  It
+// matters when a GPU owns few tiles per frame (a 1/8 share of a 1080p image has 4,050 tiles for 6,144 wavefronts, so
+// consecutive frames of one tile are in flight together all the time).
+struct ParkedResolve {
+    int pix, fj;
+    float irr[3];
+};
+constexpr int PARKED_MAX = 64;
+
 struct BlockQueue {            // one per workgroup, in static LDS
     unsigned long long pair;   // (end << 32) | cursor : absolute tile indices of the current chunk
     unsigned int lock;         // refill lock
@@ -375,6 +386,10 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     PathEntry *pring = (PathEntry *)(ringBase + wave * 64 * ENTRY_BYTES); //  SPP1: paths after their first bounce
     PathState *pool = (PathState *)(ringBase + NWAVES * 64 * ENTRY_BYTES);
     const bool compaction = a.drainCompaction != 0;
+    // parked resolves of this wavefront (pipelined spp = 1 launches only; behind the rings — such launches have no drain pool)
+    ParkedResolve *parkedList = (ParkedResolve *)(ringBase + NWAVES * 64 * ENTRY_BYTES) + wave * PARKED_MAX;
+    const bool parking = SPP1 && a.batchFrames > 1 && !compaction;
+    int nparked = 0, parkSpins = 0; // wave-uniform
     const int donateMax = a.drainCompaction < DONATE_MAX ? a.drainCompaction : DONATE_MAX; // a wavefront this thin donates
     const bool leader = lane == 0;
 
@@ -427,6 +442,43 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         return true;
     };
 
+    // park the results of the lanes with `want` (as many as fit); returns true for the lanes that were parked
+    auto park_resolves = [&](bool want, int rpix, int rfj, v3 rirr) -> bool {
+        const unsigned long long wm = __ballot(want);
+        if (wm == 0ull) return false;
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u));
+        const int room = PARKED_MAX - nparked;
+        const bool fits = want && rank < room;
+        if (fits) {
+            ParkedResolve e;
+            e.pix = rpix; e.fj = rfj; e.irr[0] = rirr.x; e.irr[1] = rirr.y; e.irr[2] = rirr.z;
+            parkedList[nparked + rank] = e;
+        }
+        const int n = __builtin_popcountll(wm);
+        nparked += n < room ? n : room;
+        __builtin_amdgcn_wave_barrier();
+        return fits;
+    };
+    // retry the parked resolves: lane l takes entry l; the ones that still have to wait are compacted to the front
+    auto service_parked = [&](bool force) -> void {
+        if (nparked == 0) return;
+        const bool mine = lane < nparked;
+        ParkedResolve e = {0, 0, {0.0f, 0.0f, 0.0f}};
+        bool keep = false;
+        if (mine) {
+            e = parkedList[lane];
+            keep = !try_resolve(e.pix, e.fj, V(e.irr[0], e.irr[1], e.irr[2]), force);
+        }
+        const unsigned long long km = __ballot(keep);
+        __builtin_amdgcn_wave_barrier(); // every entry has been read before the survivors are written back
+        if (keep) parkedList[__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u))] = e;
+        const int left = __builtin_popcountll(km);
+        parkSpins = left == nparked ? parkSpins + 1 : 0;
+        nparked = left;
+        if (force && lane == 0) atomicOr(cold_args()->errorWord, 1u);
+        __builtin_amdgcn_wave_barrier();
+    };
+
     for (;;) {
         // ---- feed idle lanes: pop from the ring; if the ring runs dry while lanes are still idle, refill it with the next
         // tile and pop again in the SAME iteration (a lane never idles through a bounce iteration because the ring happened
@@ -476,6 +528,10 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                                 v3 tirr = v_add(V(0.0f, 0.0f, 0.0f), trad);
                                 tkeep = !try_resolve(tpix, tfj, tirr, false);
                             }
+                        }
+                        if (parking) { // resolves that have to wait for the previous frame: parked (else through the ring)
+                            const bool twait = valid && !tcont && tkeep;
+                            if (park_resolves(twait, tpix, tfj, v_add(V(0.0f, 0.0f, 0.0f), trad))) tkeep = false;
                         }
                         const unsigned long long cm = __ballot(tkeep);
                         if (tkeep) {
@@ -619,7 +675,11 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         bool active = pix >= 0;
         const unsigned long long am = __ballot(active);
         if (am == 0ull) {
-            if (!(exhausted && avail == 0)) continue;
+            if (parking && nparked > 0) { // nothing to trace: look after the parked resolves (they must be gone before leaving)
+                service_parked(parkSpins > FRAME_RETRY_LIMIT);
+                if (nparked > 0 && exhausted && avail == 0) __builtin_amdgcn_s_sleep(8);
+            }
+            if (!(exhausted && avail == 0 && nparked == 0)) continue;
             if (!compaction) break;
             // ---- leaving: the last wavefront of the workgroup must outlive every donor and empty the pool
             unsigned int old = 0;
@@ -716,8 +776,17 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                     }
                 }
             }
+            if (parking) {
+                // a resolve that has to wait gives its lane back: the result is parked, the wavefront's first lanes retry it
+                const bool wait = pix >= 0 && pending;
+                if (park_resolves(wait, pix, fj, v_add(V(0.0f, 0.0f, 0.0f), rad))) {
+                    pix = -1;
+                    pending = false;
+                }
+                service_parked(parkSpins > FRAME_RETRY_LIMIT);
+            }
             // nothing but waiting paths left in this wavefront: do not hammer the pixel
-            if (__ballot(active && pending) != 0ull && __ballot(active && !pending) == 0ull) __builtin_amdgcn_s_sleep(8);
+            if ((__ballot(pix >= 0 && pending) != 0ull || nparked > 0) && __ballot(pix >= 0 && !pending) == 0ull && avail == 0) __builtin_amdgcn_s_sleep(8);
         } else {
         if (active && needRay) { // only for spp > 1: the next sample continues the pixel's RNG stream (compute.glsl:110)
             primary_ray(a, px, py, seed, ro, rd);
@@ -1113,7 +1182,8 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         a.contCapacity = park;
         a.contBatchMin = std::getenv("PT_PARK_MIN") ? std::atoi(std::getenv("PT_PARK_MIN")) : 40;
         const size_t queues = useBatchPass ? (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry))
-                              : (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) : sizeof(RingEntry)) + (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0); // no pool without drain compaction
+                              : (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) : sizeof(RingEntry)) + (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0) // no pool without drain compaction
+                                + (spp1 && a.batchFrames > 1 && a.drainCompaction == 0 ? (size_t)waves * PARKED_MAX * sizeof(ParkedResolve) : 0); // parked resolves of pipelined launches
         size_t ldsTotal = lds + queues;
         // materials leave LDS when they would cost a resident workgroup (160 KB per CU; 64 B of static LDS per workgroup)
         const size_t ldsPerCU = 160 * 1024, fixedLds = 64;

@@ -52,7 +52,7 @@ struct pt_renderer {
     // error word of the frame pipelining: ONE page-locked host word the kernels can reach (mapped): it is only ever
     // written when a hand-over fails, and the host reads it without a copy once the stream is drained
     unsigned int *hostErrWord = nullptr, *devErrWord = nullptr;
-    int queueChunk = 8;             // tiles per global ticket (PT_QUEUE_CHUNK overrides, for tuning runs)
+    int queueChunk = 0;             // tiles per global ticket; 0 = automatic (PT_QUEUE_CHUNK overrides, for tuning runs)
     unsigned long long *dTimeline = nullptr; // tuning only (pt_debug_timeline)
     // Frame pipelining: consecutive pt_render calls are collected and launched as ONE batch kernel (see pt_kernels.hip)
     // when nothing observable happens in between; every other entry point launches what is pending first.

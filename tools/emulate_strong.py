@@ -8,8 +8,11 @@ import __graft_entry__ as g
 pkg = g.load_package()
 out = {"csrc_hash": pkg.native.csrc_hash(), "band_rows": 16, "results": {}}
 sc, cam = pkg.scene.default_scene(), pkg.camera.Camera()
+only = os.environ.get("EMULATE_ONLY")  # e.g. "1920x1080:8" (tuning runs)
 for (W, H) in ((1920, 1080), (3840, 2160)):
     for world in (1, 2, 4, 8):
+        if only and only != f"{W}x{H}:{world}":
+            continue
         worst = 0.0
         for rank in sorted({0, world // 2, world - 1}):
             pt = pkg.PathTracer(None, W, H, 8, 1, 20.0, 0.14)
