@@ -895,7 +895,12 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         return x | (global_row_v(ca->bandRows, ca->bandWorld, ca->bandRank, ca->localRow0, ca->y0, ly) << 16);
     };
 
-    int avail = 0, parked = 0; // wave-uniform: ring entries [0, avail), parked continuations [0, parked)
+    int avail = 0, parked = 0, qhead = 0; // wave-uniform: ring entries [0, avail); `parked` continuations from slot qhead on (FIFO, circular)
+    int stalled = 0;                      // wave-uniform: consecutive iterations in which no lane traced anything
+    auto qslot = [&](int i) -> int { // slot of the i-th parked continuation
+        int sl = qhead + i;
+        return sl >= parkCapacity ? sl - parkCapacity : sl;
+    };
     bool exhausted = false;
     int pix = -1, sample = 0, bounce = 0, fj = 0, retries = 0;
     bool needRay = false, pending = false;
@@ -919,6 +924,73 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         if (rfj > 0 && !force && last.w != FRAME_TAG + (float)(rfj - 1)) return false;
         store_pixel_sc1(ptr, fold(last, rirr, rfj));
         return true;
+    };
+
+    // ---- rescue.  Inside a pipelined batch a pixel's last sample may have to wait for the pixel's previous frame.  If ALL
+    // lanes of a wavefront wait like that, nothing pops its ring or runs a batch pass any more — and the work those lanes
+    // wait for may be exactly what sits in this wavefront's ring or queue (small images: consecutive frames of one tile meet
+    // in one wavefront).  So a wavefront whose lanes all wait SWAPS: a lane puts its waiting result (pixel, frame,
+    // irradiance) into the slot of a queued piece of real work — a ring entry, else a parked continuation — and takes that
+    // work; the waiting results are retried whenever their slot is popped or batched (they are marked by sample == spp).
+    // Storage is conserved, no work ever depends on a lane that only waits, and every pixel still runs the same samples in
+    // the same order on its own RNG stream.
+    auto rescue = [&]() -> void {
+        bool swapped = false;
+        if (avail > 0) { // lane l looks at ring entry avail - n + l
+            const int n = avail < 64 ? avail : 64;
+            if (lane < n) {
+                PathEntryM *slot = ring + (avail - n + lane);
+                const PathEntryM e = *slot;
+                if (e.counters < 0 || ((e.counters >> 12) & 0xfff) < a.spp) { // real work (not itself a waiting resolve)
+                    PathEntryM w;
+                    w.pix = pix; w.counters = a.rayDepth | (sample << 12) | (fj << 24); w.seed = seed;
+                    w.ro[0] = w.ro[1] = w.ro[2] = 0.0f; w.rd[0] = w.rd[1] = 0.0f; w.rd[2] = 1.0f;
+                    w.thr[0] = w.thr[1] = w.thr[2] = 1.0f;
+                    w.rad[0] = w.rad[1] = w.rad[2] = 0.0f;
+                    w.irr[0] = irr.x; w.irr[1] = irr.y; w.irr[2] = irr.z;
+                    *slot = w;
+                    pix = e.pix;
+                    bounce = e.counters & 0xfff;
+                    sample = (e.counters >> 12) & 0xfff;
+                    fj = (e.counters >> 24) & 0x7f;
+                    needRay = e.counters < 0;
+                    pending = false;
+                    retries = 0;
+                    seed = e.seed;
+                    ro = V(e.ro[0], e.ro[1], e.ro[2]);
+                    rd = V(e.rd[0], e.rd[1], e.rd[2]);
+                    throughput = V(e.thr[0], e.thr[1], e.thr[2]);
+                    rad = V(e.rad[0], e.rad[1], e.rad[2]);
+                    irr = V(e.irr[0], e.irr[1], e.irr[2]);
+                    swapped = true;
+                }
+            }
+        }
+        // the lanes that found no real work in the ring (it may hold nothing but waiting resolves, which would keep batch
+        // passes from ever running again) take parked continuations: the k-th such lane looks at the k-th oldest one
+        const unsigned long long sm = __ballot(!swapped);
+        if (sm != 0ull && parked > 0) {
+            const int k = __builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u));
+            if (!swapped && k < parked) {
+                ContEntry *slot = cq + qslot(k);
+                const ContEntry e = *slot;
+                if ((e.sfj & 0xffff) < a.spp) { // a continuation (not itself a waiting resolve)
+                    ContEntry w;
+                    w.pix = pix; w.seed = seed; w.sfj = sample | (fj << 16); // sample == spp marks "last sample done, waiting"
+                    w.irr[0] = irr.x; w.irr[1] = irr.y; w.irr[2] = irr.z;
+                    *slot = w;
+                    pix = e.pix;
+                    seed = e.seed;
+                    sample = e.sfj & 0xffff;
+                    fj = e.sfj >> 16;
+                    irr = V(e.irr[0], e.irr[1], e.irr[2]);
+                    needRay = true; // its next primary ray is generated in the lane
+                    pending = false;
+                    retries = 0;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     };
 
     for (;;) {
@@ -949,11 +1021,12 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                     const int n = parked < 64 ? parked : 64;
                     valid = lane < n;
                     if (valid) {
-                        const ContEntry e = cq[parked - n + lane];
+                        const ContEntry e = cq[qslot(lane)]; // oldest first: a parked pixel never waits behind younger ones
                         tpix = e.pix; tpxy = pixel_xy(e.pix); tseed = e.seed;
                         tsample = e.sfj & 0xffff; tfj = e.sfj >> 16;
                         tirr = V(e.irr[0], e.irr[1], e.irr[2]);
                     }
+                    qhead = qslot(n);
                     parked -= n;
                     __builtin_amdgcn_wave_barrier(); // the entries are read before this pass parks new ones in their place
                 } else {
@@ -970,6 +1043,9 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                         tseed = pixel_seed(x, gy, ca->frame + tfj);
                     }
                 }
+                // (a parked record with sample == spp is a finished pixel that waited for its previous frame: retried below)
+                const bool twaiting = valid && tsample >= a.spp;
+                valid = valid && !twaiting;
                 v3 to = V(0.0f, 0.0f, 0.0f), td = V(0.0f, 0.0f, 1.0f), tthr = V(1.0f, 1.0f, 1.0f), trad = V(0.0f, 0.0f, 0.0f);
                 if (valid) primary_ray_cam(cam, invW, invH, tpxy & 0xffff, tpxy >> 16, tseed, to, td);
                 unsigned long long masks[4];
@@ -1000,7 +1076,12 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                     tirr = v_add(tirr, trad);
                     tsample++;
                 }
-                const bool tmore = tfin && tsample < a.spp;
+                bool tmore = tfin && tsample < a.spp;
+                if (twaiting) { // still waiting: back into the queue, as it was
+                    const bool force = stalled > FRAME_RETRY_LIMIT;
+                    if (!try_resolve(tpix, tfj, tirr, force)) tmore = true;
+                    else if (force) atomicOr(cold_args()->errorWord, 1u);
+                }
                 const unsigned long long pm = __ballot(tmore);
                 bool toRing = false; // overflow of the queue / a resolve that has to wait: through the ring, handled in the lane
                 int ringCounters = 0;
@@ -1011,7 +1092,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                         ContEntry e;
                         e.pix = tpix; e.seed = tseed; e.sfj = tsample | (tfj << 16);
                         e.irr[0] = tirr.x; e.irr[1] = tirr.y; e.irr[2] = tirr.z;
-                        cq[parked + rank] = e;
+                        cq[qslot(parked + rank)] = e;
                     } else if (tmore) {
                         toRing = true;
                         ringCounters = (tsample << 12) | (tfj << 24) | (int)0x80000000; // no ray yet
@@ -1019,7 +1100,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                     const int n = __builtin_popcountll(pm);
                     parked += n < room ? n : room;
                 }
-                if (tfin && !tmore && !try_resolve(tpix, tfj, tirr, false)) {
+                if (tfin && tsample >= a.spp && !try_resolve(tpix, tfj, tirr, false)) {
                     toRing = true;
                     ringCounters = a.rayDepth | (tsample << 12) | (tfj << 24); // "at full depth": resolved in the bounce loop
                 }
@@ -1067,8 +1148,14 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         const bool active = pix >= 0;
         if (__ballot(active) == 0ull) {
             if (exhausted && avail == 0 && parked == 0) break;
+            stalled++; // (only waiting records left in the queue: they are retried by the batch passes above)
+            if (parked > 0 && avail == 0) __builtin_amdgcn_s_sleep(8);
             continue;
         }
+        if (__ballot(!(active && pending && !needRay)) == 0ull && (avail > 0 || parked > 0)) rescue(); // every lane waits: see above
+        // (a wavefront that has done nothing but wait for FRAME_RETRY_LIMIT iterations in a row gives up the hand-over: waiting
+        // records move between lanes, ring and queue, so the bound is kept per wavefront, not per lane)
+        stalled = __ballot(pix >= 0 && !pending) == 0ull ? stalled + 1 : 0;
         if (active && needRay) { // fallback (queue was full): the next sample's primary ray, generated in the lane
             const int pxy = pixel_xy(pix);
             primary_ray(a, pxy & 0xffff, pxy >> 16, seed, ro, rd);
@@ -1098,7 +1185,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                 ContEntry e;
                 e.pix = pix; e.seed = seed; e.sfj = sample | (fj << 16);
                 e.irr[0] = irr.x; e.irr[1] = irr.y; e.irr[2] = irr.z;
-                cq[parked + rank] = e;
+                cq[qslot(parked + rank)] = e;
                 pix = -1;
             } else if (wantPark) {
                 needRay = true;
@@ -1108,7 +1195,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
             __builtin_amdgcn_wave_barrier();
         }
         if (pix >= 0 && pending) {
-            const bool force = retries > FRAME_RETRY_LIMIT;
+            const bool force = retries > FRAME_RETRY_LIMIT || stalled > FRAME_RETRY_LIMIT;
             if (try_resolve(pix, fj, irr, force)) {
                 if (force) atomicOr(cold_args()->errorWord, 1u);
                 pix = -1;
