@@ -266,6 +266,40 @@ def test_result_device_ptr_flushes_deferred_frames(pkg, native_lib, oracle):
     pt.Dispose()
 
 
+# ------------------------------------------------------------------------------------------------ spp > 1 batch-pass kernel
+@pytest.mark.parametrize("size,spp,frames", [((8, 8), 2, 64), ((8, 8), 5, 70), ((8, 17), 3, 64), ((16, 8), 7, 40), ((33, 40), 4, 64),
+                                             ((72, 40), 3, 33)], ids=lambda v: str(v))
+def test_multisample_pipelining_on_tiny_images(pkg, native_lib, oracle, size, spp, frames):
+    """Several samples per pixel, many frames in ONE pipelined launch, images of one to a few tiles: consecutive frames of a
+    tile meet in one wavefront, every lane ends up waiting for a previous frame whose continuations sit parked in the same
+    wavefront's queue — the situation the kernel's rescue (swap waiting results with queued work) exists for.  Must finish,
+    and equal the oracle's frame-by-frame accumulation bit for bit."""
+    w = configs.Workload("ms_tiny", "default", size[0], size[1], 8, "sky_f32_32", spp=spp, frames=frames)
+    sc, basic, objs, env, kw = configs.inputs(w)
+    pt = pkg.PathTracer(env, w.width, w.height, w.ray_depth, spp, w.focal_length, w.aperture)
+    pt.SetFrameBatch(64)
+    pt.UploadScene(sc)
+    pt.UploadBasicData(basic)
+    for _ in range(frames):
+        pt.Render()
+    got = pt.Result
+    pt.Dispose()
+    assert_bit_exact(got, oracle_render(oracle, w), f"{size} spp {spp} x{frames}")
+
+
+def test_multisample_batch_pass_equals_in_lane_chain(pkg, native_lib, oracle):
+    """The batch-pass kernel (default for spp > 1) against the oracle at a size where queue overflow, partial batches and the
+    fallback in-lane primary rays all occur, on a group handle too."""
+    w = configs.Workload("ms_mid", "default", 320, 180, 6, "sky_f32_32", spp=6, frames=5)
+    want = oracle_render(oracle, w)
+    assert_bit_exact(hip_render(pkg, w), want, "spp 6, five pipelined frames")
+    pt = make_tracer(pkg, w, devices=[0, 0, 0])
+    for _ in range(w.frames):
+        pt.Render()
+    assert_bit_exact(pt.Result, want, "spp 6 on a group handle")
+    pt.Dispose()
+
+
 # ------------------------------------------------------------------------------------------------ RCCL, world size 1
 def test_rccl_world_size_one_present(pkg, native_lib):
     """backend='nccl' IS RCCL on ROCm: initialise a one-rank process group on the GPU and run the present path
