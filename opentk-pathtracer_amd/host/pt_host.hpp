@@ -238,6 +238,17 @@ public:
         PushParams();
         if (environmentMap) SetEnvironmentMap(*environmentMap);
     }
+    // The same renderer row-tiled over several GPUs of this process (pt_create_multi; no reference counterpart): every
+    // member below works unchanged, Result() / Present() gather over xGMI inside the library.
+    PathTracer(const EnvironmentMap *environmentMap, const std::vector<int> &devices, int width, int height, int rayDepth, int spp,
+               float focalLength, float apertureDiamater)
+        : rayDepth_(rayDepth), spp_(spp), focalLength_(focalLength), apertureDiameter_(apertureDiamater), width_(width), height_(height)
+    {
+        int rc = pt_create_multi(devices.data(), (int)devices.size(), width, height, &h_);
+        if (rc != PT_OK) throw NativeError(rc, pt_last_error(nullptr));
+        PushParams();
+        if (environmentMap) SetEnvironmentMap(*environmentMap);
+    }
     ~PathTracer() { if (h_) pt_destroy(h_); }
     PathTracer(const PathTracer &) = delete;
     PathTracer &operator=(const PathTracer &) = delete;
@@ -285,6 +296,18 @@ public:
     // Accumulation checkpoint (same file as opentk-pathtracer_amd/checkpoint.py): 8-byte magic, int32 x 8
     // (width, height, y0, rows, band rows / world / rank, frame index), int32 x 2 (depth, spp), float x 2 (focal length,
     // aperture), then the raw RGBA32F rows.  The C++ mirror renders whole images (no tiling).
+    // Non-blocking present for the frame loop (MainWindow.cs:49-56): PresentAsync snapshots the frames rendered so far into
+    // the library's pinned image of `slot` (0..PT_PRESENT_SLOTS-1) while later Render() calls proceed; PresentWait returns that
+    // image (width * height RGBA8, row 0 = bottom; valid until the slot is presented into again) and the frame index it shows.
+    void PresentAsync(int slot) { Check(pt_present_rgba8_async(h_, slot), h_); }
+    const uint8_t *PresentWait(int slot, int *frameIndex = nullptr)
+    {
+        const uint8_t *img = nullptr;
+        size_t pitch = 0;
+        Check(pt_present_wait(h_, slot, &img, &pitch, frameIndex), h_);
+        return img;
+    }
+
     void SaveCheckpoint(const std::string &path) const
     {
         int frame = 0;

@@ -5,6 +5,9 @@
 // and writes the RGBA32F `Result` (raw floats, row 0 = bottom) so it can be compared with the oracle.
 //
 //   pt_host_demo render <W> <H> <frames> <out.f32> [rayDepth] [atmosphereSize]
+//   pt_host_demo frame-loop <W> <H> <frames> <out.rgba8> <devices e.g. 0 or 0,0,0>
+//                      the frame loop of MainWindow.OnRenderFrame (:40-69) with the NON-BLOCKING present on one GPU or a group of
+//                      GPUs: Render(); PresentAsync(f % 3); PresentWait((f + 1) % 3); writes the last image shown + its frame index
 //   pt_host_demo dump-scene <out.bin>            (no GPU needed: the 26,624-byte GameObjectsUBO image)
 //   pt_host_demo dump-camera <W> <H> <out.bin>   (no GPU needed: the 144-byte BasicDataUBO image)
 #include <cstdio>
@@ -53,6 +56,31 @@ int main(int argc, char **argv)
             std::printf("rendered %dx%d, %d samples/pixel\n", W, H, pathTracer.Samples());
             return 0;
         }
+        if (mode == "frame-loop" && argc == 7) {
+            int W = std::atoi(argv[2]), H = std::atoi(argv[3]), frames = std::atoi(argv[4]);
+            std::vector<int> devices;
+            for (const char *p = argv[6]; *p;) {
+                devices.push_back(std::atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
+            PathTracer pathTracer(nullptr, devices, W, H, 13, 1, 20.0f, 0.14f);
+            AtmosphericScatterer atmosphericScatterer(pathTracer, 64);
+            atmosphericScatterer.Render();
+            LoadScene(pathTracer);
+            UploadCamera(pathTracer, camera, W, H);
+            const uint8_t *shown = nullptr;
+            int shownFrame = 0, presented = 0;
+            for (int f = 0; f < frames; f++) {
+                pathTracer.Render();                       // PathTracer.Render(), MainWindow.cs:49
+                pathTracer.PresentAsync(presented % 3);    // instead of PostProcesser.Render(PathTracer.Result), :51
+                if (++presented >= 3) shown = pathTracer.PresentWait(presented % 3, &shownFrame); // the frame of two calls ago: landed
+            }
+            for (int k = 1; k <= 2 && presented >= k; k++) shown = pathTracer.PresentWait((presented + k) % 3, &shownFrame); // drain
+            write_file(argv[5], shown, (size_t)W * H * 4);
+            std::printf("frame loop over %d device(s): %d frames rendered, last image shown is frame %d\n", (int)devices.size(), frames, shownFrame);
+            return 0;
+        }
         if (mode == "resume" && argc == 9) {
             // render framesA, checkpoint, restore into a NEW renderer, render framesB more
             int W = std::atoi(argv[2]), H = std::atoi(argv[3]), framesA = std::atoi(argv[4]), framesB = std::atoi(argv[5]);
@@ -79,7 +107,7 @@ int main(int argc, char **argv)
             std::printf("resumed at frame %d, now %d samples/pixel\n", restored, second.Samples());
             return 0;
         }
-        std::fprintf(stderr, "usage: pt_host_demo render W H frames out.f32 [rayDepth] [atmoSize] | resume W H framesA framesB out.f32 ckpt shot.ppm | "
+        std::fprintf(stderr, "usage: pt_host_demo render W H frames out.f32 [rayDepth] [atmoSize] | frame-loop W H frames out.rgba8 devices | resume W H framesA framesB out.f32 ckpt shot.ppm | "
                              "dump-scene out.bin | dump-camera W H out.bin\n");
         return 1;
     } catch (const std::exception &e) {
