@@ -902,7 +902,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         return sl >= parkCapacity ? sl - parkCapacity : sl;
     };
     bool exhausted = false;
-    int pix = -1, sample = 0, bounce = 0, fj = 0, retries = 0;
+    int pix = -1, sample = 0, bounce = 0, fj = 0;
     bool needRay = false, pending = false;
     uint32_t seed = 0;
     v3 ro = V(0, 0, 0), rd = V(0, 0, 1), throughput = V(1, 1, 1), rad = V(0, 0, 0), irr = V(0, 0, 0);
@@ -929,66 +929,25 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
     // ---- rescue.  Inside a pipelined batch a pixel's last sample may have to wait for the pixel's previous frame.  If ALL
     // lanes of a wavefront wait like that, nothing pops its ring or runs a batch pass any more — and the work those lanes
     // wait for may be exactly what sits in this wavefront's ring or queue (small images: consecutive frames of one tile meet
-    // in one wavefront).  So a wavefront whose lanes all wait SWAPS: a lane puts its waiting result (pixel, frame,
-    // irradiance) into the slot of a queued piece of real work — a ring entry, else a parked continuation — and takes that
-    // work; the waiting results are retried whenever their slot is popped or batched (they are marked by sample == spp).
-    // Storage is conserved, no work ever depends on a lane that only waits, and every pixel still runs the same samples in
-    // the same order on its own RNG stream.
+    // in one wavefront).  So a wavefront whose lanes all wait moves the waiting results out of the lanes into free slots of
+    // the continuation queue (a waiting result — pixel, frame, irradiance — is a continuation with sample == spp; batch passes
+    // retry it, oldest first) and the freed lanes pop the ring as usual: no queued work depends on a lane that only waits,
+    // and every pixel still runs the same samples in the same order on its own RNG stream.  Should the queue itself be full
+    // of waiting results (more than 150 finished pixels of one wavefront all waiting for other frames), the per-wavefront
+    // stall bound below ends the wait with the error word instead of hanging.  (Swapping waiting results with queued paths
+    // was tried first: it needs the path state to be assignable at a second place, which costs 20 spilled VGPRs.)
     auto rescue = [&]() -> void {
-        bool swapped = false;
-        if (avail > 0) { // lane l looks at ring entry avail - n + l
-            const int n = avail < 64 ? avail : 64;
-            if (lane < n) {
-                PathEntryM *slot = ring + (avail - n + lane);
-                const PathEntryM e = *slot;
-                if (e.counters < 0 || ((e.counters >> 12) & 0xfff) < a.spp) { // real work (not itself a waiting resolve)
-                    PathEntryM w;
-                    w.pix = pix; w.counters = a.rayDepth | (sample << 12) | (fj << 24); w.seed = seed;
-                    w.ro[0] = w.ro[1] = w.ro[2] = 0.0f; w.rd[0] = w.rd[1] = 0.0f; w.rd[2] = 1.0f;
-                    w.thr[0] = w.thr[1] = w.thr[2] = 1.0f;
-                    w.rad[0] = w.rad[1] = w.rad[2] = 0.0f;
-                    w.irr[0] = irr.x; w.irr[1] = irr.y; w.irr[2] = irr.z;
-                    *slot = w;
-                    pix = e.pix;
-                    bounce = e.counters & 0xfff;
-                    sample = (e.counters >> 12) & 0xfff;
-                    fj = (e.counters >> 24) & 0x7f;
-                    needRay = e.counters < 0;
-                    pending = false;
-                    retries = 0;
-                    seed = e.seed;
-                    ro = V(e.ro[0], e.ro[1], e.ro[2]);
-                    rd = V(e.rd[0], e.rd[1], e.rd[2]);
-                    throughput = V(e.thr[0], e.thr[1], e.thr[2]);
-                    rad = V(e.rad[0], e.rad[1], e.rad[2]);
-                    irr = V(e.irr[0], e.irr[1], e.irr[2]);
-                    swapped = true;
-                }
+        const int room = parkCapacity - parked;
+        if (room > 0) {
+            if (lane < room) { // (every lane waits, so lane l parks into the l-th free slot)
+                ContEntry e;
+                e.pix = pix; e.seed = seed; e.sfj = sample | (fj << 16); // sample == spp marks "last sample done, waiting"
+                e.irr[0] = irr.x; e.irr[1] = irr.y; e.irr[2] = irr.z;
+                cq[qslot(parked + lane)] = e;
+                pix = -1;
+                pending = false;
             }
-        }
-        // the lanes that found no real work in the ring (it may hold nothing but waiting resolves, which would keep batch
-        // passes from ever running again) take parked continuations: the k-th such lane looks at the k-th oldest one
-        const unsigned long long sm = __ballot(!swapped);
-        if (sm != 0ull && parked > 0) {
-            const int k = __builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u));
-            if (!swapped && k < parked) {
-                ContEntry *slot = cq + qslot(k);
-                const ContEntry e = *slot;
-                if ((e.sfj & 0xffff) < a.spp) { // a continuation (not itself a waiting resolve)
-                    ContEntry w;
-                    w.pix = pix; w.seed = seed; w.sfj = sample | (fj << 16); // sample == spp marks "last sample done, waiting"
-                    w.irr[0] = irr.x; w.irr[1] = irr.y; w.irr[2] = irr.z;
-                    *slot = w;
-                    pix = e.pix;
-                    seed = e.seed;
-                    sample = e.sfj & 0xffff;
-                    fj = e.sfj >> 16;
-                    irr = V(e.irr[0], e.irr[1], e.irr[2]);
-                    needRay = true; // its next primary ray is generated in the lane
-                    pending = false;
-                    retries = 0;
-                }
-            }
+            parked += room < 64 ? room : 64;
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -1131,7 +1090,6 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                 fj = (e.counters >> 24) & 0x7f;
                 needRay = e.counters < 0;
                 pending = false;
-                retries = 0;
                 seed = e.seed;
                 ro = V(e.ro[0], e.ro[1], e.ro[2]);
                 rd = V(e.rd[0], e.rd[1], e.rd[2]);
@@ -1195,13 +1153,11 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
             __builtin_amdgcn_wave_barrier();
         }
         if (pix >= 0 && pending) {
-            const bool force = retries > FRAME_RETRY_LIMIT || stalled > FRAME_RETRY_LIMIT;
+            const bool force = stalled > FRAME_RETRY_LIMIT; // (bounded per wavefront: waiting records move between lanes, ring and queue)
             if (try_resolve(pix, fj, irr, force)) {
                 if (force) atomicOr(cold_args()->errorWord, 1u);
                 pix = -1;
                 pending = false;
-            } else {
-                retries++;
             }
         }
         { // nothing but waiting paths left in this wavefront: do not hammer the pixel
