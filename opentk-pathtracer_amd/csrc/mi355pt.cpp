@@ -646,7 +646,10 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
         return fail(h, PT_E_BAD_ARGUMENT, "bound result buffer is smaller than the tile");
     // Only the default kernel pipelines frames; the A/B variants launch at once.  On a caller-owned stream nothing is
     // deferred: the contract there is that the frame is enqueued on that stream when pt_render returns.
-    const bool batchable = h->variant == 0 && h->maxBatch > 1 && h->dTimeline == nullptr && !h->externalStream();
+    // A host that presents EVERY frame (MainWindow.cs:49-56) gains nothing from holding a frame back — the present that
+    // follows launches it anyway — and loses if it waits for a present slot in between (the GPU would run dry): launch at once.
+    const bool batchable = h->variant == 0 && h->maxBatch > 1 && h->dTimeline == nullptr && !h->externalStream() && h->presentCadence != 1;
+    h->rendersSincePresent++;
     h->pendingFrames++;
     h->frame++; // PathTracer.cs:117 post-increment
     if (out_total_samples) *out_total_samples = h->frame * h->spp; // PathTracer.cs:112
@@ -729,6 +732,8 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
     if (int rc = bind_device(h)) return rc;
     ptimpl::PresentSlot &s = h->slots[slot];
     const size_t pixels = h->tilePixels();
+    h->presentCadence = h->rendersSincePresent;
+    h->rendersSincePresent = 0;
     if (int rc = ptimpl::ensure_slot_events(h, slot)) return rc;
     if (int rc = ptimpl::ensure_slot_device(h, slot, pixels)) return rc;
     if (int rc = ptimpl::ensure_slot_host(h, slot, pixels)) return rc;

@@ -60,6 +60,8 @@ struct pt_renderer {
     int maxBatch = 64;            // PT_FRAME_BATCH=1 turns batching off (every pt_render launches at once)
     int batchWorkgroupsPerCU = 6; // grid of the batch kernel (PT_BATCH_WG, tuning)
     bool batchLaunched = false;   // a batch kernel ran since the last error-word check
+    int rendersSincePresent = 0;  // pt_render calls since the last pt_present_rgba8_async ...
+    int presentCadence = 0;       // ... and how many there were before that present (1 = the host presents every frame)
     hipEvent_t mainDone = nullptr; // recorded behind the last integrator launch on the main stream
     bool mainInFlight = false;     // ... and not yet seen complete
     bool stripeInFlight[ptimpl::kMaxStripes] = {false, false, false, false}; // same for the stripe streams
