@@ -648,7 +648,10 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     // deferred: the contract there is that the frame is enqueued on that stream when pt_render returns.
     // A host that presents EVERY frame (MainWindow.cs:49-56) gains nothing from holding a frame back — the present that
     // follows launches it anyway — and loses if it waits for a present slot in between (the GPU would run dry): launch at once.
-    const bool batchable = h->variant == 0 && h->maxBatch > 1 && h->dTimeline == nullptr && !h->externalStream() && h->presentCadence != 1;
+    // (only the first pt_render after a present is treated that way: a host that goes on rendering without presenting gets
+    // its frames pipelined again)
+    const bool presentsEveryFrame = h->presentCadence == 1 && h->rendersSincePresent == 0;
+    const bool batchable = h->variant == 0 && h->maxBatch > 1 && h->dTimeline == nullptr && !h->externalStream() && !presentsEveryFrame;
     h->rendersSincePresent++;
     h->pendingFrames++;
     h->frame++; // PathTracer.cs:117 post-increment
