@@ -67,6 +67,11 @@ int join_stripes(pt_handle h)
     if (h->pendingFrames > 0)
         if (int rc = flush_frames(h)) return rc;
     h->mainDirty = true; // whoever joins is about to put other work on the main stream: the next striped frame orders behind it
+    h->chainBroken = true; // ... and the next tagged launch re-joins the two launch streams before it starts
+    if (h->chainPending) {
+        PT_HIP(h, hipStreamWaitEvent(h->stream, h->chainDone, 0));
+        h->chainPending = false;
+    }
     for (int j = 0; j < kMaxStripes; j++) {
         if (h->stripePending[j]) {
             if (j > 0) PT_HIP(h, hipStreamWaitEvent(h->stream, h->stripeDone[j], 0)); // (stripe 0 runs on the main stream itself)
@@ -84,6 +89,18 @@ int check_handover(pt_handle h)
     if (h->hostErrWord && *(volatile unsigned int *)h->hostErrWord) {
         *(volatile unsigned int *)h->hostErrWord = 0;
         return fail(h, PT_E_HIP, "frame pipelining: a pixel's previous frame never arrived (result is not trustworthy)");
+    }
+    return PT_OK;
+}
+
+// The host is about to observe the accumulation image (read it, hand out its pointer, synchronise on a bound buffer):
+// chained launches leave frame tags in its alpha channel, the reference's constant is 1 (compute.glsl:129).
+int fix_alpha(pt_handle h)
+{
+    if (int rc = join_stripes(h)) return rc;
+    if (h->tagsLive) {
+        PT_HIP(h, pt::launch_set_alpha(h->accum(), h->tilePixels(), h->stream));
+        h->tagsLive = false;
     }
     return PT_OK;
 }
@@ -123,6 +140,7 @@ int clear_accum(pt_handle h)
         return fail(h, PT_E_BAD_ARGUMENT, "bound result buffer is smaller than the tile");
     if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, pt::launch_clear(h->accum(), h->tilePixels(), h->stream));
+    h->tagsLive = false;
     return PT_OK;
 }
 
@@ -234,6 +252,8 @@ PT_API int pt_destroy(pt_handle h)
     ptimpl::free_slots(h);
     if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
     if (h->gatherReady) (void)hipEventDestroy(h->gatherReady);
+    if (h->chainStream) { (void)hipStreamSynchronize(h->chainStream); (void)hipStreamDestroy(h->chainStream); }
+    if (h->chainDone) (void)hipEventDestroy(h->chainDone);
     for (int j = 0; j < ptimpl::kMaxStripes; j++)
         if (h->stripeStream[j]) (void)hipStreamSynchronize(h->stripeStream[j]);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -335,6 +355,9 @@ PT_API int pt_reset(pt_handle h)
     PT_CHECK_HANDLE(h);
     PT_FAN_OUT(h, pt_reset(part));
     if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
+    // (the frame counter goes backwards: the tags in the image must not be mistaken for frames of the new sequence)
+    if (int rc = bind_device(h)) return rc;
+    if (int rc = ptimpl::fix_alpha(h)) return rc;
     h->frame = 0; // PathTracer.cs:139 — frame 0 weights the old contents by 0, so no clear is needed
     return PT_OK;
 }
@@ -458,7 +481,12 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     // variant -> (kernel variant, stripes): 0 = default (2 stripes x 5 workgroups/CU); 20+k / 30+k / 40+k = 2 / 3 / 4
     // stripes of the persistent kernel with k+1 workgroups per CU; everything else = one kernel on the main stream
     int stripes = 1, kernelVariant = h->variant;
-    if (h->variant == 0 && n > 1) { stripes = 1; kernelVariant = 10 + h->batchWorkgroupsPerCU - 1; h->batchLaunched = true; }
+    // Tagged launches (pixels handed over through alpha tags): every launch of more than one frame, and — once the host has
+    // pipelined frames on this handle — single frames too, so that they can overlap the launches around them (a host that
+    // presents every frame, or only ever renders one frame at a time, keeps the faster single-frame stripes).
+    const bool chainable = h->variant == 0 && !h->externalStream() && h->maxBatch > 1 && h->dTimeline == nullptr;
+    const bool tagged = h->variant == 0 && (n > 1 || (chainable && h->sawBatch && h->presentCadence != 1));
+    if (tagged) { stripes = 1; kernelVariant = 10 + h->batchWorkgroupsPerCU - 1; h->batchLaunched = true; if (n > 1) h->sawBatch = true; }
     else if (h->variant == 0 && h->externalStream()) { stripes = 1; kernelVariant = 14; } // everything ON the caller's stream
     else if (h->variant == 0) { stripes = 2; kernelVariant = 14; }
     else if (h->variant >= 20 && h->variant < 50) { stripes = h->variant / 10; kernelVariant = 10 + h->variant % 10; }
@@ -467,10 +495,59 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     // Drain compaction (a thin draining wavefront donates its paths to its workgroup's pool) shortens the tail of ONE
     // launch.  With stripes the tail of one launch is covered by the other stripe's (or the next frame's) main phase, and
     // the pool's LDS and the donor traffic only cost: auto = on for single-launch variants, off for striped frames.
-    a.drainCompaction = h->drainCompaction >= 0 ? h->drainCompaction : (stripes > 1 || n > 1 ? 0 : 32); // a batch drains once per n frames
+    a.drainCompaction = h->drainCompaction >= 0 ? h->drainCompaction : (stripes > 1 || tagged ? 0 : 32); // a batch drains once per n frames
+    a.tagged = tagged ? 1 : 0;
+    a.keepTags = 0;
+    a.chainTag = 0.0f;
 
-    if (stripes == 1) {
+    if (tagged && chainable) {
+        // ---- chained launch: alternate between the main stream and the chain stream; the pixels' alpha tags order it behind
+        // the previous launch (which may still be draining on the other stream), nothing else does
+        a.y0 = h->y0;
+        a.rows = h->rows;
+        a.accum = h->accum();
+        a.tilesY = (h->rows + 7) / 8;
+        a.keepTags = 1;
+        int si = h->chainToggle;
+        if (h->chainBroken) {
+            // something else happened since the last tagged launch (an upload, a read, a striped frame ...): it was joined into
+            // the main stream; start there again, and let the chain stream see those inputs before its next launch
+            if (int rc = join_stripes(h)) return rc;
+            si = 0;
+            if (!h->chainDone) PT_HIP(h, hipEventCreateWithFlags(&h->chainDone, hipEventDisableTiming));
+            PT_HIP(h, hipEventRecord(h->inputsReady, h->stream));
+            h->chainNeedsInputs = true;
+        }
+        a.chainTag = h->tagsLive ? h->lastTag : 0.0f;
+        hipStream_t st = h->stream;
+        if (si == 1) {
+            if (!h->chainStream) PT_HIP(h, hipStreamCreateWithFlags(&h->chainStream, hipStreamNonBlocking));
+            st = h->chainStream;
+            if (h->chainNeedsInputs) {
+                PT_HIP(h, hipStreamWaitEvent(st, h->inputsReady, 0));
+                h->chainNeedsInputs = false;
+            }
+        }
+        a.queue = h->dQueue + (si == 1 ? 32 : 0); // each launch stream draws tickets from its own counter
+        a.queueBase = h->stripeQueueBase[si == 1 ? 2 : 0];
+        unsigned int tickets = 0;
+        PT_HIP(h, pt::launch_integrate(a, st, &tickets));
+        h->stripeQueueBase[si == 1 ? 2 : 0] += tickets;
+        if (si == 1) {
+            PT_HIP(h, hipEventRecord(h->chainDone, st));
+            h->chainInFlight = h->chainPending = true;
+        } else {
+            PT_HIP(h, hipEventRecord(h->mainDone, st));
+            h->mainInFlight = true;
+        }
+        h->chainToggle = si ^ 1;
+        h->chainBroken = false; // (join_stripes above set it; this launch re-opens the chain)
+        h->mainDirty = true;    // a striped frame that follows must order its helper stripe behind this launch
+        h->tagsLive = true;
+        h->lastTag = 2.0f + (float)((firstFrame + n - 1) & 1023); // pt::frame_tag of the launch's last frame
+    } else if (stripes == 1) {
         if (int rc = join_stripes(h)) return rc;
+        h->tagsLive = false; // (the plain path stores alpha = 1 for every pixel; a tagged launch of an A/B variant stores 1 last)
         a.y0 = h->y0;
         a.rows = h->rows;
         a.accum = h->accum();
@@ -488,6 +565,10 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         // (only when something other than stripe 0's own frames went onto the main stream since the last striped frame:
         // stripe 0 runs there, and the helper stripes must not wait for ITS previous frame — overlapping one stripe's drain
         // with the other's main phase is the point of the stripes)
+        if (h->chainPending || h->tagsLive) { // a chained launch may still run on the chain stream: the stripes read its pixels plainly
+            if (int rc = join_stripes(h)) return rc;
+            h->tagsLive = false; // every pixel gets alpha = 1 from this frame
+        }
         const bool orderHelpers = h->mainDirty;
         if (orderHelpers) PT_HIP(h, hipEventRecord(h->inputsReady, h->stream));
         h->mainDirty = false;
@@ -526,6 +607,10 @@ bool gpu_busy(pt_handle h)
     if (h->mainInFlight) {
         if (hipEventQuery(h->mainDone) == hipErrorNotReady) busy = true;
         else h->mainInFlight = false;
+    }
+    if (h->chainInFlight) {
+        if (hipEventQuery(h->chainDone) == hipErrorNotReady) busy = true;
+        else h->chainInFlight = false;
     }
     for (int j = 0; j < ptimpl::kMaxStripes; j++) {
         if (!h->stripeInFlight[j]) continue;
@@ -671,7 +756,7 @@ PT_API int pt_read_result(pt_handle h, float *dst, size_t row_pitch_bytes)
     if (row_pitch_bytes < rowBytes) return fail(h, PT_E_BAD_ARGUMENT, "row pitch smaller than a row");
     if (h->isGroup()) return ptimpl::group_read_result(h, dst, row_pitch_bytes);
     if (int rc = bind_device(h)) return rc;
-    if (int rc = join_stripes(h)) return rc;
+    if (int rc = ptimpl::fix_alpha(h)) return rc;
     PT_HIP(h, hipMemcpy2DAsync(dst, row_pitch_bytes, h->accum(), rowBytes, rowBytes, (size_t)h->rows,
                                hipMemcpyDeviceToHost, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -693,6 +778,7 @@ PT_API int pt_write_result(pt_handle h, const float *src, size_t row_pitch_bytes
     // alpha is the reference's constant 1 (compute.glsl:129) whatever the file held: inside a pipelined launch alpha
     // carries the frame tag, so a restored 2.0 must never reach the kernel
     PT_HIP(h, pt::launch_set_alpha(h->accum(), h->tilePixels(), h->stream));
+    h->tagsLive = false;
     PT_HIP(h, hipStreamSynchronize(h->stream));
     h->frame = frame_index;
     return PT_OK;
@@ -811,7 +897,7 @@ PT_API int pt_synchronize(pt_handle h)
     PT_CHECK_HANDLE(h);
     PT_FAN_OUT(h, pt_synchronize(part));
     if (int rc = bind_device(h)) return rc;
-    if (int rc = join_stripes(h)) return rc;
+    if (int rc = ptimpl::fix_alpha(h)) return rc; // (a bound buffer is observed after this call)
     PT_HIP(h, hipStreamSynchronize(h->stream));
     return ptimpl::check_handover(h);
 }
@@ -898,7 +984,7 @@ PT_API int pt_result_device_ptr(pt_handle h, void **out_ptr, size_t *out_bytes)
     // whatever pt_render deferred is launched and joined into the handle's stream first: work the caller orders behind
     // that stream (or behind pt_synchronize) then sees every frame rendered so far
     if (int rc = bind_device(h)) return rc;
-    if (int rc = join_stripes(h)) return rc;
+    if (int rc = ptimpl::fix_alpha(h)) return rc;
     if (out_ptr) *out_ptr = h->accum();
     if (out_bytes) *out_bytes = h->tilePixels() * sizeof(float4);
     return PT_OK;
@@ -911,7 +997,7 @@ PT_API int pt_bind_result_buffer(pt_handle h, void *device_ptr, size_t bytes)
     if (device_ptr && bytes < h->tilePixels() * sizeof(float4))
         return fail(h, PT_E_BAD_ARGUMENT, "buffer smaller than rows*width*16 bytes");
     if (int rc = bind_device(h)) return rc;
-    if (int rc = join_stripes(h)) return rc;
+    if (int rc = ptimpl::fix_alpha(h)) return rc; // (the image rendered so far stays behind with alpha = 1)
     h->boundAccum = (float4 *)device_ptr;
     h->boundBytes = device_ptr ? bytes : 0;
     // alpha doubles as the frame tag inside pipelined launches: whatever the caller's memory holds, it starts as 1
@@ -924,7 +1010,7 @@ PT_API int pt_set_stream(pt_handle h, void *hip_stream)
     PT_CHECK_HANDLE(h);
     if (h->isGroup()) return fail(h, PT_E_BAD_ARGUMENT, "pt_set_stream is not available on a group handle");
     if (int rc = bind_device(h)) return rc;
-    if (int rc = join_stripes(h)) return rc;
+    if (int rc = ptimpl::fix_alpha(h)) return rc;
     PT_HIP(h, hipStreamSynchronize(h->stream));
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->ownStream;
     return PT_OK;

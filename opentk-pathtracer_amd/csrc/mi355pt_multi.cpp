@@ -120,7 +120,7 @@ int parts_ready_accum(pt_handle g, std::vector<const void *> &src, std::vector<h
 {
     for (pt_handle p : g->parts) {
         if (int rc = ptimpl::bind_device(p)) return part_fail(g, p, rc);
-        if (int rc = ptimpl::join_stripes(p)) return part_fail(g, p, rc);
+        if (int rc = ptimpl::fix_alpha(p)) return part_fail(g, p, rc); // (chained launches leave frame tags in alpha)
         PT_HIP(g, hipEventRecord(p->gatherReady, p->stream));
         src.push_back(p->accum());
         ready.push_back(p->gatherReady);

@@ -209,6 +209,11 @@ __global__ __launch_bounds__(256) void pt_integrate_pool_kernel(const FrameArgs 
 // the same wavefront); after FRAME_RETRY_LIMIT attempts it proceeds anyway and raises the launch's error word.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr float FRAME_TAG = 2.0f;
+// the tag of (absolute) frame f: distinct for any two frames that can be in flight together, exact in binary32.  Launches
+// may CHAIN: the first frame of a tagged launch waits for the tag of the previous launch's last frame (FrameArgs::chainTag), so
+// two launches on different streams overlap like the frames inside one launch do (the second fills the wavefront slots the
+// first one's drain frees) — the host restores alpha = 1 before anything can observe the image (pt_set_alpha_kernel).
+PT_DEV float frame_tag(int absFrame) { return FRAME_TAG + (float)(absFrame & 1023); }
 constexpr int FRAME_RETRY_LIMIT = 1 << 22;
 constexpr int MAX_BATCH_FRAMES = 64;
 
@@ -300,7 +305,7 @@ PT_DEV int queue_pop_tile(BlockQueue *q)
                 const int numTiles = ca->tilesX * ca->tilesY * ca->batchFrames, chunk = ca->queueChunk; // (frame, tile) pairs, frame-major
                 if (leader) ticket = atomicAdd(ca->queue, 1u) - ca->queueBase;
                 ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
-                long long first = ((ca->batchFrames > 1 ? 0ll : (long long)gridDim.x) + ticket) * chunk; // batches have no static chunks
+                long long first = ((ca->tagged ? 0ll : (long long)gridDim.x) + ticket) * chunk; // tagged launches have no static chunks
                 if (first >= numTiles) {
                     if (leader) lds_store(&q->done, 1u);
                 } else {
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         // work that resident workgroups are waiting for — tickets are only ever held by workgroups that are running.
         long long first = (long long)blockIdx.x * a.queueChunk;
         long long last = first + a.queueChunk < numTiles ? first + a.queueChunk : numTiles;
-        if (first >= numTiles || a.batchFrames > 1) { first = 0; last = 0; }
+        if (first >= numTiles || a.tagged) { first = 0; last = 0; }
         queue.pair = ((unsigned long long)last << 32) | (unsigned long long)first;
         queue.lock = 0u;
         queue.done = 0u;
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     const bool compaction = a.drainCompaction != 0;
     // parked resolves of this wavefront (pipelined spp = 1 launches only; behind the rings — such launches have no drain pool)
     ParkedResolve *parkedList = (ParkedResolve *)(ringBase + NWAVES * 64 * ENTRY_BYTES) + wave * PARKED_MAX;
-    const bool parking = SPP1 && a.batchFrames > 1 && !compaction;
+    const bool parking = SPP1 && a.tagged && !compaction;
     int nparked = 0, parkSpins = 0; // wave-uniform
     const int donateMax = a.drainCompaction < DONATE_MAX ? a.drainCompaction : DONATE_MAX; // a wavefront this thin donates
     const bool leader = lane == 0;
@@ -425,19 +430,20 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             rirr = v_scale(rirr, f_div_ieee(1.0f, (float)ca->spp));
             w = f_div_ieee(1.0f, (float)(ca->frame + rfj + 1));
         }
-        const float alpha = rfj == ca->batchFrames - 1 ? 1.0f : FRAME_TAG + (float)rfj; // (one frame per launch: rfj = 0 = last)
+        const float alpha = (rfj == ca->batchFrames - 1 && !ca->keepTags) ? 1.0f : frame_tag(ca->frame + rfj);
         return make_float4(f_mix(last.x, rirr.x, w), f_mix(last.y, rirr.y, w), f_mix(last.z, rirr.z, w), alpha);
     };
     // False = the pixel still holds an older frame (only possible inside a batch): try again in the next iteration.
     auto try_resolve = [&](int rpix, int rfj, v3 rirr, bool force) -> bool {
         float4 *ptr = a.accum + rpix;
-        if (a.batchFrames == 1) {
+        if (!a.tagged) {
             float4 last = *ptr;
             *ptr = fold(last, rirr, 0);
             return true;
         }
         float4 last = load_pixel_sc1(ptr);
-        if (rfj > 0 && !force && last.w != FRAME_TAG + (float)(rfj - 1)) return false;
+        const float expected = rfj > 0 ? frame_tag(a.frame + rfj - 1) : a.chainTag; // (0 = the launch's first frame has no predecessor in flight)
+        if (expected != 0.0f && !force && last.w != expected) return false;
         store_pixel_sc1(ptr, fold(last, rirr, rfj));
         return true;
     };
@@ -875,7 +881,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
     if (threadIdx.x == 0) {
         long long first = (long long)blockIdx.x * a.queueChunk;
         long long last = first + a.queueChunk < numTiles ? first + a.queueChunk : numTiles;
-        if (first >= numTiles || a.batchFrames > 1) { first = 0; last = 0; } // batches draw every chunk from the global counter
+        if (first >= numTiles || a.tagged) { first = 0; last = 0; } // tagged launches draw every chunk from the global counter
         queue.pair = ((unsigned long long)last << 32) | (unsigned long long)first;
         queue.lock = 0u;
         queue.done = 0u;
@@ -911,17 +917,18 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         ColdArgs ca = cold_args();
         rirr = v_scale(rirr, f_div_ieee(1.0f, (float)ca->spp));
         const float w = f_div_ieee(1.0f, (float)(ca->frame + rfj + 1));
-        const float alpha = rfj == ca->batchFrames - 1 ? 1.0f : FRAME_TAG + (float)rfj;
+        const float alpha = (rfj == ca->batchFrames - 1 && !ca->keepTags) ? 1.0f : frame_tag(ca->frame + rfj);
         return make_float4(f_mix(last.x, rirr.x, w), f_mix(last.y, rirr.y, w), f_mix(last.z, rirr.z, w), alpha);
     };
     auto try_resolve = [&](int rpix, int rfj, v3 rirr, bool force) -> bool {
         float4 *ptr = a.accum + rpix;
-        if (a.batchFrames == 1) {
+        if (!a.tagged) {
             *ptr = fold(*ptr, rirr, 0);
             return true;
         }
         float4 last = load_pixel_sc1(ptr);
-        if (rfj > 0 && !force && last.w != FRAME_TAG + (float)(rfj - 1)) return false;
+        const float expected = rfj > 0 ? frame_tag(a.frame + rfj - 1) : a.chainTag;
+        if (expected != 0.0f && !force && last.w != expected) return false;
         store_pixel_sc1(ptr, fold(last, rirr, rfj));
         return true;
     };
@@ -1211,7 +1218,15 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         // spp > 1: the batch-pass kernel (every sample's first bounce coherent and culled), unless drain compaction is asked
         // for (single-launch frames of the A/B variants and of caller-owned streams keep the in-lane sample chain)
         static const bool noBatchPass = std::getenv("PT_NO_BATCH_PASS") != nullptr; // A/B runs
-        const bool useBatchPass = !spp1 && a.drainCompaction == 0 && !noBatchPass;
+        // ... and unless frames are pipelined over a SMALL image.  Inside a tagged launch a finished pixel may wait for its
+        // previous frame; the batch-pass kernel keeps work outside the lanes (parked continuations), and when consecutive frames
+        // of a tile meet in one wavefront — few tiles per frame for the ~5,000 resident wavefronts — every lane, and then the
+        // whole queue, can fill up with results that wait for exactly that parked work.  The kernel's rescue (park waiting
+        // results too) and stall bound turn that into a delay or, at worst, an error code, never a hang; but it HAS been seen
+        // (225 tiles per frame, 32 frames: 2-4 % of launches), so such launches use the in-lane sample chain, whose ring
+        // discipline cannot form that cycle.  16,384 tiles per frame (1024 x 1024) leave a wavefront 3-4 tiles per frame.
+        const bool smallPipelined = a.tagged && (long long)a.tilesX * a.tilesY < 16384;
+        const bool useBatchPass = !spp1 && a.drainCompaction == 0 && !noBatchPass && !smallPipelined;
         // the continuation queues take what a 5-per-CU workgroup has left next to the scene and the rings (<= 128 entries per wavefront)
         int park = 0;
         if (useBatchPass) {
@@ -1226,7 +1241,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         a.contBatchMin = std::getenv("PT_PARK_MIN") ? std::atoi(std::getenv("PT_PARK_MIN")) : 40;
         const size_t queues = useBatchPass ? (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry))
                               : (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) : sizeof(RingEntry)) + (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0) // no pool without drain compaction
-                                + (spp1 && a.batchFrames > 1 && a.drainCompaction == 0 ? (size_t)waves * PARKED_MAX * sizeof(ParkedResolve) : 0); // parked resolves of pipelined launches
+                                + (spp1 && a.tagged && a.drainCompaction == 0 ? (size_t)waves * PARKED_MAX * sizeof(ParkedResolve) : 0); // parked resolves of tagged launches
         size_t ldsTotal = lds + queues;
         // materials leave LDS when they would cost a resident workgroup (160 KB per CU; 64 B of static LDS per workgroup)
         const size_t ldsPerCU = 160 * 1024, fixedLds = 64;
@@ -1252,7 +1267,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
 #undef PT_LAUNCH_PERSISTENT
         // every workgroup draws tickets until its first failing one: (numChunks - nwg) successful + nwg failing
         // (a pipelined batch draws every chunk dynamically: numChunks successful + nwg failing)
-        *ticketsConsumed = a.batchFrames > 1 ? (unsigned int)(numChunks + nwg) : (unsigned int)(numChunks > nwg ? numChunks : nwg);
+        *ticketsConsumed = a.tagged ? (unsigned int)(numChunks + nwg) : (unsigned int)(numChunks > nwg ? numChunks : nwg);
     } else {
         int poolTiles = pool_tiles_for_variant(a.variant);
         int pools = (tiles + poolTiles - 1) / poolTiles;

@@ -38,6 +38,12 @@ struct FrameArgs {
     int queueChunk;         // tiles per global ticket of the persistent kernel's queue
     int drainCompaction;    // 0 = off; else a draining wavefront with at most this many live paths donates them (<= 48)
     int batchFrames;        // frames rendered by this launch (>= 1): frame, frame+1, ... over the same tiles (see the kernel's frame pipelining)
+    int tagged;             // 1 = pixels are handed over through alpha tags (device-coherent 16-byte accesses): every launch of more than one
+                            // frame, and single frames that may overlap a neighbouring launch; 0 = plain read-modify-write, alpha = 1
+    int keepTags;           // 1 = the LAST frame of the launch stores its tag too (the next launch chains on it; the host restores
+                            // alpha = 1 before anything observes the image), 0 = it stores the 1 the reference stores
+    float chainTag;         // tagged launches: the tag the pixel must show before the launch's FIRST frame may resolve it (the last
+                            // frame of the previous, possibly still running launch); 0 = no such predecessor
     int contCapacity;       // set by the launch (spp > 1 batch-pass kernel): parked continuations per wavefront
     int contBatchMin;       // ... and how many of them make a batch pass worth running
     int materialsInLds;     // set by the launch: 1 = the 64-byte materials are staged in LDS, 0 = read from `objects` (large scenes)

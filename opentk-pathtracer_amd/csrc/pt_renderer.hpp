@@ -64,6 +64,19 @@ struct pt_renderer {
     int presentCadence = 0;       // ... and how many there were before that present (1 = the host presents every frame)
     hipEvent_t mainDone = nullptr; // recorded behind the last integrator launch on the main stream
     bool mainInFlight = false;     // ... and not yet seen complete
+    // Launch chaining (pipelined launches of the default kernel): consecutive tagged launches alternate between the main stream
+    // and `chainStream` and are ordered per PIXEL by the alpha tags, not by the streams, so a launch starts in the wavefront
+    // slots the previous launch's drain frees.  While `tagsLive` the image's alpha channel holds tags: every entry point that
+    // lets the host observe the image restores alpha = 1 first (fix_alpha).
+    hipStream_t chainStream = nullptr; // created on first use
+    hipEvent_t chainDone = nullptr;    // recorded behind the last launch on chainStream
+    bool chainInFlight = false, chainPending = false; // (for gpu_busy / the main stream has not yet waited for it)
+    int chainToggle = 0;               // stream of the next tagged launch: 0 = main, 1 = chainStream
+    bool chainNeedsInputs = false;     // the chain stream has not yet waited for the inputs put on the main stream
+    bool chainBroken = true;           // something other than a tagged launch happened since the last one: streams re-join first
+    bool tagsLive = false;             // the image's alpha holds frame tags (last one: lastTag)
+    float lastTag = 0.0f;
+    bool sawBatch = false;             // the host has pipelined frames before: single frames launch tagged too, so that they overlap
     bool stripeInFlight[ptimpl::kMaxStripes] = {false, false, false, false}; // same for the stripe streams
     int drainCompaction = -1;      // donate threshold in live paths (<= 32), 0 = off, -1 = auto; env PT_DRAIN_COMPACTION
     int numCUs = 256;
@@ -134,6 +147,7 @@ int bind_device(pt_handle h);
 int flush_frames(pt_handle h);  // launch the frames pt_render deferred
 int join_stripes(pt_handle h);  // flush + make h->stream wait for every helper stream
 int check_handover(pt_handle h); // frame-pipelining error word (call after the stream has been synchronised)
+int fix_alpha(pt_handle h);      // join + restore alpha = 1 if the image still carries frame tags (before the host observes it)
 int ensure_stripe(pt_handle h, int j); // create stripe stream j (j > 0) and its event on first use
 hipStream_t stripe_stream(pt_handle h, int j); // stripe 0 runs on the main stream
 // tone map this handle's rows into `dst` (RGBA8, compact rows) on h->stream, behind every frame rendered so far

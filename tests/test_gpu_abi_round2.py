@@ -310,6 +310,80 @@ def test_multisample_pipelining_on_tiny_images(pkg, native_lib, oracle, size, sp
     assert_bit_exact(got, oracle_render(oracle, w), f"{size} spp {spp} x{frames}")
 
 
+def test_multisample_pipelining_small_image_never_stalls(pkg, native_lib, oracle):
+    """Regression for a hand-over stall the round-2 fuzzer found (2-4 % of such launches on the first batch-pass kernel): 200
+    small spheres, 200x72 pixels (225 tiles), 2 bounces, 4 spp, 33 frames with 32 in one pipelined launch — consecutive frames
+    of a tile meet in one wavefront, whose lanes and queue fill up with results that wait for work parked in the same
+    wavefront.  Pipelined launches over fewer than 16,384 tiles per frame use the in-lane sample chain now; every repetition
+    must finish promptly (the stall bound would take 6 s and raise PT_E_HIP) and equal the oracle."""
+    import time
+    rng = np.random.RandomState(5)
+    S = pkg.scene
+    sc = S.Scene()
+    for i in range(200):
+        sc.spheres.append(S.Sphere(rng.uniform([-18, -11, -20], [18, 11, 0]).astype(np.float32), np.float32(0.6 * rng.uniform(0.2, 1.5)), i,
+                                   S.Material(albedo=rng.rand(3))))
+    sc.cuboids.append(S.Cuboid(S.vec3(0.0, -11.0, -10.0), S.vec3(30.0, 1.0, 30.0), 0, S.Material(albedo=S.vec3(0.7))))
+    W, H, depth, spp, frames = 200, 72, 2, 4, 33
+    basic = pkg.camera.basic_data_ubo(pkg.camera.Camera(), W, H)
+    env = pkg.envmap.synthetic_sky_rgba32f(16)
+    want = oracle.render(W, H, basic, sc.ubo_bytes(), env, num_spheres=200, num_cuboids=1, ray_depth=depth, spp=spp,
+                         focal_length=200.0, aperture=0.0, num_frames=frames)
+    for rep in range(40):
+        pt = pkg.PathTracer(env, W, H, depth, spp, 200.0, 0.0)
+        pt.SetFrameBatch(32)
+        pt.UploadScene(sc)
+        pt.UploadBasicData(basic)
+        t = time.perf_counter()
+        for _ in range(frames):
+            pt.Render()
+        got = pt.Result
+        dt = time.perf_counter() - t
+        pt.Dispose()
+        assert dt < 2.0, f"repetition {rep} took {dt:.1f} s"
+        assert_bit_exact(got, want, f"repetition {rep}")
+
+
+def test_chained_launches_overlap_and_restore_alpha(pkg, native_lib, oracle):
+    """Launch chaining: tagged launches alternate between two streams and are ordered per pixel by alpha tags that survive the
+    launch; the host must never see them.  Frames in uneven groups (1 + 5 + 64 + 3 ...), camera uploads in between (which
+    do not join the streams), a reset (the frame counter goes backwards), reads at odd moments, a bound buffer."""
+    torch = pytest.importorskip("torch")
+    w = configs.Workload("chain", "default", 96, 56, 8, "sky_f32_32")
+    sc, basic, objs, env, kw = configs.inputs(w)
+    pt = make_tracer(pkg, w)
+    pt.SetFrameBatch(64)
+    done, acc = 0, None
+    for group in (1, 5, 64, 3, 70, 2):
+        for _ in range(group):
+            pt.Render()
+        pt.UploadBasicData(basic)  # kernarg only: flushes the pending frames, does not join
+        acc = oracle.render(w.width, w.height, basic, objs, env, frame_start=done, num_frames=group, image=acc, **kw)
+        done += group
+        if group in (64, 2):
+            got = pt.Result
+            assert (got[..., 3] == 1.0).all()
+            assert_bit_exact(got, acc, f"after {done} frames in chained launches")
+    pt.ResetRenderer()
+    for _ in range(9):
+        pt.Render()
+    acc = oracle.render(w.width, w.height, basic, objs, env, num_frames=9, image=acc, **kw)
+    assert_bit_exact(pt.Result, acc, "after a reset inside a chain")
+    buf = torch.from_numpy(acc.copy()).cuda()
+    torch.cuda.synchronize()
+    pt.BindResultBuffer(buf.data_ptr(), buf.numel() * 4)
+    pkg.native.check(native_lib.pt_write_result(pt._h, acc.ctypes.data_as(C.POINTER(C.c_float)), 0, 9), pt._h)
+    for _ in range(40):
+        pt.Render()
+    pt.Synchronize()  # the bound buffer is observed after this call: alpha must be 1 again
+    acc = oracle.render(w.width, w.height, basic, objs, env, frame_start=9, num_frames=40, image=acc, **kw)
+    got = buf.cpu().numpy()
+    assert (got[..., 3] == 1.0).all()
+    assert_bit_exact(got, acc, "bound buffer after chained launches")
+    pt.BindResultBuffer(None, 0)
+    pt.Dispose()
+
+
 def test_multisample_batch_pass_equals_in_lane_chain(pkg, native_lib, oracle):
     """The batch-pass kernel (default for spp > 1) against the oracle at a size where queue overflow, partial batches and the
     fallback in-lane primary rays all occur, on a group handle too."""
