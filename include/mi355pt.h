@@ -202,7 +202,11 @@ PT_API int pt_read_environment(pt_handle h, float *dst_rgba32f, int *out_face_si
 PT_API int pt_result_device_ptr(pt_handle h, void **out_device_ptr, size_t *out_bytes);
 /* Render into caller-owned device memory (>= rows*width*16 bytes) instead of the internal image; NULL restores.
  * The buffer's RGB contents are taken as the accumulation so far (zero them for a fresh render: frame 0 multiplies
- * them by 0, and 0 * NaN is NaN as in the reference); its alpha channel is set to 1 at bind time (stream-ordered). */
+ * them by 0, and 0 * NaN is NaN as in the reference); its alpha channel is set to 1 at bind time (stream-ordered).
+ * On the library's own stream the buffer must be observed through the library: while pt_render calls are outstanding its
+ * alpha channel carries the frame tags of the pipelined launches, and pt_synchronize / pt_read_result /
+ * pt_result_device_ptr restore alpha = 1 (the value the reference stores, compute.glsl:129) before they return.  On a
+ * caller-owned stream (pt_set_stream) every frame stores alpha = 1 and stream order alone is enough. */
 PT_API int pt_bind_result_buffer(pt_handle h, void *device_ptr, size_t bytes);
 /* Use an existing hipStream_t (passed as void*) instead of the handle's own stream; NULL restores.  With a caller
  * stream every pt_render is enqueued on THAT stream before it returns (one launch per frame, no deferral, no
