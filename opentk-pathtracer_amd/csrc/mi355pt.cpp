@@ -64,8 +64,14 @@ namespace ptimpl {
 // anything that reads their output or overwrites their inputs).
 int join_stripes(pt_handle h)
 {
-    if (h->pendingFrames > 0)
-        if (int rc = flush_frames(h)) return rc;
+    if (h->pendingFrames > 0) {
+        // whatever follows a join is ordered by the streams again, so this launch need not leave its tags in the image: its
+        // last frame stores the reference's alpha = 1 and the usual render-N-then-read sequence needs no alpha pass at all
+        h->flushFinal = true;
+        int rc = flush_frames(h);
+        h->flushFinal = false;
+        if (rc) return rc;
+    }
     h->mainDirty = true; // whoever joins is about to put other work on the main stream: the next striped frame orders behind it
     h->chainBroken = true; // ... and the next tagged launch re-joins the two launch streams before it starts
     if (h->chainPending) {
@@ -507,7 +513,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         a.rows = h->rows;
         a.accum = h->accum();
         a.tilesY = (h->rows + 7) / 8;
-        a.keepTags = 1;
+        a.keepTags = h->flushFinal ? 0 : 1;
         int si = h->chainToggle;
         if (h->chainBroken) {
             // something else happened since the last tagged launch (an upload, a read, a striped frame ...): it was joined into
@@ -543,7 +549,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         h->chainToggle = si ^ 1;
         h->chainBroken = false; // (join_stripes above set it; this launch re-opens the chain)
         h->mainDirty = true;    // a striped frame that follows must order its helper stripe behind this launch
-        h->tagsLive = true;
+        h->tagsLive = a.keepTags != 0;
         h->lastTag = 2.0f + (float)((firstFrame + n - 1) & 1023); // pt::frame_tag of the launch's last frame
     } else if (stripes == 1) {
         if (int rc = join_stripes(h)) return rc;

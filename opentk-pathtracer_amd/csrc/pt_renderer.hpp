@@ -76,6 +76,7 @@ struct pt_renderer {
     bool chainBroken = true;           // something other than a tagged launch happened since the last one: streams re-join first
     bool tagsLive = false;             // the image's alpha holds frame tags (last one: lastTag)
     float lastTag = 0.0f;
+    bool flushFinal = false;           // the flush comes from an entry point that joins the streams: its launch stores alpha = 1 last
     bool sawBatch = false;             // the host has pipelined frames before: single frames launch tagged too, so that they overlap
     bool stripeInFlight[ptimpl::kMaxStripes] = {false, false, false, false}; // same for the stripe streams
     int drainCompaction = -1;      // donate threshold in live paths (<= 32), 0 = off, -1 = auto; env PT_DRAIN_COMPACTION
