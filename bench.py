@@ -235,11 +235,15 @@ def main():
                 return out.cuda() if out is not None else None
             return D.present(tile, H, rank, world, band_rows=BAND)
 
-        def sync_all():
+        def sync_local():
             pt.Synchronize()
             torch.cuda.synchronize()
+
+        def sync_all():  # local work done on every rank, then all ranks together (the barrier is a GPU collective on RCCL: drain it too)
+            sync_local()
             if world > 1:
                 dist.barrier()
+                torch.cuda.synchronize()
 
         # Clock warm-up (NOT counted as steps): the GPU needs ~40 ms of load to leave its idle clock; render for a fixed
         # wall time, then restart the accumulation so that the W warm-up steps and the K timed steps start from frame 0.
@@ -262,8 +266,10 @@ def main():
         for _ in range(steps):
             pt.Render()
         kernel_ms_total = pt.TimerEnd()   # HIP events on the kernel's own stream; also drains it
-        sync_all()
-        elapsed = time.perf_counter() - t0
+        sync_local()
+        elapsed = time.perf_counter() - t0  # this rank's K steps, from the common start; the job's time is the MAX over ranks (below)
+        if world > 1:
+            dist.barrier()                   # closing barrier: every rank has finished before anyone gathers
 
         t1 = time.perf_counter()
         full = gather_image()
