@@ -221,6 +221,7 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     PT_CREATE_HIP(hipEventCreate(&h->evEnd));
     PT_CREATE_HIP(hipMalloc((void **)&h->dObjects, PT_GAME_OBJECTS_UBO_SIZE));
     PT_CREATE_HIP(hipMemsetAsync(h->dObjects, 0, PT_GAME_OBJECTS_UBO_SIZE, h->stream));
+    PT_CREATE_HIP(hipMalloc((void **)&h->dGrid, (ptgrid::kMaxCells + 1) * 2 + ptgrid::kMaxRefs + 16));
     PT_CREATE_HIP(hipMalloc((void **)&h->dLut, 256 * sizeof(float)));
     PT_CREATE_HIP(hipMalloc((void **)&h->dQueue, 64 * sizeof(unsigned int)));
     PT_CREATE_HIP(hipMemsetAsync(h->dQueue, 0, 64 * sizeof(unsigned int), h->stream));
@@ -270,6 +271,7 @@ PT_API int pt_destroy(pt_handle h)
     if (h->inputsReady) (void)hipEventDestroy(h->inputsReady);
     if (h->mainDone) (void)hipEventDestroy(h->mainDone);
     if (h->dObjects) (void)hipFree(h->dObjects);
+    if (h->dGrid) (void)hipFree(h->dGrid);
     if (h->dLut) (void)hipFree(h->dLut);
     if (h->dQueue) (void)hipFree(h->dQueue);
     if (h->hostErrWord) (void)hipHostFree(h->hostErrWord);
@@ -380,6 +382,7 @@ PT_API int pt_set_params(pt_handle h, int num_spheres, int num_cuboids, int ray_
     // the kernels carry bounce / sample counters in 12-bit fields of their path records
     if (ray_depth > PT_MAX_RAY_DEPTH || spp > PT_MAX_SPP)
         return fail(h, PT_E_OUT_OF_RANGE, "ray_depth / spp exceed PT_MAX_RAY_DEPTH / PT_MAX_SPP (4095)");
+    if (num_spheres != h->numSpheres) h->gridDirty = true;
     h->numSpheres = num_spheres;
     h->numCuboids = num_cuboids;
     h->rayDepth = ray_depth;
@@ -413,6 +416,8 @@ PT_API int pt_upload_game_objects(pt_handle h, int byte_offset, int size, const 
     if (int rc = join_stripes(h)) return rc;
     // pageable source: HIP stages the bytes before returning, so the caller may reuse `src` immediately
     PT_HIP(h, hipMemcpyAsync((char *)h->dObjects + byte_offset, src, (size_t)size, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(h->objectsShadow + byte_offset, src, (size_t)size);
+    if (byte_offset < PT_MAX_SPHERES * 80) h->gridDirty = true; // (the Spheres[] array ends at byte 20,480)
     return PT_OK;
 }
 
@@ -483,6 +488,28 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     a.queueChunk = h->queueChunk > 0 ? h->queueChunk : (n > 1 && (long long)((h->width + 7) / 8) * ((h->rows + 7) / 8) < 12000 ? 4 : 8);
     a.errorWord = h->devErrWord;
     a.timeline = h->dTimeline;
+    // sphere grid of large scenes: rebuilt here, before the first launch that sees the changed scene.  Launches still in flight
+    // read the old grid: join first, then the copy is ordered behind them on the main stream like a scene upload.
+    if (h->gridDirty) {
+        h->gridDirty = false;
+        h->grid = ptgrid::build((const float *)h->objectsShadow, h->numSpheres);
+        if (h->grid.valid) {
+            if (int rc = join_stripes(h)) return rc;
+            PT_HIP(h, hipMemcpyAsync(h->dGrid, h->grid.packed.data(), h->grid.packed.size(), hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    a.grid = h->grid.valid ? h->dGrid : nullptr;
+    a.gridBytes = h->grid.valid ? (int)h->grid.packed.size() : 0;
+    a.gridLdsBytes = 0;
+    for (int k = 0; k < 3; k++) {
+        a.gridDims[k] = h->grid.dims[k];
+        a.gridLo[k] = h->grid.lo[k];
+        a.gridHi[k] = h->grid.hi[k];
+        a.gridCell[k] = h->grid.cell[k];
+        a.gridInvCell[k] = h->grid.invCell[k];
+        a.gridCenter[k] = h->grid.center[k];
+    }
+    a.gridReach2 = h->grid.reach2;
 
     // variant -> (kernel variant, stripes): 0 = default (2 stripes x 5 workgroups/CU); 20+k / 30+k / 40+k = 2 / 3 / 4
     // stripes of the persistent kernel with k+1 workgroups per CU; everything else = one kernel on the main stream
@@ -1059,6 +1086,20 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_timeline(pt_handl
     }
     PT_HIP(h, hipStreamSynchronize(h->stream));
     if (host_out) PT_HIP(h, hipMemcpy(host_out, h->dTimeline, (size_t)max_waves * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+// Test aid (not declared in the public header): the sphere grid the NEXT launch would use for the current scene.
+// out[0..2] = cells per axis, out[3] = sphere references, out[4] = 1 if a grid exists (else the in-order loop runs).
+extern "C" __attribute__((visibility("default"))) int pt_debug_sphere_grid(pt_handle h, int out[5])
+{
+    PT_CHECK_HANDLE(h);
+    if (!out) return fail(h, PT_E_BAD_ARGUMENT, "out == NULL");
+    pt_handle r = h->isGroup() ? h->parts[0] : h;
+    const ptgrid::SphereGrid g = r->gridDirty ? ptgrid::build((const float *)r->objectsShadow, r->numSpheres) : r->grid;
+    for (int k = 0; k < 3; k++) out[k] = g.dims[k];
+    out[3] = g.numRefs;
+    out[4] = g.valid ? 1 : 0;
     return PT_OK;
 }
 

@@ -50,14 +50,17 @@ struct SceneLds {
     const float *invr;  // [numSpheres rounded up to 4] 1 / radius (IEEE quotient, computed once per workgroup)
     const float *lut;   // [256] sRGB8 -> linear (only staged for SRGB8_A8 environments)
     const float4 *objects; // the std140 GameObjectsUBO in device memory (materials of large scenes are read from here)
+    const unsigned short *gridStarts; // sphere grid (large scenes, FrameArgs::grid) staged in LDS, or nullptr
+    const unsigned char *gridRefs;
 };
 
 // Geometry (16 B per sphere + 4 B 1/radius, 32 B per cuboid) is read by every ray and always lives in LDS.  The
 // 64-byte materials are read once per hit, by the winner only: they are staged too while the workgroup still fits
 // 5-per-CU, and stay in device memory (L2-resident, 26 KB) for large scenes, where they would cost a resident workgroup.
-__host__ __device__ inline size_t scene_lds_bytes(int ns, int nc, int envFormat, bool matInLds)
+__host__ __device__ inline size_t scene_lds_bytes(int ns, int nc, int envFormat, bool matInLds, int gridLdsBytes = 0)
 {
-    return (size_t)(ns + 2 * nc + (matInLds ? 4 * (ns + nc) : 0)) * 16 + (size_t)((ns + 3) & ~3) * 4 + (envFormat == 1 ? 1024 : 0);
+    return (size_t)(ns + 2 * nc + (matInLds ? 4 * (ns + nc) : 0)) * 16 + (size_t)((ns + 3) & ~3) * 4 + (envFormat == 1 ? 1024 : 0) +
+           (size_t)gridLdsBytes;
 }
 
 // ---------------------------------------------------------------------------------------------- environment
@@ -227,12 +230,100 @@ PT_DEV Material load_material(const float4 *m)
 // MASKED: only the spheres whose bit is set in the wave-uniform masks[0..3] are visited (still in index order).  The
 // masks come from cull_spheres(): a sphere outside them fails its own `t2 > 0` / discriminant test for EVERY ray of
 // the wavefront, and a sphere that fails its own test never changes T — skipping it cannot change the result.
-template <bool MASKED, bool MATLDS>
+//
+// GRID (large scenes, generic bounce): instead of all ns spheres a ray visits the spheres listed in the cells of a uniform
+// grid along its way (3D-DDA, every lane on its own), and stops once the accepted distance lies before the exit of the
+// current cell.  The result is the one the in-order loop produces, by this argument.  Call a sphere VALID for the ray when
+// it passes `disc >= 0, t1 <= t2, t2 > 0`, INSIDE when in addition t1 < 0 (the origin is in it), OUTSIDE otherwise.  The
+// in-order loop accepts every inside sphere (t1 < 0 < T always) and an outside sphere only if t1 < T, so with L = the
+// highest-index inside sphere (none: L = -1, T = FLT_MAX) its result is: the outside sphere of index > L with the smallest
+// t1 below t2(L), the lowest index among equal t1 — or L itself.  That is a minimum over a set and may be taken in any
+// order given the two tie rules.  Inside spheres contain the origin, so all of them are listed in the FIRST cell, whose
+// list is ascending: processed with the reference's own rule it yields L; later cells apply the set rule (index > L;
+// smaller t1, or equal t1 and lower index than an outside winner).  A sphere's hit point lies in its bounding box, which is
+// inflated at build time by more than the rounding error of t1 for origins within `gridReach` of the grid (pt_sphere_grid.hpp),
+// so it is listed in the cell that contains the hit point and has been tested when the walk reaches that cell.  Lanes the
+// argument does not cover — origin out of reach, non-finite or non-unit direction, an inside sphere met after the first
+// cell — take the in-order loop afterwards (needBrute).
+template <bool MASKED, bool MATLDS, bool GRID = false>
 PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, const unsigned long long *masks PROF_PARAM)
 {
     PROF_BEGIN
     float T = FLOAT_MAX, wt2 = 0.0f;
     int winner = -1;
+    bool needBrute = true;
+    if (GRID && !MASKED && sc.gridStarts != nullptr) {
+        ColdArgs ca = cold_args();
+        const v3 rel = V(o.x - ca->gridCenter[0], o.y - ca->gridCenter[1], o.z - ca->gridCenter[2]);
+        const float dd = v_dot(d, d);
+        needBrute = !(v_dot(rel, rel) <= ca->gridReach2 && dd > 0.25f && dd < 4.0f); // (NaN anywhere -> in-order loop)
+        if (!needBrute) {
+            // reciprocal direction, clamped: no infinities / NaNs in the walk (an axis the ray is parallel to is never chosen)
+            const float ix_ = __builtin_fabsf(d.x) > 1e-18f ? __builtin_amdgcn_rcpf(d.x) : (d.x < 0.0f ? -1e18f : 1e18f);
+            const float iy_ = __builtin_fabsf(d.y) > 1e-18f ? __builtin_amdgcn_rcpf(d.y) : (d.y < 0.0f ? -1e18f : 1e18f);
+            const float iz_ = __builtin_fabsf(d.z) > 1e-18f ? __builtin_amdgcn_rcpf(d.z) : (d.z < 0.0f ? -1e18f : 1e18f);
+            const float ax0 = (ca->gridLo[0] - o.x) * ix_, ax1 = (ca->gridHi[0] - o.x) * ix_;
+            const float ay0 = (ca->gridLo[1] - o.y) * iy_, ay1 = (ca->gridHi[1] - o.y) * iy_;
+            const float az0 = (ca->gridLo[2] - o.z) * iz_, az1 = (ca->gridHi[2] - o.z) * iz_;
+            const float tn = f_max(0.0f, f_max(f_min(ax0, ax1), f_max(f_min(ay0, ay1), f_min(az0, az1))));
+            const float tf = f_min(f_max(ax0, ax1), f_min(f_max(ay0, ay1), f_max(az0, az1)));
+            if (tn <= tf) { // (else: the ray misses the box that holds every sphere)
+                const int nx = ca->gridDims[0], ny = ca->gridDims[1], nz = ca->gridDims[2];
+                const v3 p = v_fma(d, tn, o);
+                int cx = (int)((p.x - ca->gridLo[0]) * ca->gridInvCell[0]), cy = (int)((p.y - ca->gridLo[1]) * ca->gridInvCell[1]),
+                    cz = (int)((p.z - ca->gridLo[2]) * ca->gridInvCell[2]);
+                cx = cx < 0 ? 0 : (cx >= nx ? nx - 1 : cx);
+                cy = cy < 0 ? 0 : (cy >= ny ? ny - 1 : cy);
+                cz = cz < 0 ? 0 : (cz >= nz ? nz - 1 : cz);
+                const bool px = !(d.x < 0.0f), py = !(d.y < 0.0f), pz = !(d.z < 0.0f);
+                // parameter at which the ray leaves the current cell along each axis, its increment per cell, cells left to the box's face
+                float mx = (ca->gridLo[0] + (float)(cx + (px ? 1 : 0)) * ca->gridCell[0] - o.x) * ix_;
+                float my = (ca->gridLo[1] + (float)(cy + (py ? 1 : 0)) * ca->gridCell[1] - o.y) * iy_;
+                float mz = (ca->gridLo[2] + (float)(cz + (pz ? 1 : 0)) * ca->gridCell[2] - o.z) * iz_;
+                const float dx = __builtin_fabsf(ca->gridCell[0] * ix_), dy = __builtin_fabsf(ca->gridCell[1] * iy_),
+                            dz = __builtin_fabsf(ca->gridCell[2] * iz_);
+                int rx = px ? nx - 1 - cx : cx, ry = py ? ny - 1 - cy : cy, rz = pz ? nz - 1 - cz : cz;
+                int cell = (cz * ny + cy) * nx + cx;
+                const int sx = px ? 1 : -1, sy = py ? nx : -nx, sz = pz ? nx * ny : -(nx * ny);
+                int L = -1;
+                bool first = true;
+                for (;;) {
+                    int k = sc.gridStarts[cell];
+                    const int kEnd = sc.gridStarts[cell + 1];
+                    for (; k < kEnd; k++) {
+                        const int j = sc.gridRefs[k];
+                        const float4 s = sc.sph[j];
+                        const v3 oc = V(o.x - s.x, o.y - s.y, o.z - s.z);
+                        const float b = v_dot(d, oc);
+                        const float c = f_fma(-s.w, s.w, v_dot(oc, oc));
+                        const float disc = f_fma(b, b, -c);
+                        if (!(disc < 0.0f) && !(c > 0.0f && b > 1e-10f)) {
+                            const float sq = pt_sqrt(disc);
+                            const float t1 = -b - sq, t2 = -b + sq;
+                            if (t1 <= t2 && t2 > 0.0f) {
+                                if (t1 < 0.0f) { // inside: the reference accepts it whatever T is
+                                    if (first) { L = j; T = t2; wt2 = t2; winner = j; }
+                                    else needBrute = true; // (cannot happen within the build's margins; never trust it silently)
+                                } else if (j > L && (t1 < T || (t1 == T && winner != L && j < winner))) {
+                                    T = t1; wt2 = t2; winner = j;
+                                }
+                            }
+                        }
+                    }
+                    first = false;
+                    const bool xm = mx <= my && mx <= mz, ym = !xm && my <= mz;
+                    const float texit = xm ? mx : (ym ? my : mz);
+                    if (T <= texit) break; // nothing listed only in later cells can be nearer
+                    int left;
+                    if (xm) { left = --rx; mx += dx; cell += sx; }
+                    else if (ym) { left = --ry; my += dy; cell += sy; }
+                    else { left = --rz; mz += dz; cell += sz; }
+                    if (left < 0) break; // left the box
+                }
+            }
+        }
+        if (needBrute) { T = FLOAT_MAX; wt2 = 0.0f; winner = -1; }
+    }
     // Sphere pass, 4 spheres per step: the four discriminants are computed branch-free from four broadcast LDS
     // reads issued together (ILP instead of one exposed LDS latency per sphere); only lanes with a real
     // forward candidate enter the exact sqrt path, and candidates are accepted strictly in index order.
@@ -267,6 +358,7 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
         }
         i = ns;
     }
+    if (!GRID || needBrute) { // (GRID: only the lanes the grid could not serve)
     for (; i + 4 <= ns; i += 4) {
         float4 s0 = sc.sph[i], s1 = sc.sph[i + 1], s2 = sc.sph[i + 2], s3 = sc.sph[i + 3];
         float b[4], c[4], disc[4];
@@ -287,6 +379,7 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
         float b = v_dot(d, oc);
         float c = f_fma(-s.w, s.w, v_dot(oc, oc));
         candidate(i, b, c, f_fma(b, b, -c));
+    }
     }
     PROF_MARK(1) // sphere pass
     v3 invd = V(f_rcp(d.x), f_rcp(d.y), f_rcp(d.z)); // slab test by reciprocal (pt-f32 contract)
@@ -469,12 +562,12 @@ PT_DEV float bsdf(v3 &ro, v3 &rd, const Hit &h, bool &isRefractive, uint32_t &se
 
 // One iteration of Radiance's bounce loop (compute.glsl:140-180) for one path.  Returns true when the path
 // continues (hit, survived Russian roulette), false when it ended (miss -> environment, or roulette kill).
-template <bool MASKED, bool MATLDS>
+template <bool MASKED, bool MATLDS, bool GRID = false>
 PT_DEV bool bounce_step_t(const SceneLds &sc, int ns, int nc, const EnvRef &env, v3 &ro, v3 &rd, v3 &throughput, v3 &rad,
                           uint32_t &seed, const unsigned long long *masks PROF_PARAM)
 {
     Hit h;
-    if (ray_trace_t<MASKED, MATLDS>(sc, ns, nc, ro, rd, h, masks PROF_PASS)) {
+    if (ray_trace_t<MASKED, MATLDS, GRID>(sc, ns, nc, ro, rd, h, masks PROF_PASS)) {
         PROF_BEGIN
         if (h.fromInside) { // Beer's law, compute.glsl:145-149
             h.normal = v_neg(h.normal);

@@ -79,8 +79,18 @@ PT_DEV SceneLds stage_scene(const FrameArgs &a)
         }
     }
     if (a.envFormat == 1 && tid < 256) lut[tid] = a.srgbLut[tid];
+    // sphere grid of large scenes (only when this launch traverses it): packed uint16 starts + uint8 refs, copied word by word
+    unsigned int *grid = (unsigned int *)(lut + (a.envFormat == 1 ? 256 : 0));
+    const unsigned short *gridStarts = nullptr;
+    const unsigned char *gridRefs = nullptr;
+    if (a.gridLdsBytes > 0) {
+        const unsigned int *src = (const unsigned int *)a.grid;
+        for (int i = tid; i < (a.gridBytes + 3) / 4; i += nthreads) grid[i] = src[i];
+        gridStarts = (const unsigned short *)grid;
+        gridRefs = (const unsigned char *)(gridStarts + a.gridDims[0] * a.gridDims[1] * a.gridDims[2] + 1);
+    }
     __syncthreads();
-    return SceneLds{sph, cmin, cmax, mat, invr, lut, obj};
+    return SceneLds{sph, cmin, cmax, mat, invr, lut, obj, gridStarts, gridRefs};
 }
 
 // XCD-aware workgroup id: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, so id b is
@@ -354,7 +364,7 @@ struct DrainControl {        // static LDS, one per workgroup
 // that handful; material / BSDF / environment code runs on coherent lanes too.  Paths that end at the first bounce are
 // resolved immediately, the survivors go to the ring as PathEntry records and are picked up by idle lanes of the
 // generic bounce loop.  Per path the arithmetic is unchanged (same tests in the same order, same RNG draws).
-template <int NWAVES, int MIN_WAVES_PER_SIMD, bool TIMELINE, bool SPP1, bool MATLDS>
+template <int NWAVES, int MIN_WAVES_PER_SIMD, bool TIMELINE, bool SPP1, bool MATLDS, bool GRID = false>
 __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_persistent_kernel(const FrameArgs a)
 {
     __shared__ __attribute__((aligned(16))) BlockQueue queue; // 16 B: keeps the dynamic-LDS base 16-byte aligned
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // the ring lives behind the staged scene in dynamic LDS
     constexpr int ENTRY_BYTES = SPP1 ? (int)sizeof(PathEntry) : (int)sizeof(RingEntry);
-    char *ringBase = (char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, a.materialsInLds != 0);
+    char *ringBase = (char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, a.materialsInLds != 0, a.gridLdsBytes);
     RingEntry *ring = (RingEntry *)(ringBase + wave * 64 * ENTRY_BYTES);  // !SPP1: primary rays
     PathEntry *pring = (PathEntry *)(ringBase + wave * 64 * ENTRY_BYTES); //  SPP1: paths after their first bounce
     PathState *pool = (PathState *)(ringBase + NWAVES * 64 * ENTRY_BYTES);
@@ -763,7 +773,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             if (active) {
                 if (!pending) {
                     bool cont = false;
-                    if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
+                    if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
                     bounce++;
                     pending = !cont || bounce >= a.rayDepth;
                 }
@@ -804,7 +814,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         if (active) {
             if (!pending) {
                 bool cont = false;
-                if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
+                if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
                 bounce++;
                 if (!cont || bounce >= a.rayDepth) {
                     irr = v_add(irr, rad);
@@ -889,7 +899,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
     SceneLds sc = stage_scene(a); // ends with __syncthreads()
     EnvRef env{nullptr, (LdsFloats)sc.lut, 0, 0};
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    char *ringBase = (char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, a.materialsInLds != 0);
+    char *ringBase = (char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, a.materialsInLds != 0, a.gridLdsBytes);
     PathEntryM *ring = (PathEntryM *)ringBase + wave * 64;
     const int CONT_BATCH_MIN = a.contBatchMin; // parked continuations that make a batch pass worth its ~950 instructions
     const int parkCapacity = a.contCapacity; // per wavefront (whatever LDS is left next to scene and rings, see the launch)
@@ -1196,6 +1206,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
 {
     FrameArgs a = args;
     a.materialsInLds = 1;
+    a.gridLdsBytes = 0;
     *ticketsConsumed = 0;
     int tiles = a.tilesX * a.tilesY;
     size_t lds = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, true);
@@ -1242,23 +1253,32 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         const size_t queues = useBatchPass ? (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry))
                               : (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) : sizeof(RingEntry)) + (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0) // no pool without drain compaction
                                 + (spp1 && a.tagged && a.drainCompaction == 0 ? (size_t)waves * PARKED_MAX * sizeof(ParkedResolve) : 0); // parked resolves of tagged launches
+        // Large scenes (spp = 1): the generic bounce walks the sphere grid (ray_trace_t<GRID>); the grid rides in LDS next to the scene
+        static const bool noGrid = std::getenv("PT_NO_SPHERE_GRID") != nullptr; // A/B runs
+        const bool useGrid = spp1 && a.grid != nullptr && a.gridBytes > 0 && !noGrid && !a.timeline;
+        a.gridLdsBytes = useGrid ? (a.gridBytes + 15) & ~15 : 0;
+        lds += (size_t)a.gridLdsBytes;
         size_t ldsTotal = lds + queues;
         // materials leave LDS when they would cost a resident workgroup (160 KB per CU; 64 B of static LDS per workgroup)
         const size_t ldsPerCU = 160 * 1024, fixedLds = 64;
-        const size_t ldsLean = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, false) + queues;
+        const size_t ldsLean = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, false, a.gridLdsBytes) + queues;
         size_t wgFull = ldsPerCU / (ldsTotal + fixedLds), wgLean = ldsPerCU / (ldsLean + fixedLds);
         if (wgFull > (size_t)blocksPerCU) wgFull = (size_t)blocksPerCU;
         if (wgLean > (size_t)blocksPerCU) wgLean = (size_t)blocksPerCU;
         static const bool forceLean = std::getenv("PT_FORCE_LEAN_LDS") != nullptr; // A/B runs: materials always from the UBO copy
-        if (wgLean > wgFull || forceLean) {
+        if (wgLean > wgFull || forceLean || useGrid) { // (the grid kernel is only instantiated for materials in device memory)
             a.materialsInLds = 0;
             ldsTotal = ldsLean;
         }
+#ifndef PT_GRID_MIN_WAVES
+#define PT_GRID_MIN_WAVES 6
+#endif
 #define PT_LAUNCH_PERSISTENT(TL, S1, ML) \
     hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, (S1 ? 6 : 5), TL, S1, ML>), dim3(nwg), dim3(256), ldsTotal, stream, a)
         const bool matLds = a.materialsInLds != 0;
         if (a.timeline && spp1 && matLds) PT_LAUNCH_PERSISTENT(true, true, true); // per-wavefront timestamps (tools/timeline.py)
         else if (spp1 && matLds) PT_LAUNCH_PERSISTENT(false, true, true);
+        else if (spp1 && useGrid) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_GRID_MIN_WAVES, false, true, false, true>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1) PT_LAUNCH_PERSISTENT(false, true, false);
         else if (useBatchPass && matLds) hipLaunchKernelGGL(pt_integrate_multisample_kernel<true>, dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (useBatchPass) hipLaunchKernelGGL(pt_integrate_multisample_kernel<false>, dim3(nwg), dim3(256), ldsTotal, stream, a);

@@ -48,6 +48,16 @@ struct FrameArgs {
     int contBatchMin;       // ... and how many of them make a batch pass worth running
     int materialsInLds;     // set by the launch: 1 = the 64-byte materials are staged in LDS, 0 = read from `objects` (large scenes)
     unsigned long long *timeline; // optional (tuning): per wavefront {start, queue exhausted, end, iterations} timestamps
+    // Sphere grid of large scenes (pt_sphere_grid.hpp; nullptr = none): a uniform grid over the spheres' bounds, per cell the
+    // ascending list of the spheres whose (slightly inflated) bounding box touches it.  Packed as uint16 starts[cells + 1]
+    // followed by uint8 refs[starts[cells]]; staged into LDS by the kernels that traverse it.
+    const unsigned char *grid;
+    int gridBytes;          // size of the packed grid
+    int gridLdsBytes;       // set by the launch: LDS bytes the staged grid takes (0 = this launch does not traverse it)
+    int gridDims[3];        // cells per axis (their product is the cell count)
+    float gridLo[3], gridHi[3], gridCell[3], gridInvCell[3]; // box, cell size and its reciprocal per axis
+    float gridCenter[3];    // a ray uses the grid when its origin lies within sqrt(gridReach2) of the box centre (see ray_trace_t)
+    float gridReach2;
 };
 
 // the persistent kernel reads the camera block straight from its kernarg segment (see primary_ray_cam)

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "pt_kernels.hpp"
+#include "pt_sphere_grid.hpp"
 
 namespace ptimpl {
 constexpr uint32_t kAlive = 0x4d335054u; // "M3PT"
@@ -47,6 +48,12 @@ struct pt_renderer {
     unsigned char atmoUbo[PT_ATMOSPHERE_UBO_SIZE] = {0}; // host shadow of UBO 2
 
     float *dObjects = nullptr;      // 26,624 B device copy of UBO 1
+    // Sphere grid of large scenes (pt_sphere_grid.hpp): rebuilt from a host shadow of UBO 1 before the first launch after the
+    // scene or the sphere count changed
+    unsigned char objectsShadow[PT_GAME_OBJECTS_UBO_SIZE] = {0};
+    bool gridDirty = true;
+    ptgrid::SphereGrid grid;
+    unsigned char *dGrid = nullptr; // (kMaxCells + 1) * 2 + kMaxRefs bytes
     float *dLut = nullptr;          // 256-entry sRGB table
     unsigned int *dQueue = nullptr; // global chunk-ticket counter of the persistent kernel (never reset: epoch scheme)
     // error word of the frame pipelining: ONE page-locked host word the kernels can reach (mapped): it is only ever

@@ -1,0 +1,116 @@
+// pt_sphere_grid.hpp — host-side build of the uniform sphere grid that the generic bounce of large scenes walks
+// (ray_trace_t<GRID> in pt_device.hpp has the traversal and the argument why its result equals the reference's in-order loop,
+// compute.glsl:226-258).  The reference has no acceleration structure: every ray tests every sphere; at 256 spheres that is
+// 2,816 of the ~4,000 vector instructions of a bounce.  The grid only decides WHICH spheres a ray tests, never how.
+//
+// Built on the host from a shadow of the std140 GameObjectsUBO whenever the scene changed (<= 256 spheres: microseconds),
+// uploaded stream-ordered like the scene itself.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace ptgrid {
+
+constexpr int kMinSpheres = 64;   // below this the in-order loop is as fast (default scene: 48 spheres)
+constexpr int kMaxCells = 256;    // uint16 starts: 514 bytes of LDS
+constexpr int kMaxRefs = 1024;    // uint8 refs: LDS budget (scene + rings + parked list leave ~1.5 KB at 6 workgroups per CU)
+
+struct SphereGrid {
+    bool valid = false;
+    int dims[3] = {1, 1, 1};
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, cell[3] = {0, 0, 0}, invCell[3] = {0, 0, 0}, center[3] = {0, 0, 0};
+    float reach2 = 0.0f;
+    std::vector<unsigned char> packed; // uint16 starts[cells + 1], uint8 refs[], padded to a multiple of 4 bytes
+    int numRefs = 0;
+};
+
+// objects: the 26,624-byte std140 block (sphere i: centre.xyz, radius at float 20 * i).
+inline SphereGrid build(const float *objects, int ns)
+{
+    SphereGrid g;
+    if (ns < kMinSpheres || ns > 256) return g;
+    double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300}, maxAbs = 0.0;
+    std::vector<double> rad(ns);
+    for (int i = 0; i < ns; i++) {
+        const float *s = objects + 20 * i;
+        for (int k = 0; k < 4; k++)
+            if (!std::isfinite(s[k])) return g; // (a sphere that can never be hit would be fine to skip, but keep the rule simple)
+        rad[i] = std::fabs((double)s[3]); // the intersection only uses radius^2
+        for (int k = 0; k < 3; k++) {
+            blo[k] = std::min(blo[k], (double)s[k] - rad[i]);
+            bhi[k] = std::max(bhi[k], (double)s[k] + rad[i]);
+            maxAbs = std::max(maxAbs, std::fabs((double)s[k]) + rad[i]);
+        }
+    }
+    double diag2 = 0.0;
+    for (int k = 0; k < 3; k++) diag2 += (bhi[k] - blo[k]) * (bhi[k] - blo[k]);
+    const double Rg = 0.5 * std::sqrt(diag2); // half diagonal of the spheres' bounding box
+    if (!(Rg > 0.0) || !(Rg < 1e15) || !(maxAbs < 1e15)) return g;
+    // A ray may use the grid when its origin is within `reach` of the box centre: then |o - c| <= D for every sphere.
+    // Rounding error of the fp32 discriminant b*b - c for such a ray: <= ~4e-7 D^2 from the dot products plus ~2.5e-7 D (M + D)
+    // from forming o - c at coordinate magnitude M; the computed hit point then lies within sqrt(2 * err) of the sphere
+    // (worst case: grazing hit of a tiny sphere).  Boxes are inflated by twice that.
+    const double reach = 3.0 * Rg, D = reach + Rg, M = maxAbs + reach;
+    const double err = 4e-7 * D * D + 2.5e-7 * D * (M + D);
+    const double margin = 2.0 * std::sqrt(2.0 * err);
+    double ext[3], vol = 1.0;
+    for (int k = 0; k < 3; k++) {
+        g.lo[k] = (float)(blo[k] - margin);
+        g.hi[k] = (float)(bhi[k] + margin);
+        // (float rounding may move a face inwards by half an ulp: far less than the margin, which is counted twice below)
+        ext[k] = (double)g.hi[k] - (double)g.lo[k];
+        if (!(ext[k] > 0.0)) return g;
+        vol *= ext[k];
+        g.center[k] = (float)(0.5 * (blo[k] + bhi[k]));
+    }
+    g.reach2 = (float)(reach * reach * 0.98); // (compared against an fp32 distance^2: stay inside the analysed range)
+    // ~1 cell per sphere, cells as cubic as the box allows
+    const double side = std::cbrt(vol / std::min(ns, kMaxCells));
+    for (int k = 0; k < 3; k++) g.dims[k] = std::max(1, std::min(32, (int)(ext[k] / side + 0.5)));
+    while (g.dims[0] * g.dims[1] * g.dims[2] > kMaxCells) {
+        int big = 0;
+        for (int k = 1; k < 3; k++)
+            if (g.dims[k] > g.dims[big]) big = k;
+        g.dims[big]--;
+    }
+    for (int k = 0; k < 3; k++) {
+        g.cell[k] = (float)(ext[k] / g.dims[k]);
+        g.invCell[k] = (float)(g.dims[k] / ext[k]);
+    }
+    const int cells = g.dims[0] * g.dims[1] * g.dims[2];
+    // cell range of every sphere's inflated box (the margin once more: the kernel finds a point's cell in fp32)
+    std::vector<int> range(6 * ns);
+    std::vector<int> count(cells + 1, 0);
+    for (int i = 0; i < ns; i++) {
+        const float *s = objects + 20 * i;
+        for (int k = 0; k < 3; k++) {
+            const double a = ((double)s[k] - rad[i] - 2.0 * margin - (double)g.lo[k]) * g.dims[k] / ext[k];
+            const double b = ((double)s[k] + rad[i] + 2.0 * margin - (double)g.lo[k]) * g.dims[k] / ext[k];
+            range[6 * i + 2 * k] = std::max(0, std::min(g.dims[k] - 1, (int)std::floor(a)));
+            range[6 * i + 2 * k + 1] = std::max(0, std::min(g.dims[k] - 1, (int)std::floor(b)));
+        }
+        for (int z = range[6 * i + 4]; z <= range[6 * i + 5]; z++)
+            for (int y = range[6 * i + 2]; y <= range[6 * i + 3]; y++)
+                for (int x = range[6 * i]; x <= range[6 * i + 1]; x++) count[(z * g.dims[1] + y) * g.dims[0] + x + 1]++;
+    }
+    for (int c = 0; c < cells; c++) count[c + 1] += count[c];
+    g.numRefs = count[cells];
+    if (g.numRefs > kMaxRefs) return g; // big overlapping spheres: every cell lists everything, the in-order loop is the better plan
+    const size_t bytes = ((size_t)(cells + 1) * 2 + (size_t)g.numRefs + 3) & ~(size_t)3;
+    g.packed.assign(bytes, 0);
+    uint16_t *starts = (uint16_t *)g.packed.data();
+    unsigned char *refs = g.packed.data() + (size_t)(cells + 1) * 2;
+    for (int c = 0; c <= cells; c++) starts[c] = (uint16_t)count[c];
+    std::vector<int> fill(count.begin(), count.end() - 1);
+    for (int i = 0; i < ns; i++) // ascending sphere index inside every cell
+        for (int z = range[6 * i + 4]; z <= range[6 * i + 5]; z++)
+            for (int y = range[6 * i + 2]; y <= range[6 * i + 3]; y++)
+                for (int x = range[6 * i]; x <= range[6 * i + 1]; x++) refs[fill[(z * g.dims[1] + y) * g.dims[0] + x]++] = (unsigned char)i;
+    g.valid = true;
+    return g;
+}
+
+} // namespace ptgrid
