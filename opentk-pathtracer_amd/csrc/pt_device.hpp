@@ -285,14 +285,25 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
                 int rx = px ? nx - 1 - cx : cx, ry = py ? ny - 1 - cy : cy, rz = pz ? nz - 1 - cz : cz;
                 int cell = (cz * ny + cy) * nx + cx;
                 const int sx = px ? 1 : -1, sy = py ? nx : -nx, sz = pz ? nx * ny : -(nx * ny);
-                int L = -1;
-                bool first = true;
+                int L = -1, viol = 0; // (flags carried through divergent loops live in VGPRs: a bool would cost mask bookkeeping per round)
+                bool first = true; // (wave-uniform: the lanes walk in lock step, one cell per round)
+                int k = sc.gridStarts[cell], kEnd = sc.gridStarts[cell + 1];
                 for (;;) {
-                    int k = sc.gridStarts[cell];
-                    const int kEnd = sc.gridStarts[cell + 1];
-                    for (; k < kEnd; k++) {
-                        const int j = sc.gridRefs[k];
-                        const float4 s = sc.sph[j];
+                    // Where the ray goes next does not depend on this cell's tests: decide it first and fetch the next cell's list
+                    // bounds now, so that their LDS latency is covered by the tests (only the stop criterion needs T).
+                    const bool xm = mx <= my && mx <= mz, ym = !xm && my <= mz;
+                    const float texit = xm ? mx : (ym ? my : mz);
+                    const bool more = (xm ? rx : (ym ? ry : rz)) > 0; // cells left along the axis of the step
+                    const int ncell = more ? cell + (xm ? sx : (ym ? sy : sz)) : cell;
+                    const int nk = sc.gridStarts[ncell], nkEnd = sc.gridStarts[ncell + 1];
+                    // two-deep software pipeline over the list: the next sphere's geometry and the index after it are in flight during
+                    // a test (reads past the end of a list fetch some other byte / sphere of the staged scene: unused)
+                    int j = sc.gridRefs[k], jn = sc.gridRefs[k + 1];
+                    float4 s = sc.sph[j];
+                    while (k < kEnd) {
+                        const float4 sn = sc.sph[jn];
+                        const int jnn = sc.gridRefs[k + 2];
+                        k++;
                         const v3 oc = V(o.x - s.x, o.y - s.y, o.z - s.z);
                         const float b = v_dot(d, oc);
                         const float c = f_fma(-s.w, s.w, v_dot(oc, oc));
@@ -300,26 +311,36 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
                         if (!(disc < 0.0f) && !(c > 0.0f && b > 1e-10f)) {
                             const float sq = pt_sqrt(disc);
                             const float t1 = -b - sq, t2 = -b + sq;
-                            if (t1 <= t2 && t2 > 0.0f) {
-                                if (t1 < 0.0f) { // inside: the reference accepts it whatever T is
-                                    if (first) { L = j; T = t2; wt2 = t2; winner = j; }
-                                    else needBrute = true; // (cannot happen within the build's margins; never trust it silently)
-                                } else if (j > L && (t1 < T || (t1 == T && winner != L && j < winner))) {
-                                    T = t1; wt2 = t2; winner = j;
-                                }
-                            }
+                            // branch-free, bit-wise on purpose: `&&` / `||` would come back as nested exec-mask regions
+                            const bool valid = (t1 <= t2) & (t2 > 0.0f);
+                            const bool inside = valid & (t1 < 0.0f); // the reference accepts it whatever T is (t1 < 0 < T)
+                            const bool nearer = (t1 < T) | ((t1 == T) & (winner != L) & (j < winner));
+                            const bool accOut = valid & !inside & (j > L) & nearer;
+                            const bool accIn = inside & first;
+                            viol |= (inside & !first) ? 1 : 0; // (cannot happen within the build's margins; never trust it silently)
+                            const bool acc = accIn | accOut;
+                            T = acc ? (inside ? t2 : t1) : T;
+                            wt2 = acc ? t2 : wt2;
+                            winner = acc ? j : winner;
+                            L = accIn ? j : L;
                         }
+                        j = jn;
+                        jn = jnn;
+                        s = sn;
                     }
                     first = false;
-                    const bool xm = mx <= my && mx <= mz, ym = !xm && my <= mz;
-                    const float texit = xm ? mx : (ym ? my : mz);
-                    if (T <= texit) break; // nothing listed only in later cells can be nearer
-                    int left;
-                    if (xm) { left = --rx; mx += dx; cell += sx; }
-                    else if (ym) { left = --ry; my += dy; cell += sy; }
-                    else { left = --rz; mz += dz; cell += sz; }
-                    if (left < 0) break; // left the box
+                    if (T <= texit || !more) break; // nothing listed only in later cells can be nearer / left the box
+                    mx = xm ? mx + dx : mx;
+                    my = ym ? my + dy : my;
+                    mz = (xm || ym) ? mz : mz + dz;
+                    rx = xm ? rx - 1 : rx;
+                    ry = ym ? ry - 1 : ry;
+                    rz = (xm || ym) ? rz : rz - 1;
+                    cell = ncell;
+                    k = nk;
+                    kEnd = nkEnd;
                 }
+                needBrute = viol != 0;
             }
         }
         if (needBrute) { T = FLOAT_MAX; wt2 = 0.0f; winner = -1; }
