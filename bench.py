@@ -207,6 +207,8 @@ def main():
     import torch.distributed as dist
 
     scene = {"default": pkg.scene.default_scene, "stress256": pkg.scene.stress_scene, "glass": pkg.scene.glass_scene}[scene_name]()
+    if os.environ.get("BENCH_STRESS_SPHERES") and scene_name == "stress256":  # tuning runs: the stress scene with fewer spheres
+        scene = pkg.scene.stress_scene(int(os.environ["BENCH_STRESS_SPHERES"]))
     cam = pkg.camera.Camera()
     csrc_hash = pkg.native.csrc_hash()
     frames_per_launch = args.frame_batch if args.variant == 0 else 1

@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -31,7 +33,8 @@ struct SphereGrid {
 inline SphereGrid build(const float *objects, int ns)
 {
     SphereGrid g;
-    if (ns < kMinSpheres || ns > 256) return g;
+    static const int minSpheres = std::getenv("PT_GRID_MIN_SPHERES") ? std::atoi(std::getenv("PT_GRID_MIN_SPHERES")) : kMinSpheres; // tuning runs
+    if (ns < minSpheres || ns < 2 || ns > 256) return g;
     double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300}, maxAbs = 0.0;
     std::vector<double> rad(ns);
     for (int i = 0; i < ns; i++) {
@@ -49,46 +52,76 @@ inline SphereGrid build(const float *objects, int ns)
     for (int k = 0; k < 3; k++) diag2 += (bhi[k] - blo[k]) * (bhi[k] - blo[k]);
     const double Rg = 0.5 * std::sqrt(diag2); // half diagonal of the spheres' bounding box
     if (!(Rg > 0.0) || !(Rg < 1e15) || !(maxAbs < 1e15)) return g;
-    // A ray may use the grid when its origin is within `reach` of the box centre: then |o - c| <= D for every sphere.
-    // Rounding error of the fp32 discriminant b*b - c for such a ray: <= ~4e-7 D^2 from the dot products plus ~2.5e-7 D (M + D)
-    // from forming o - c at coordinate magnitude M; the computed hit point then lies within sqrt(2 * err) of the sphere
-    // (worst case: grazing hit of a tiny sphere).  Boxes are inflated by twice that.
-    const double reach = 3.0 * Rg, D = reach + Rg, M = maxAbs + reach;
-    const double err = 4e-7 * D * D + 2.5e-7 * D * (M + D);
-    const double margin = 2.0 * std::sqrt(2.0 * err);
+    // A ray may use the grid when its origin is within `reach` of the box centre: then |o - c| <= D = reach + Rg for every
+    // sphere.  How far can the fp32 hit point P = o + d * t1 of such a ray lie from the sphere it belongs to?  With
+    // q(t) = |o + d t - c|^2 - r^2 = (t - t1*)(t - t2*), the computed root satisfies |q(t1)| <= 2 err, where err bounds the
+    // rounding error of the discriminant b*b - c: <= 1.2e-6 D^2 (three-term dot products, the fused b*b - c, the 2-ulp
+    // square root) + 2.5e-7 D M from forming o - c at coordinate magnitude M.  So | |P - c| - r | <= min(2 err / r, sqrt(2 err)):
+    // every sphere's box is inflated by twice that (and the same bound covers an origin that is classified as inside a
+    // sphere it touches from outside), plus a slack for the fp32 cell arithmetic of the walk itself.
+    const double reach = 2.0 * Rg, D = reach + Rg, M = maxAbs + reach;
+    const double err = 1.2e-6 * D * D + 2.5e-7 * D * M;
+    const double walkSlack = 1e-5 * (D + M);
+    std::vector<double> margin(ns);
+    double maxMargin = 0.0;
+    for (int i = 0; i < ns; i++) {
+        const double radial = rad[i] > 0.0 ? std::min(2.0 * err / rad[i], std::sqrt(2.0 * err)) : std::sqrt(2.0 * err);
+        margin[i] = 2.0 * radial + walkSlack;
+        maxMargin = std::max(maxMargin, margin[i]);
+    }
+    for (int k = 0; k < 3; k++) { // the box holds every inflated sphere box
+        blo[k] = 1e300;
+        bhi[k] = -1e300;
+    }
+    for (int i = 0; i < ns; i++) {
+        const float *s = objects + 20 * i;
+        for (int k = 0; k < 3; k++) {
+            blo[k] = std::min(blo[k], (double)s[k] - rad[i] - margin[i]);
+            bhi[k] = std::max(bhi[k], (double)s[k] + rad[i] + margin[i]);
+        }
+    }
     double ext[3], vol = 1.0;
     for (int k = 0; k < 3; k++) {
-        g.lo[k] = (float)(blo[k] - margin);
-        g.hi[k] = (float)(bhi[k] + margin);
-        // (float rounding may move a face inwards by half an ulp: far less than the margin, which is counted twice below)
+        g.lo[k] = (float)(blo[k] - walkSlack); // (fp32 rounding may move a face by half an ulp: inside the slack)
+        g.hi[k] = (float)(bhi[k] + walkSlack);
         ext[k] = (double)g.hi[k] - (double)g.lo[k];
         if (!(ext[k] > 0.0)) return g;
         vol *= ext[k];
-        g.center[k] = (float)(0.5 * (blo[k] + bhi[k]));
+        g.center[k] = (float)(0.5 * (blo[k] + bhi[k])); // (of the inflated box: within maxMargin of the spheres' own centre)
     }
-    g.reach2 = (float)(reach * reach * 0.98); // (compared against an fp32 distance^2: stay inside the analysed range)
-    // ~1 cell per sphere, cells as cubic as the box allows
-    const double side = std::cbrt(vol / std::min(ns, kMaxCells));
+    const double reachIn = std::max(0.0, reach - maxMargin) * 0.99; // (compared against an fp32 distance^2: stay inside the analysed range)
+    g.reach2 = (float)(reachIn * reachIn);
+    static const int cellTarget = std::getenv("PT_GRID_CELLS") ? std::atoi(std::getenv("PT_GRID_CELLS")) : kMaxCells; // tuning runs
+    const int maxCells = std::max(1, std::min(cellTarget, kMaxCells));
+    // about 5 cells per 8 spheres (measured on the 256-sphere scene: 8 x 5 x 4 cells beat both coarser and finer grids), cells as
+    // cubic as the box allows
+    const double side = std::cbrt(vol / std::max(1, std::min(ns * 5 / 8, maxCells)));
     for (int k = 0; k < 3; k++) g.dims[k] = std::max(1, std::min(32, (int)(ext[k] / side + 0.5)));
-    while (g.dims[0] * g.dims[1] * g.dims[2] > kMaxCells) {
+    while (g.dims[0] * g.dims[1] * g.dims[2] > maxCells) {
         int big = 0;
         for (int k = 1; k < 3; k++)
             if (g.dims[k] > g.dims[big]) big = k;
         g.dims[big]--;
+    }
+    if (const char *dimsEnv = std::getenv("PT_GRID_DIMS")) { // tuning runs: "x,y,z"
+        int x = 0, y = 0, z = 0;
+        if (std::sscanf(dimsEnv, "%d,%d,%d", &x, &y, &z) == 3 && x > 0 && y > 0 && z > 0 && x * y * z <= kMaxCells) {
+            g.dims[0] = x; g.dims[1] = y; g.dims[2] = z;
+        }
     }
     for (int k = 0; k < 3; k++) {
         g.cell[k] = (float)(ext[k] / g.dims[k]);
         g.invCell[k] = (float)(g.dims[k] / ext[k]);
     }
     const int cells = g.dims[0] * g.dims[1] * g.dims[2];
-    // cell range of every sphere's inflated box (the margin once more: the kernel finds a point's cell in fp32)
+    // cell range of every sphere's inflated box
     std::vector<int> range(6 * ns);
     std::vector<int> count(cells + 1, 0);
     for (int i = 0; i < ns; i++) {
         const float *s = objects + 20 * i;
         for (int k = 0; k < 3; k++) {
-            const double a = ((double)s[k] - rad[i] - 2.0 * margin - (double)g.lo[k]) * g.dims[k] / ext[k];
-            const double b = ((double)s[k] + rad[i] + 2.0 * margin - (double)g.lo[k]) * g.dims[k] / ext[k];
+            const double a = ((double)s[k] - rad[i] - margin[i] - (double)g.lo[k]) * g.dims[k] / ext[k];
+            const double b = ((double)s[k] + rad[i] + margin[i] - (double)g.lo[k]) * g.dims[k] / ext[k];
             range[6 * i + 2 * k] = std::max(0, std::min(g.dims[k] - 1, (int)std::floor(a)));
             range[6 * i + 2 * k + 1] = std::max(0, std::min(g.dims[k] - 1, (int)std::floor(b)));
         }
