@@ -1,6 +1,9 @@
 """Randomised HIP-vs-oracle parity fuzzing (development helper): random scenes (counts, sizes from tiny to huge, nested and
 overlapping spheres, random materials incl. glass), random cameras (inside objects too), lens, depth, spp, image size,
-frame count, batch size and (round 2) group handles over 1-3 parts; every image must equal the oracle bit for bit.   python tools/fuzz_parity.py [cases] [seed]"""
+frame count, batch size and (round 2) group handles over 1-3 parts; every image must equal the oracle bit for bit.
+FUZZ_FOCUS=pipelining: tiny images, many frames per launch.  FUZZ_FOCUS=grid: 64-256 spheres at 1 spp (the sphere grid of large
+scenes): planar / clustered / tiny / far-from-origin layouts, duplicate and degenerate spheres, cameras inside spheres and far away.
+python tools/fuzz_parity.py [cases] [seed]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,22 +27,53 @@ def rand_material():
     return S.Material(albedo=rng.rand(3), specular_chance=rng.rand() * 0.5, specular_roughness=rng.rand(), ior=1 + rng.rand(),
                       refraction_chance=rng.rand() * 0.5, refraction_roughness=rng.rand(), absorbance=rng.rand(3))
 
+GRID = os.environ.get("FUZZ_FOCUS") == "grid"  # many spheres, one sample: the sphere-grid traversal of large scenes
+
 def rand_scene():
     sc = S.Scene()
     ns = int(rng.choice([0, 1, 3, 17, 48, 64, 65, 100, 200, 256]))
     nc = int(rng.choice([0, 1, 7, 20, 64]))
     scale = float(rng.choice([0.05, 0.6, 2.0, 8.0, 40.0]))
+    lo, hi, off = np.array([-18, -11, -20], F), np.array([18, 11, 0], F), np.zeros(3, F)
+    clusters = None
+    if GRID:
+        ns = int(rng.choice([64, 65, 80, 100, 128, 160, 200, 255, 256]))
+        scale = float(rng.choice([0.01, 0.05, 0.3, 0.6, 0.6, 1.0, 2.0, 4.0]))
+        kind = rng.randint(6)
+        if kind == 1:    # everything in one plane / one line
+            hi = lo + (hi - lo) * np.array([[1, 1, 0], [1, 0, 0], [0, 1, 1]][rng.randint(3)], F)
+        elif kind == 2:  # far from the origin: coarse fp32 spacing
+            off = rng.uniform(-1, 1, 3).astype(F) * F(rng.choice([100.0, 1000.0, 20000.0]))
+        elif kind == 3:  # a few tight clusters
+            clusters = rng.uniform(lo, hi, (int(rng.choice([2, 5, 12])), 3)).astype(F)
+        elif kind == 4:  # a tiny scene
+            lo, hi = lo * F(0.01), hi * F(0.01)
+            scale *= 0.01
     for i in range(ns):
-        pos = rng.uniform([-18, -11, -20], [18, 11, 0]).astype(F)
-        sc.spheres.append(S.Sphere(pos, F(scale * rng.uniform(0.2, 1.5)), i, rand_material()))
+        if GRID and i > 0 and rng.rand() < 0.08:  # an exact copy of an earlier sphere's geometry: equal t1, the lower index must win
+            src = sc.spheres[rng.randint(i)]
+            sc.spheres.append(S.Sphere(src.position.copy(), src.radius, i, rand_material()))
+            continue
+        if clusters is not None:
+            pos = (clusters[rng.randint(len(clusters))] + rng.randn(3).astype(F) * F(1.5 * scale) + off).astype(F)
+        else:
+            pos = (rng.uniform(lo, hi).astype(F) + off).astype(F)
+        r = F(scale * rng.uniform(0.2, 1.5))
+        if GRID and rng.rand() < 0.03:
+            r = F(rng.choice([0.0, -0.7, 1e-4, 30.0]))  # degenerate, negative (only r*r is used), tiny, one giant among the small
+        sc.spheres.append(S.Sphere(pos, r, i, rand_material()))
+    sc.fuzz_offset = off
     if rng.rand() < 0.5:
         sc.cuboids = S.default_cuboids()[:min(nc, 7)]
+        for c in sc.cuboids:
+            c.position = (np.asarray(c.position, F) + off).astype(F)
     for i in range(len(sc.cuboids), nc):
-        c = rng.uniform([-18, -11, -20], [18, 11, 0]).astype(F)
+        c = (rng.uniform([-18, -11, -20], [18, 11, 0]).astype(F) + off).astype(F)
         sc.cuboids.append(S.Cuboid(c, rng.uniform(0.2, 6.0, 3).astype(F), i, rand_material()))
     return sc
 
 bad = 0
+grids_used = 0
 t0 = time.time()
 for case in range(cases):
     sc = rand_scene()
@@ -53,7 +87,19 @@ for case in range(cases):
     parts = int(rng.choice([0, 0, 0, 1, 2, 3]))  # > 0: a group handle over `parts` copies of device 0 (pt_create_multi)
     if parts and H < parts:
         parts = 0
-    cam = pkg.camera.Camera(position=tuple(float(v) for v in rng.uniform([-19, -12, -22], [19, 12, 2])),
+    cam_pos = rng.uniform([-19, -12, -22], [19, 12, 2])
+    if GRID:
+        spp = 1
+        depth = int(rng.choice([2, 5, 8, 20]))
+        W, H = int(rng.choice([33, 64, 120])), int(rng.choice([17, 40, 72]))
+        where = rng.randint(4)
+        if where == 1 and sc.num_spheres:  # inside (or at the surface of) a sphere
+            sp = sc.spheres[rng.randint(sc.num_spheres)]
+            cam_pos = np.asarray(sp.position, np.float64) - sc.fuzz_offset + rng.uniform(-1, 1, 3) * abs(float(sp.radius))
+        elif where == 2:                   # far outside: beyond the grid's reach (in-order loop)
+            cam_pos = cam_pos * float(rng.choice([3.0, 10.0, 100.0]))
+    cam_pos = cam_pos + getattr(sc, "fuzz_offset", np.zeros(3))
+    cam = pkg.camera.Camera(position=tuple(float(v) for v in cam_pos),
                             look_x=float(rng.uniform(-180, 180)), look_y=float(rng.uniform(-85, 85)))
     focal, aperture = float(rng.choice([0.5, 5.0, 20.0, 200.0])), float(rng.choice([0.0, 0.14, 2.0, 15.0]))
     env = pkg.envmap.synthetic_sky_rgba32f(16) if rng.rand() < 0.7 else pkg.envmap.synthetic_sky_srgb8(16)
@@ -63,6 +109,12 @@ for case in range(cases):
         pt.SetPartition(int(rng.choice([0, 8, 16])))
     pt.SetFrameBatch(batch)
     pt.UploadScene(sc); pt.UploadBasicData(basic)
+    if GRID:  # how many cases really walk a grid (the others fall back to the in-order loop: too few / too big spheres)
+        import ctypes as C
+        info = (C.c_int * 5)()
+        pt._lib.pt_debug_sphere_grid.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        pt._lib.pt_debug_sphere_grid(pt._h, info)
+        grids_used += int(info[4])
     desc = (f"ns={sc.num_spheres} nc={sc.num_cuboids} {W}x{H} depth={depth} spp={spp} frames={frames} batch={batch} parts={parts} "
             f"focal={focal} aperture={aperture}")
     if os.environ.get("FUZZ_VERBOSE"):
@@ -83,5 +135,5 @@ for case in range(cases):
         bad += 1
         print(f"case {case}: {int((~same).sum())}/{same.size} pixels differ: ns={sc.num_spheres} nc={sc.num_cuboids} {W}x{H} depth={depth} spp={spp} "
               f"frames={frames} batch={batch} parts={parts} focal={focal} aperture={aperture}", flush=True)
-print(f"{cases} cases, {bad} with differences, {time.time() - t0:.1f} s")
+print(f"{cases} cases, {bad} with differences, {time.time() - t0:.1f} s" + (f", {grids_used} of them walked a sphere grid" if GRID else ""))
 sys.exit(1 if bad else 0)
