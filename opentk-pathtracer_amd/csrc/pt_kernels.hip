@@ -881,7 +881,7 @@ struct ContEntry {  // 24 bytes: a pixel between two of its samples
     float irr[3];
 };
 
-template <bool MATLDS>
+template <bool MATLDS, bool GRID = false>
 __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const FrameArgs a)
 {
     __shared__ __attribute__((aligned(16))) BlockQueue queue;
@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         bool wantPark = false;
         if (active && !pending) {
             bool cont = false;
-            if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr);
+            if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr);
             bounce++;
             if (!cont || bounce >= a.rayDepth) {
                 irr = v_add(irr, rad); // compute.glsl:122
@@ -1253,9 +1253,9 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         const size_t queues = useBatchPass ? (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry))
                               : (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) : sizeof(RingEntry)) + (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0) // no pool without drain compaction
                                 + (spp1 && a.tagged && a.drainCompaction == 0 ? (size_t)waves * PARKED_MAX * sizeof(ParkedResolve) : 0); // parked resolves of tagged launches
-        // Large scenes (spp = 1): the generic bounce walks the sphere grid (ray_trace_t<GRID>); the grid rides in LDS next to the scene
+        // Large scenes: the generic bounce walks the sphere grid (ray_trace_t<GRID>); the grid rides in LDS next to the scene
         static const bool noGrid = std::getenv("PT_NO_SPHERE_GRID") != nullptr; // A/B runs
-        const bool useGrid = spp1 && a.grid != nullptr && a.gridBytes > 0 && !noGrid && !a.timeline;
+        const bool useGrid = a.grid != nullptr && a.gridBytes > 0 && !noGrid && !a.timeline;
         a.gridLdsBytes = useGrid ? (a.gridBytes + 15) & ~15 : 0;
         lds += (size_t)a.gridLdsBytes;
         size_t ldsTotal = lds + queues;
@@ -1281,8 +1281,10 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         else if (spp1 && useGrid) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_GRID_MIN_WAVES, false, true, false, true>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1) PT_LAUNCH_PERSISTENT(false, true, false);
         else if (useBatchPass && matLds) hipLaunchKernelGGL(pt_integrate_multisample_kernel<true>, dim3(nwg), dim3(256), ldsTotal, stream, a);
+        else if (useBatchPass && useGrid) hipLaunchKernelGGL((pt_integrate_multisample_kernel<false, true>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (useBatchPass) hipLaunchKernelGGL(pt_integrate_multisample_kernel<false>, dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (matLds) PT_LAUNCH_PERSISTENT(false, false, true);
+        else if (useGrid) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, 5, false, false, false, true>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else PT_LAUNCH_PERSISTENT(false, false, false);
 #undef PT_LAUNCH_PERSISTENT
         // every workgroup draws tickets until its first failing one: (numChunks - nwg) successful + nwg failing

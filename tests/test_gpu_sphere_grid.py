@@ -169,6 +169,28 @@ def test_grid_follows_scene_edits(pkg, native_lib, oracle):
     pt.Dispose()
 
 
+@pytest.mark.parametrize("batch", [1, 64], ids=["batch_pass_kernel", "in_lane_chain"])
+def test_grid_with_several_samples_per_pixel(pkg, native_lib, oracle, batch):
+    """spp > 1: frame by frame the batch-pass kernel runs (pt_integrate_multisample_kernel), pipelined over a small image the
+    in-lane sample chain — both walk the grid in their generic bounce."""
+    rng = np.random.RandomState(14)
+    sc = big_scene(pkg, rng, 240, glass_fraction=0.3)
+    cam = camera(pkg, (-17.0, 3.5, -8.6), yaw=-32.0, pitch=1.0)
+    basic = pkg.camera.basic_data_ubo(cam, W, H)
+    env = pkg.envmap.synthetic_sky_rgba32f(16)
+    want = oracle.render(W, H, basic, sc.ubo_bytes(), env, num_spheres=240, num_cuboids=sc.num_cuboids, ray_depth=6, spp=3,
+                         focal_length=12.0, aperture=0.05, num_frames=5)
+    pt = pkg.PathTracer(env, W, H, 6, 3, 12.0, 0.05)
+    pt.SetFrameBatch(batch)
+    pt.UploadScene(sc)
+    pt.UploadBasicData(basic)
+    for _ in range(5):
+        pt.Render()
+    assert grid_info(native_lib, pt)[4] == 1
+    assert_bit_exact(pt.Result, want, f"3 spp, frame batch {batch}, 240 spheres")
+    pt.Dispose()
+
+
 def test_grid_on_group_handle_and_caller_stream(pkg, native_lib, oracle):
     torch = pytest.importorskip("torch")
     rng = np.random.RandomState(13)
