@@ -17,4 +17,7 @@ python tools/emulate_strong.py gpurun_out/$RND/emulate_strong.json > gpurun_out/
 python tools/present_rate.py --json gpurun_out/$RND/present_rate.json > gpurun_out/$RND/present_rate.log 2>&1
 python tools/present_rate.py --devices 0,0 --json gpurun_out/$RND/present_rate_group2.json > gpurun_out/$RND/present_rate_group2.log 2>&1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --share-gpu --steps 256 --warmup 128 > gpurun_out/$RND/bench_2ranks_one_gpu.json 2> gpurun_out/$RND/bench_2ranks_one_gpu.err
-tail -3 gpurun_out/$RND/pytest_gpu.log; cat gpurun_out/$RND/present_rate.log | grep "ms per"; cat gpurun_out/$RND/bench_configs.log | tail -9
+bash tools/short_runs.sh > gpurun_out/$RND/short_runs.log 2>&1
+{ echo "== general"; timeout 600 python tools/fuzz_parity.py 600 101; echo "== FUZZ_FOCUS=pipelining"; FUZZ_FOCUS=pipelining timeout 600 python tools/fuzz_parity.py 300 102;
+  echo "== FUZZ_FOCUS=grid"; FUZZ_FOCUS=grid timeout 600 python tools/fuzz_parity.py 1000 103; } 2>&1 | grep -v amdgpu.ids > gpurun_out/$RND/fuzz.log
+tail -3 gpurun_out/$RND/pytest_gpu.log; cat gpurun_out/$RND/fuzz.log; cat gpurun_out/$RND/present_rate.log | grep "ms per"; cat gpurun_out/$RND/bench_configs.log | tail -9
