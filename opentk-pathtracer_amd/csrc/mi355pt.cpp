@@ -261,6 +261,8 @@ PT_API int pt_destroy(pt_handle h)
     if (h->gatherReady) (void)hipEventDestroy(h->gatherReady);
     if (h->chainStream) { (void)hipStreamSynchronize(h->chainStream); (void)hipStreamDestroy(h->chainStream); }
     if (h->chainDone) (void)hipEventDestroy(h->chainDone);
+    for (int k = 0; k < 2; k++)
+        if (h->chainPre[k]) (void)hipEventDestroy(h->chainPre[k]);
     for (int j = 0; j < ptimpl::kMaxStripes; j++)
         if (h->stripeStream[j]) (void)hipStreamSynchronize(h->stripeStream[j]);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -548,6 +550,10 @@ int launch_frames(pt_handle h, int firstFrame, int n)
             if (int rc = join_stripes(h)) return rc;
             si = 0;
             if (!h->chainDone) PT_HIP(h, hipEventCreateWithFlags(&h->chainDone, hipEventDisableTiming));
+            for (int k = 0; k < 2; k++) {
+                if (!h->chainPre[k]) PT_HIP(h, hipEventCreateWithFlags(&h->chainPre[k], hipEventDisableTiming));
+                h->chainPreValid[k] = false;
+            }
             PT_HIP(h, hipEventRecord(h->inputsReady, h->stream));
             h->chainNeedsInputs = true;
         }
@@ -561,6 +567,10 @@ int launch_frames(pt_handle h, int firstFrame, int n)
                 h->chainNeedsInputs = false;
             }
         }
+        // this launch's predecessor runs (or waits) on the other stream: become eligible no earlier than it does
+        if (h->chainPreValid[si ^ 1]) PT_HIP(h, hipStreamWaitEvent(st, h->chainPre[si ^ 1], 0));
+        PT_HIP(h, hipEventRecord(h->chainPre[si], st));
+        h->chainPreValid[si] = true;
         a.queue = h->dQueue + (si == 1 ? 32 : 0); // each launch stream draws tickets from its own counter
         a.queueBase = h->stripeQueueBase[si == 1 ? 2 : 0];
         unsigned int tickets = 0;
@@ -1101,6 +1111,27 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_sphere_grid(pt_ha
     out[3] = g.numRefs;
     out[4] = g.valid ? 1 : 0;
     return PT_OK;
+}
+
+// Test aid (not declared in the public header; needs no GPU): build the sphere grid of a std140 GameObjectsUBO on the host.
+// header[0..2] = cells per axis, [3] = references, [4] = valid; box[0..2] = lo, [3..5] = hi, [6..8] = centre, [9] = reach^2;
+// packed (capacity bytes) receives uint16 starts[cells + 1] followed by uint8 refs[].  Returns the packed size.
+extern "C" __attribute__((visibility("default"))) int pt_debug_build_sphere_grid(const float *objects, int num_spheres, int header[5],
+                                                                                 float box[10], unsigned char *packed, int capacity)
+{
+    if (!objects || !header || !box) return PT_E_BAD_ARGUMENT;
+    const ptgrid::SphereGrid g = ptgrid::build(objects, num_spheres);
+    for (int k = 0; k < 3; k++) {
+        header[k] = g.dims[k];
+        box[k] = g.lo[k];
+        box[3 + k] = g.hi[k];
+        box[6 + k] = g.center[k];
+    }
+    header[3] = g.numRefs;
+    header[4] = g.valid ? 1 : 0;
+    box[9] = g.reach2;
+    if (packed && capacity >= (int)g.packed.size() && !g.packed.empty()) std::memcpy(packed, g.packed.data(), g.packed.size());
+    return (int)g.packed.size();
 }
 
 PT_API int pt_set_frame_batch(pt_handle h, int max_frames)

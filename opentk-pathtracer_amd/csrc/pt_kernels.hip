@@ -869,7 +869,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
 // Per pixel nothing changes: same samples in the same order on one RNG stream, irradiance summed in sample order -> the
 // image is bit-identical to every other variant.  Frames are pipelined exactly as in the spp = 1 kernel (alpha tags).
 struct PathEntryM { // 72 bytes: a path after its first bounce, plus what its pixel needs for the samples that follow
-    int pix;        // linear index into accum (the pixel's image coordinates are re-derived from it where a ray is generated)
+    int pix;        // x | local row << 16 of the pixel in this launch's accumulation rows (both < 32768: no division to unpack)
     int counters;   // bounces done | sample << 12 | frame of the batch << 24 ; bit 31: no ray yet (generate it in the lane)
     uint32_t seed;
     float ro[3], rd[3], thr[3], rad[3], irr[3];
@@ -905,9 +905,9 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
     const int parkCapacity = a.contCapacity; // per wavefront (whatever LDS is left next to scene and rings, see the launch)
     ContEntry *cq = (ContEntry *)(ringBase + NWAVES * 64 * (int)sizeof(PathEntryM)) + wave * parkCapacity;
     // image coordinates of accumulation pixel `p` of this launch: x | global row << 16
-    auto pixel_xy = [&](int p) -> int {
+    auto pixel_xy = [&](int p) -> int { // p = x | local row << 16 (no division anywhere)
         ColdArgs ca = cold_args();
-        const int ly = p / ca->width, x = p - ly * ca->width;
+        const int ly = p >> 16, x = p & 0xffff;
         return x | (global_row_v(ca->bandRows, ca->bandWorld, ca->bandRank, ca->localRow0, ca->y0, ly) << 16);
     };
 
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         return make_float4(f_mix(last.x, rirr.x, w), f_mix(last.y, rirr.y, w), f_mix(last.z, rirr.z, w), alpha);
     };
     auto try_resolve = [&](int rpix, int rfj, v3 rirr, bool force) -> bool {
-        float4 *ptr = a.accum + rpix;
+        float4 *ptr = a.accum + ((rpix >> 16) * cold_args()->width + (rpix & 0xffff));
         if (!a.tagged) {
             *ptr = fold(*ptr, rirr, 0);
             return true;
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                     valid = x < width && ly < ca->rows;
                     if (valid) {
                         const int gy = global_row_v(ca->bandRows, ca->bandWorld, ca->bandRank, ca->localRow0, ca->y0, ly);
-                        tpix = ly * width + x;
+                        tpix = x | (ly << 16);
                         tpxy = x | (gy << 16);
                         tseed = pixel_seed(x, gy, ca->frame + tfj);
                     }

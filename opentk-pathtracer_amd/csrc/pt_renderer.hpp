@@ -77,6 +77,11 @@ struct pt_renderer {
     // lets the host observe the image restores alpha = 1 first (fix_alpha).
     hipStream_t chainStream = nullptr; // created on first use
     hipEvent_t chainDone = nullptr;    // recorded behind the last launch on chainStream
+    // recorded on the main / chain stream right BEFORE its latest chained launch: the next launch (other stream) waits for it, so
+    // that it cannot become eligible before the launch it depends on has (two launches that are both eligible share the machine;
+    // a dependent launch that got ALL of it first would starve its predecessor)
+    hipEvent_t chainPre[2] = {nullptr, nullptr};
+    bool chainPreValid[2] = {false, false};
     bool chainInFlight = false, chainPending = false; // (for gpu_busy / the main stream has not yet waited for it)
     int chainToggle = 0;               // stream of the next tagged launch: 0 = main, 1 = chainStream
     bool chainNeedsInputs = false;     // the chain stream has not yet waited for the inputs put on the main stream

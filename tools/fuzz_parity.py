@@ -27,6 +27,9 @@ def rand_material():
     return S.Material(albedo=rng.rand(3), specular_chance=rng.rand() * 0.5, specular_roughness=rng.rand(), ior=1 + rng.rand(),
                       refraction_chance=rng.rand() * 0.5, refraction_roughness=rng.rand(), absorbance=rng.rand(3))
 
+ONLY = int(os.environ["FUZZ_ONLY"]) if os.environ.get("FUZZ_ONLY") else None  # replay one case of a run (FUZZ_REPEAT times)
+REPEAT = int(os.environ.get("FUZZ_REPEAT", "1"))
+JITTER = np.random.RandomState(int(os.environ["FUZZ_JITTER"])) if os.environ.get("FUZZ_JITTER") else None  # random pauses between pt_render calls
 GRID = os.environ.get("FUZZ_FOCUS") == "grid"  # many spheres, one sample: the sphere-grid traversal of large scenes
 
 def rand_scene():
@@ -104,9 +107,12 @@ for case in range(cases):
     focal, aperture = float(rng.choice([0.5, 5.0, 20.0, 200.0])), float(rng.choice([0.0, 0.14, 2.0, 15.0]))
     env = pkg.envmap.synthetic_sky_rgba32f(16) if rng.rand() < 0.7 else pkg.envmap.synthetic_sky_srgb8(16)
     basic = pkg.camera.basic_data_ubo(cam, W, H)
+    band = int(rng.choice([0, 8, 16])) if parts > 1 and rng.rand() < 0.5 else None
+    if ONLY is not None and case != ONLY:  # (the random stream is consumed above: the selected case is exactly the one of a full run)
+        continue
     pt = pkg.PathTracer(env, W, H, depth, spp, focal, aperture, **({"devices": [0] * parts} if parts else {}))
-    if parts > 1 and rng.rand() < 0.5:
-        pt.SetPartition(int(rng.choice([0, 8, 16])))
+    if band is not None:
+        pt.SetPartition(band)
     pt.SetFrameBatch(batch)
     pt.UploadScene(sc); pt.UploadBasicData(basic)
     if GRID:  # how many cases really walk a grid (the others fall back to the in-order loop: too few / too big spheres)
@@ -115,25 +121,41 @@ for case in range(cases):
         pt._lib.pt_debug_sphere_grid.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         pt._lib.pt_debug_sphere_grid(pt._h, info)
         grids_used += int(info[4])
-    desc = (f"ns={sc.num_spheres} nc={sc.num_cuboids} {W}x{H} depth={depth} spp={spp} frames={frames} batch={batch} parts={parts} "
+    desc = (f"ns={sc.num_spheres} nc={sc.num_cuboids} {W}x{H} depth={depth} spp={spp} frames={frames} batch={batch} parts={parts} band={band} "
             f"focal={focal} aperture={aperture}")
     if os.environ.get("FUZZ_VERBOSE"):
         print(f"case {case}: {desc}", flush=True)
-    try:
-        for _ in range(frames): pt.Render()
-        got = pt.Result
-    except Exception as e:  # an error code from the library is a failure of the case, not of the fuzzer
-        bad += 1
-        print(f"case {case}: {e}: {desc}", flush=True)
-        pt.Dispose()
-        continue
+    want = None
+    for rep in range(REPEAT):
+        if rep and os.environ.get("FUZZ_FRESH"):  # a new handle per repetition (fresh allocations, first launches of a handle)
+            pt.Dispose()
+            pt = pkg.PathTracer(env, W, H, depth, spp, focal, aperture, **({"devices": [0] * parts} if parts else {}))
+            if band is not None:
+                pt.SetPartition(band)
+            pt.SetFrameBatch(batch)
+            pt.UploadScene(sc); pt.UploadBasicData(basic)
+        elif rep:
+            pt.ResetRenderer()
+        try:
+            for _ in range(frames):
+                pt.Render()
+                if JITTER is not None:  # vary how the library groups frames into launches (it launches when the GPU is idle)
+                    t_end = time.perf_counter() + float(JITTER.choice([0, 0, 0, 5e-6, 2e-5, 1e-4, 4e-4]))
+                    while time.perf_counter() < t_end: pass
+            got = pt.Result
+        except Exception as e:  # an error code from the library is a failure of the case, not of the fuzzer
+            bad += 1
+            print(f"case {case}: {e}: {desc}", flush=True)
+            break
+        if want is None:
+            want = oracle.render(W, H, basic, sc.ubo_bytes(), env, num_spheres=sc.num_spheres, num_cuboids=sc.num_cuboids, ray_depth=depth,
+                                 spp=spp, focal_length=focal, aperture=aperture, num_frames=frames)
+        same = (got.view(np.uint32) == want.view(np.uint32)).all(-1)
+        if not same.all():
+            bad += 1
+            ys, xs = np.nonzero(~same)
+            print(f"case {case}" + (f" (repetition {rep})" if REPEAT > 1 else "") + f": {int((~same).sum())}/{same.size} pixels differ: {desc}; first at x={xs[0]} y={ys[0]}: "
+                  f"got {got[ys[0], xs[0]]} want {want[ys[0], xs[0]]}", flush=True)
     pt.Dispose()
-    want = oracle.render(W, H, basic, sc.ubo_bytes(), env, num_spheres=sc.num_spheres, num_cuboids=sc.num_cuboids, ray_depth=depth,
-                         spp=spp, focal_length=focal, aperture=aperture, num_frames=frames)
-    same = (got.view(np.uint32) == want.view(np.uint32)).all(-1)
-    if not same.all():
-        bad += 1
-        print(f"case {case}: {int((~same).sum())}/{same.size} pixels differ: ns={sc.num_spheres} nc={sc.num_cuboids} {W}x{H} depth={depth} spp={spp} "
-              f"frames={frames} batch={batch} parts={parts} focal={focal} aperture={aperture}", flush=True)
 print(f"{cases} cases, {bad} with differences, {time.time() - t0:.1f} s" + (f", {grids_used} of them walked a sphere grid" if GRID else ""))
 sys.exit(1 if bad else 0)

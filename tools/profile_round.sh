@@ -36,6 +36,19 @@ if [ -z "$PROFILE_NO_CAL" ]; then
 fi
 python $R/bench.py ${@:2} > $OUT/bench.json 2> $OUT/bench.err
 tail -c 400 $OUT/bench.json
-# only the small files travel back (the raw traces are large): per-kernel stats + counter tables
+# only the small files travel back (the raw traces are large): per-kernel stats + counter tables, and the integrator's rows of
+# the stats run's kernel trace (start / end of every launch: consecutive launches OVERLAP on two streams, see summarize_profile.py)
+python - <<PY
+import csv, glob
+rows = []
+for f in glob.glob("$OUT/stats/**/*kernel_trace.csv", recursive=True) + glob.glob("$OUT/stats/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        if "pt_integrate" in r.get("Kernel_Name", ""):
+            rows.append({k: r[k] for k in ("Kernel_Name", "Queue_Id", "Start_Timestamp", "End_Timestamp") if k in r})
+    break
+if rows:
+    w = csv.DictWriter(open("$OUT/stats/integrator_launches.csv", "w", newline=""), fieldnames=list(rows[0]))
+    w.writeheader(); w.writerows(rows)
+PY
 find $OUT -name "*_kernel_trace.csv" -delete
 ls $OUT

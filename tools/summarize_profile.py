@@ -66,10 +66,29 @@ calls = sum(int(r["Calls"]) for r in kstats)
 known = 16.0 * pixels  # calibration: the depth-0 launch reads 16 B and writes 16 B per pixel, nothing else of size
 fetch_factor = known / (cal["FETCH_SIZE"] * 1024.0) if cal["FETCH_SIZE"] else None
 write_factor = known / (cal["WRITE_SIZE"] * 1024.0) if cal["WRITE_SIZE"] else None
+# Consecutive pipelined launches overlap pairwise (launch chaining: two streams, ordered per pixel by tags), so the SUM of the
+# launch durations counts the overlapped time twice.  The machine time per frame is the UNION of the launch intervals / frames.
+launches_path = os.path.join(src, "stats", "integrator_launches.csv")
+union_ns = None
+if os.path.exists(launches_path):
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(launches_path)))
+    union_ns, cur_s, cur_e = 0, None, None
+    for s_, e_ in iv:
+        if cur_e is None or s_ > cur_e:
+            if cur_e is not None:
+                union_ns += cur_e - cur_s
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    if cur_e is not None:
+        union_ns += cur_e - cur_s
+    shutil.copy(launches_path, os.path.join(dst, f"{tag}_integrator_launches.csv"))
 summary = {
     "tag": tag, "workload": key, "csrc_hash": CSRC_HASH, "frames_profiled": frames,
+    "kernel_ns_per_frame_rocprof_union_of_launch_intervals": (union_ns / frames if union_ns and frames else None),
+    "launch_overlap_factor": (total_ns / union_ns if union_ns else None),
     "integrator_launches": calls, "kernels": [{"name": r["Name"][:96], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])} for r in kstats],
-    "kernel_ns_per_frame_rocprof": total_ns / frames if frames else None,
+    "kernel_ns_per_frame_rocprof_sum_of_launch_durations": total_ns / frames if frames else None,
     "frames_per_launch_mean": frames / calls if calls else None,
     "bench_kernel_ms_hip_events": bench.get("roofline", {}).get("kernel_ms"),
     "bench_value_msamples": bench.get("value"),
