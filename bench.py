@@ -343,8 +343,11 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes * frames_per_launch,
                          "note": "32 B/pixel/frame (float4 load + store of the accumulation image); kernel_ms = GPU time per "
                                  "step (= frame) from HIP events on the library's streams. The default kernel pipelines up to "
-                                 "frames_per_launch consecutive frames inside ONE launch (rocprofv3's average launch duration "
-                                 "= frames_per_launch x kernel_ms; achieved = algorithmic_bytes_per_launch / that duration). "
+                                 "frames_per_launch consecutive frames inside ONE launch (achieved = algorithmic_bytes_per_launch "
+                                 "/ (frames_per_launch x kernel_ms)). Consecutive launches OVERLAP pairwise on two streams (launch "
+                                 "chaining: a launch starts in the wavefront slots its predecessor's drain frees), so rocprofv3's "
+                                 "per-launch durations add up to more than the elapsed time: profiles/<round>/*_summary.json report "
+                                 "their sum AND the union of the launch intervals per frame; the union is what kernel_ms measures. "
                                  "--frame-batch 1 launches every frame on its own (2 overlapping row-stripe launches). "
                                  "The path is fp32-VALU bound, see `valu_issue`"},
             "present_ms": round(m["present_ms"], 3),
