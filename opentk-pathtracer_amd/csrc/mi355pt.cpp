@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 
@@ -228,6 +229,9 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     PT_CREATE_HIP(hipHostMalloc((void **)&h->hostErrWord, sizeof(unsigned int), hipHostMallocMapped));
     *h->hostErrWord = 0;
     PT_CREATE_HIP(hipHostGetDevicePointer((void **)&h->devErrWord, h->hostErrWord, 0));
+    PT_CREATE_HIP(hipHostMalloc((void **)&h->hostStarted, ptimpl::kStartedWords * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(h->hostStarted, 0, ptimpl::kStartedWords * sizeof(unsigned int));
+    PT_CREATE_HIP(hipHostGetDevicePointer((void **)&h->devStarted, h->hostStarted, 0));
     {
         hipDeviceProp_t prop;
         PT_CREATE_HIP(hipGetDeviceProperties(&prop, device_id));
@@ -261,8 +265,6 @@ PT_API int pt_destroy(pt_handle h)
     if (h->gatherReady) (void)hipEventDestroy(h->gatherReady);
     if (h->chainStream) { (void)hipStreamSynchronize(h->chainStream); (void)hipStreamDestroy(h->chainStream); }
     if (h->chainDone) (void)hipEventDestroy(h->chainDone);
-    for (int k = 0; k < 2; k++)
-        if (h->chainPre[k]) (void)hipEventDestroy(h->chainPre[k]);
     for (int j = 0; j < ptimpl::kMaxStripes; j++)
         if (h->stripeStream[j]) (void)hipStreamSynchronize(h->stripeStream[j]);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -277,6 +279,7 @@ PT_API int pt_destroy(pt_handle h)
     if (h->dLut) (void)hipFree(h->dLut);
     if (h->dQueue) (void)hipFree(h->dQueue);
     if (h->hostErrWord) (void)hipHostFree(h->hostErrWord);
+    if (h->hostStarted) (void)hipHostFree(h->hostStarted);
     if (h->dEnv) (void)hipFree(h->dEnv);
     if (h->dAccum) (void)hipFree(h->dAccum);
     if (h->dRgba8) (void)hipFree(h->dRgba8);
@@ -489,6 +492,8 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     // per frame for 6,144 wavefronts) takes 4, which keeps fewer frames in flight at once (+5 % there, neutral above)
     a.queueChunk = h->queueChunk > 0 ? h->queueChunk : (n > 1 && (long long)((h->width + 7) / 8) * ((h->rows + 7) / 8) < 12000 ? 4 : 8);
     a.errorWord = h->devErrWord;
+    a.startedFlags = nullptr;
+    a.launchSeq = 0;
     a.timeline = h->dTimeline;
     // sphere grid of large scenes: rebuilt here, before the first launch that sees the changed scene.  Launches still in flight
     // read the old grid: join first, then the copy is ordered behind them on the main stream like a scene upload.
@@ -543,17 +548,28 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         a.accum = h->accum();
         a.tilesY = (h->rows + 7) / 8;
         a.keepTags = h->flushFinal ? 0 : 1;
-        int si = h->chainToggle;
+        // Beside its predecessor (other stream) only if that launch is fully resident — then this launch can only ever get the slots
+        // the predecessor's workgroups give up when they are done; otherwise behind it on the same stream (no overlap, always safe).
+        const bool mayChain = !h->chainBroken && h->lastWorkgroups > 0 && h->lastWorkgroups <= ptimpl::kStartedWords;
+        auto all_started = [&]() -> bool {
+            for (int i = 0; i < h->lastWorkgroups; i++)
+                if (((volatile unsigned int *)h->hostStarted)[i] != h->launchSeq) return false;
+            return true;
+        };
+        bool resident = mayChain && all_started();
+        if (mayChain && !resident && h->flushFinal) {
+            // the caller is about to wait for these frames anyway (read / synchronise / timer): give a predecessor that was launched
+            // a moment ago the few microseconds its workgroups need to report in (short render-N-then-read sequences)
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!resident && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(60)) resident = all_started();
+        }
+        int si = resident ? (h->lastStreamIdx ^ 1) : h->lastStreamIdx;
         if (h->chainBroken) {
             // something else happened since the last tagged launch (an upload, a read, a striped frame ...): it was joined into
             // the main stream; start there again, and let the chain stream see those inputs before its next launch
             if (int rc = join_stripes(h)) return rc;
             si = 0;
             if (!h->chainDone) PT_HIP(h, hipEventCreateWithFlags(&h->chainDone, hipEventDisableTiming));
-            for (int k = 0; k < 2; k++) {
-                if (!h->chainPre[k]) PT_HIP(h, hipEventCreateWithFlags(&h->chainPre[k], hipEventDisableTiming));
-                h->chainPreValid[k] = false;
-            }
             PT_HIP(h, hipEventRecord(h->inputsReady, h->stream));
             h->chainNeedsInputs = true;
         }
@@ -567,15 +583,17 @@ int launch_frames(pt_handle h, int firstFrame, int n)
                 h->chainNeedsInputs = false;
             }
         }
-        // this launch's predecessor runs (or waits) on the other stream: become eligible no earlier than it does
-        if (h->chainPreValid[si ^ 1]) PT_HIP(h, hipStreamWaitEvent(st, h->chainPre[si ^ 1], 0));
-        PT_HIP(h, hipEventRecord(h->chainPre[si], st));
-        h->chainPreValid[si] = true;
+        a.startedFlags = h->devStarted;
+        a.launchSeq = ++h->launchSeq;
+        if (a.launchSeq == 0) a.launchSeq = ++h->launchSeq; // (0 is what a fresh array holds)
         a.queue = h->dQueue + (si == 1 ? 32 : 0); // each launch stream draws tickets from its own counter
         a.queueBase = h->stripeQueueBase[si == 1 ? 2 : 0];
         unsigned int tickets = 0;
-        PT_HIP(h, pt::launch_integrate(a, st, &tickets));
+        int workgroups = 0;
+        PT_HIP(h, pt::launch_integrate(a, st, &tickets, &workgroups));
         h->stripeQueueBase[si == 1 ? 2 : 0] += tickets;
+        h->lastWorkgroups = workgroups;
+        h->lastStreamIdx = si;
         if (si == 1) {
             PT_HIP(h, hipEventRecord(h->chainDone, st));
             h->chainInFlight = h->chainPending = true;
@@ -583,7 +601,6 @@ int launch_frames(pt_handle h, int firstFrame, int n)
             PT_HIP(h, hipEventRecord(h->mainDone, st));
             h->mainInFlight = true;
         }
-        h->chainToggle = si ^ 1;
         h->chainBroken = false; // (join_stripes above set it; this launch re-opens the chain)
         h->mainDirty = true;    // a striped frame that follows must order its helper stripe behind this launch
         h->tagsLive = a.keepTags != 0;

@@ -390,6 +390,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         drain.alive = (unsigned int)NWAVES;
         drain.pushing = 0u;
         drain.lock = 0u;
+        if (a.startedFlags) // "this workgroup is resident" (launch chaining): a system-scope store, the host polls the word
+            __hip_atomic_store(a.startedFlags + blockIdx.x, a.launchSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     SceneLds sc = stage_scene(a); // ends with __syncthreads()
     EnvRef env{nullptr, (LdsFloats)sc.lut, 0, 0}; // descriptor is cold-loaded at the miss-shading site (bounce_step)
@@ -895,6 +897,8 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         queue.pair = ((unsigned long long)last << 32) | (unsigned long long)first;
         queue.lock = 0u;
         queue.done = 0u;
+        if (a.startedFlags) // "this workgroup is resident" (launch chaining): a system-scope store, the host polls the word
+            __hip_atomic_store(a.startedFlags + blockIdx.x, a.launchSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     SceneLds sc = stage_scene(a); // ends with __syncthreads()
     EnvRef env{nullptr, (LdsFloats)sc.lut, 0, 0};
@@ -1202,7 +1206,7 @@ static int pool_tiles_for_variant(int variant)
     }
 }
 
-hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned int *ticketsConsumed)
+hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned int *ticketsConsumed, int *workgroups)
 {
     FrameArgs a = args;
     a.materialsInLds = 1;
@@ -1290,6 +1294,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         // every workgroup draws tickets until its first failing one: (numChunks - nwg) successful + nwg failing
         // (a pipelined batch draws every chunk dynamically: numChunks successful + nwg failing)
         *ticketsConsumed = a.tagged ? (unsigned int)(numChunks + nwg) : (unsigned int)(numChunks > nwg ? numChunks : nwg);
+        if (workgroups) *workgroups = nwg;
     } else {
         int poolTiles = pool_tiles_for_variant(a.variant);
         int pools = (tiles + poolTiles - 1) / poolTiles;

@@ -48,6 +48,10 @@ struct FrameArgs {
     int contBatchMin;       // ... and how many of them make a batch pass worth running
     int materialsInLds;     // set by the launch: 1 = the 64-byte materials are staged in LDS, 0 = read from `objects` (large scenes)
     unsigned long long *timeline; // optional (tuning): per wavefront {start, queue exhausted, end, iterations} timestamps
+    // Launch chaining: every workgroup of a tagged launch stores launchSeq into startedFlags[blockIdx.x] (host-visible memory)
+    // when it starts, so that the host can tell whether the launch is fully RESIDENT (see launch_frames in mi355pt.cpp)
+    unsigned int *startedFlags;
+    unsigned int launchSeq;
     // Sphere grid of large scenes (pt_sphere_grid.hpp; nullptr = none): a uniform grid over the spheres' bounds, per cell the
     // ascending list of the spheres whose (slightly inflated) bounding box touches it.  Packed as uint16 starts[cells + 1]
     // followed by uint8 refs[starts[cells]]; staged into LDS by the kernels that traverse it.
@@ -75,7 +79,8 @@ struct AtmoArgs {
 };
 
 // ticketsConsumed: by how much the launch advances *a.queue (the caller adds it to the next launch's queueBase)
-hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int *ticketsConsumed);
+// workgroups: the grid size of the launch (persistent kernels)
+hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int *ticketsConsumed, int *workgroups = nullptr);
 hipError_t launch_atmosphere(const AtmoArgs &a, hipStream_t stream);
 hipError_t launch_clear(float4 *p, size_t n, hipStream_t stream);
 // alpha := 1 over n pixels (pt_write_result / pt_bind_result_buffer: alpha is the frame tag inside pipelined launches)

@@ -18,6 +18,7 @@
 namespace ptimpl {
 constexpr uint32_t kAlive = 0x4d335054u; // "M3PT"
 constexpr int kMaxStripes = 4;
+constexpr int kStartedWords = 4096; // >= workgroups of any persistent launch (8 per CU)
 
 // One image of the non-blocking present path (pt_present_rgba8_async / pt_present_wait).
 struct PresentSlot {
@@ -77,13 +78,15 @@ struct pt_renderer {
     // lets the host observe the image restores alpha = 1 first (fix_alpha).
     hipStream_t chainStream = nullptr; // created on first use
     hipEvent_t chainDone = nullptr;    // recorded behind the last launch on chainStream
-    // recorded on the main / chain stream right BEFORE its latest chained launch: the next launch (other stream) waits for it, so
-    // that it cannot become eligible before the launch it depends on has (two launches that are both eligible share the machine;
-    // a dependent launch that got ALL of it first would starve its predecessor)
-    hipEvent_t chainPre[2] = {nullptr, nullptr};
-    bool chainPreValid[2] = {false, false};
+    // A launch may only run BESIDE its predecessor (on the other stream) when that predecessor is fully resident: a dependent launch
+    // that got hold of the machine first would leave the launch it waits for a handful of workgroup slots (seen once: a 4K
+    // half-image took 1.7 s per frame).  Every workgroup of a tagged launch reports in by storing the launch's sequence number
+    // into its word of this host-mapped array; the host looks before it chooses the stream of the next launch.
+    unsigned int *hostStarted = nullptr, *devStarted = nullptr; // kStartedWords words
+    unsigned int launchSeq = 0;        // sequence number of the latest tagged launch
+    int lastWorkgroups = 0;            // ... its grid size
+    int lastStreamIdx = 0;             // ... and its stream (0 = main, 1 = chainStream)
     bool chainInFlight = false, chainPending = false; // (for gpu_busy / the main stream has not yet waited for it)
-    int chainToggle = 0;               // stream of the next tagged launch: 0 = main, 1 = chainStream
     bool chainNeedsInputs = false;     // the chain stream has not yet waited for the inputs put on the main stream
     bool chainBroken = true;           // something other than a tagged launch happened since the last one: streams re-join first
     bool tagsLive = false;             // the image's alpha holds frame tags (last one: lastTag)
