@@ -122,7 +122,9 @@ PT_API int pt_set_params(pt_handle h, int num_spheres, int num_cuboids, int ray_
 PT_API int pt_upload_basic_data(pt_handle h, int byte_offset, int size, const void *src);
 
 /* GameObjectsUBO.SubData(BufferOffset, size, data) — src/BaseSTD140Compatible.cs:12-16: std140 Spheres[256]@0
- * (80 B each), Cuboids[64]@20480 (96 B each). 0 <= offset, offset+size <= 26,624. */
+ * (80 B each), Cuboids[64]@20480 (96 B each). 0 <= offset, offset+size <= 26,624.  (The library shadows the block on the
+ * host: scenes with >= 64 spheres get a sphere grid for their secondary rays, rebuilt before the next launch; results are
+ * bit-identical to the reference's loop over all spheres.) */
 PT_API int pt_upload_game_objects(pt_handle h, int byte_offset, int size, const void *src);
 
 /* PathTracer.EnvironmentMap = <cube texture> — PathTracer.cs:85,118; cube creation src/MainWindow.cs:177-187,
