@@ -256,7 +256,9 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
         ColdArgs ca = cold_args();
         const v3 rel = V(o.x - ca->gridCenter[0], o.y - ca->gridCenter[1], o.z - ca->gridCenter[2]);
         const float dd = v_dot(d, d);
-        needBrute = !(v_dot(rel, rel) <= ca->gridReach2 && dd > 0.25f && dd < 4.0f); // (NaN anywhere -> in-order loop)
+        // (the intersection formulas assume a unit direction, compute.glsl:261-277; every direction the integrator produces is
+        // normalised to ~1e-7, and the margins of the build cover 1e-5: anything else — and NaN anywhere — takes the in-order loop)
+        needBrute = !(v_dot(rel, rel) <= ca->gridReach2 && __builtin_fabsf(dd - 1.0f) < 1e-5f);
         if (!needBrute) {
             // reciprocal direction, clamped: no infinities / NaNs in the walk (an axis the ray is parallel to is never chosen)
             const float ix_ = __builtin_fabsf(d.x) > 1e-18f ? __builtin_amdgcn_rcpf(d.x) : (d.x < 0.0f ? -1e18f : 1e18f);
