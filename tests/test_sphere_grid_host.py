@@ -122,3 +122,40 @@ def test_grid_is_refused_for_small_huge_and_non_finite_scenes(pkg, native_lib):
         s.position = np.array([1.0, 2.0, 3.0], np.float32)
         s.radius = np.float32(0.0)                                      # a single point: no extent
     assert not build(native_lib, sc)["valid"]
+
+
+def test_set_rule_equals_in_order_loop_for_any_visiting_order():
+    """The argument of ray_trace_t<GRID> in executable form.  Given per-sphere (valid, t1, t2) the reference visits spheres in
+    index order and accepts `valid and t1 < T` with T := t1 < 0 ? t2 : t1 (compute.glsl:226-247).  The grid walk sees the spheres
+    that contain the origin first, in ascending order (first cell), everything else in ANY order and possibly several times,
+    and applies: index > L and (t1 < T, or t1 == T and lower index than an outside winner).  Both must agree — including equal
+    t1 (duplicate spheres), several containing spheres, and a containing sphere's exit t2 tying with an outside entry."""
+    rng = np.random.RandomState(9)
+    FLT_MAX = np.float32(3.4028234663852886e38)
+    for trial in range(4000):
+        n = rng.randint(1, 24)
+        vals = np.float32(rng.choice([0.5, 1.0, 1.5, 2.0, 2.5, 3.0], n))  # few distinct values: ties are common
+        inside = rng.rand(n) < 0.25
+        valid = rng.rand(n) < 0.8
+        t1 = np.where(inside, -vals, vals).astype(np.float32)
+        t2 = (np.abs(t1) + np.float32(rng.choice([0.0, 0.5, 1.0, 2.0], n))).astype(np.float32)  # t2 >= |t1| > 0; tangent hits have t1 == t2
+        # the reference
+        T, winner = FLT_MAX, -1
+        for i in range(n):
+            if valid[i] and t1[i] < T:
+                T, winner = (t2[i] if t1[i] < 0 else t1[i]), i
+        # the walk: first cell = every containing sphere plus a random subset of the others, ascending; then the rest, shuffled, with repeats
+        first = sorted(set(np.nonzero(inside)[0]) | set(rng.choice(n, rng.randint(0, n + 1), replace=False)))
+        later = list(rng.permutation(n)) + list(rng.choice(n, rng.randint(0, n + 1)))
+        gT, gw, L = FLT_MAX, -1, -1
+        for phase, seq in ((True, first), (False, later)):
+            for j in seq:
+                if not valid[j]:
+                    continue
+                if t1[j] < 0:
+                    if phase:
+                        L, gT, gw = j, t2[j], j
+                    continue  # (later cells never list a containing sphere that the first cell does not: nothing to do)
+                if j > L and (t1[j] < gT or (t1[j] == gT and gw != L and j < gw)):
+                    gT, gw = t1[j], j
+        assert (gw, gT) == (winner, T), (trial, winner, T, gw, gT)
