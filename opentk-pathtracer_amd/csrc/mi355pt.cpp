@@ -138,6 +138,24 @@ int ensure_accum(pt_handle h)
         PT_HIP(h, hipMalloc((void **)&h->dAccum, need * sizeof(float4)));
         h->accumCapacity = need;
     }
+#ifdef PT_AUDIT
+    if (need > h->auditCapacity) {
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->dAudit) PT_HIP(h, hipFree(h->dAudit));
+        h->dAudit = nullptr;
+        h->auditCapacity = 0;
+        PT_HIP(h, hipMalloc((void **)&h->dAudit, need * sizeof(unsigned long long)));
+        h->auditCapacity = need;
+    }
+#endif
+    return PT_OK;
+}
+
+// hand-over audit: the pixels' history is unknown from here on (cleared / restored / re-bound image, frame counter reset).
+// Call with the streams joined; stream-ordered on the main stream.
+int audit_forget(pt_handle h)
+{
+    if (h->dAudit) PT_HIP(h, hipMemsetAsync(h->dAudit, 0xFF, h->tilePixels() * sizeof(unsigned long long), h->stream));
     return PT_OK;
 }
 
@@ -148,7 +166,7 @@ int clear_accum(pt_handle h)
     if (int rc = join_stripes(h)) return rc;
     PT_HIP(h, pt::launch_clear(h->accum(), h->tilePixels(), h->stream));
     h->tagsLive = false;
-    return PT_OK;
+    return audit_forget(h);
 }
 
 } // namespace
@@ -224,14 +242,22 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     PT_CREATE_HIP(hipMemsetAsync(h->dObjects, 0, PT_GAME_OBJECTS_UBO_SIZE, h->stream));
     PT_CREATE_HIP(hipMalloc((void **)&h->dGrid, (ptgrid::kMaxCells + 1) * 2 + ptgrid::kMaxRefs + 16));
     PT_CREATE_HIP(hipMalloc((void **)&h->dLut, 256 * sizeof(float)));
-    PT_CREATE_HIP(hipMalloc((void **)&h->dQueue, 64 * sizeof(unsigned int)));
-    PT_CREATE_HIP(hipMemsetAsync(h->dQueue, 0, 64 * sizeof(unsigned int), h->stream));
+    PT_CREATE_HIP(hipMalloc((void **)&h->dQueue, ptimpl::kQueueWords * sizeof(unsigned int)));
+    PT_CREATE_HIP(hipMemsetAsync(h->dQueue, 0, ptimpl::kQueueWords * sizeof(unsigned int), h->stream));
     PT_CREATE_HIP(hipHostMalloc((void **)&h->hostErrWord, sizeof(unsigned int), hipHostMallocMapped));
     *h->hostErrWord = 0;
     PT_CREATE_HIP(hipHostGetDevicePointer((void **)&h->devErrWord, h->hostErrWord, 0));
     PT_CREATE_HIP(hipHostMalloc((void **)&h->hostStarted, ptimpl::kStartedWords * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(h->hostStarted, 0, ptimpl::kStartedWords * sizeof(unsigned int));
     PT_CREATE_HIP(hipHostGetDevicePointer((void **)&h->devStarted, h->hostStarted, 0));
+#ifdef PT_AUDIT
+    {
+        const size_t words = 4 + (size_t)pt::kAuditLogRecords * pt::kAuditRecordWords;
+        PT_CREATE_HIP(hipHostMalloc((void **)&h->hostAuditLog, words * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(h->hostAuditLog, 0, words * sizeof(unsigned int));
+        PT_CREATE_HIP(hipHostGetDevicePointer((void **)&h->devAuditLog, h->hostAuditLog, 0));
+    }
+#endif
     {
         hipDeviceProp_t prop;
         PT_CREATE_HIP(hipGetDeviceProperties(&prop, device_id));
@@ -280,6 +306,8 @@ PT_API int pt_destroy(pt_handle h)
     if (h->dQueue) (void)hipFree(h->dQueue);
     if (h->hostErrWord) (void)hipHostFree(h->hostErrWord);
     if (h->hostStarted) (void)hipHostFree(h->hostStarted);
+    if (h->hostAuditLog) (void)hipHostFree(h->hostAuditLog);
+    if (h->dAudit) (void)hipFree(h->dAudit);
     if (h->dEnv) (void)hipFree(h->dEnv);
     if (h->dAccum) (void)hipFree(h->dAccum);
     if (h->dRgba8) (void)hipFree(h->dRgba8);
@@ -372,7 +400,7 @@ PT_API int pt_reset(pt_handle h)
     if (int rc = bind_device(h)) return rc;
     if (int rc = ptimpl::fix_alpha(h)) return rc;
     h->frame = 0; // PathTracer.cs:139 — frame 0 weights the old contents by 0, so no clear is needed
-    return PT_OK;
+    return audit_forget(h);
 }
 
 PT_API int pt_set_params(pt_handle h, int num_spheres, int num_cuboids, int ray_depth, int spp, float focal_length,
@@ -494,6 +522,8 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     a.errorWord = h->devErrWord;
     a.startedFlags = nullptr;
     a.launchSeq = 0;
+    a.audit = nullptr; // (set next to every a.accum below)
+    a.auditLog = h->devAuditLog;
     a.timeline = h->dTimeline;
     // sphere grid of large scenes: rebuilt here, before the first launch that sees the changed scene.  Launches still in flight
     // read the old grid: join first, then the copy is ordered behind them on the main stream like a scene upload.
@@ -546,6 +576,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         a.y0 = h->y0;
         a.rows = h->rows;
         a.accum = h->accum();
+        a.audit = h->dAudit;
         a.tilesY = (h->rows + 7) / 8;
         a.keepTags = h->flushFinal ? 0 : 1;
         // Beside its predecessor (other stream) only if that launch is fully resident — then this launch can only ever get the slots
@@ -586,12 +617,12 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         a.startedFlags = h->devStarted;
         a.launchSeq = ++h->launchSeq;
         if (a.launchSeq == 0) a.launchSeq = ++h->launchSeq; // (0 is what a fresh array holds)
-        a.queue = h->dQueue + (si == 1 ? 32 : 0); // each launch stream draws tickets from its own counter
-        a.queueBase = h->stripeQueueBase[si == 1 ? 2 : 0];
+        a.queue = h->dQueue + (si == 1 ? ptimpl::kChainQueueWord : 0); // each launch stream draws tickets from its own counter
+        a.queueBase = si == 1 ? h->chainQueueBase : h->stripeQueueBase[0];
         unsigned int tickets = 0;
         int workgroups = 0;
         PT_HIP(h, pt::launch_integrate(a, st, &tickets, &workgroups));
-        h->stripeQueueBase[si == 1 ? 2 : 0] += tickets;
+        (si == 1 ? h->chainQueueBase : h->stripeQueueBase[0]) += tickets;
         h->lastWorkgroups = workgroups;
         h->lastStreamIdx = si;
         if (si == 1) {
@@ -611,6 +642,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         a.y0 = h->y0;
         a.rows = h->rows;
         a.accum = h->accum();
+        a.audit = h->dAudit;
         a.tilesY = (h->rows + 7) / 8;
         a.queue = h->dQueue;
         a.queueBase = h->stripeQueueBase[0];
@@ -641,6 +673,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
             a.localRow0 = r0;
             a.rows = r1 - r0;
             a.accum = h->accum() + (size_t)r0 * h->width;
+            a.audit = h->dAudit ? h->dAudit + (size_t)r0 * h->width : nullptr;
             a.tilesY = (a.rows + 7) / 8;
             a.queue = h->dQueue + 16 * j;
             a.queueBase = h->stripeQueueBase[j];
@@ -839,6 +872,7 @@ PT_API int pt_write_result(pt_handle h, const float *src, size_t row_pitch_bytes
     // carries the frame tag, so a restored 2.0 must never reach the kernel
     PT_HIP(h, pt::launch_set_alpha(h->accum(), h->tilePixels(), h->stream));
     h->tagsLive = false;
+    if (int rc = audit_forget(h)) return rc;
     PT_HIP(h, hipStreamSynchronize(h->stream));
     h->frame = frame_index;
     return PT_OK;
@@ -933,9 +967,14 @@ PT_API int pt_present_wait(pt_handle h, int slot, const uint8_t **out_host_rgba8
         PT_HIP(h, hipEventSynchronize(s.copied));
         s.inFlight = false;
         s.valid = true;
-        if (h->hostErrWord && *(volatile unsigned int *)h->hostErrWord) { // the image's frames are complete: copy stream is behind them
-            *(volatile unsigned int *)h->hostErrWord = 0;
-            return fail(h, PT_E_HIP, "frame pipelining: a pixel's previous frame never arrived (result is not trustworthy)");
+        // the image's frames are complete (the copy stream is behind them): did a frame hand-over give up?  (a group handle has no
+        // error word of its own: its parts' words are consulted)
+        std::vector<pt_handle> owners = h->isGroup() ? h->parts : std::vector<pt_handle>{h};
+        for (pt_handle p : owners) {
+            if (p->hostErrWord && *(volatile unsigned int *)p->hostErrWord) {
+                *(volatile unsigned int *)p->hostErrWord = 0;
+                return fail(h, PT_E_HIP, "frame pipelining: a pixel's previous frame never arrived (result is not trustworthy)");
+            }
         }
     }
     if (out_host_rgba8) *out_host_rgba8 = s.host;
@@ -1062,7 +1101,7 @@ PT_API int pt_bind_result_buffer(pt_handle h, void *device_ptr, size_t bytes)
     h->boundBytes = device_ptr ? bytes : 0;
     // alpha doubles as the frame tag inside pipelined launches: whatever the caller's memory holds, it starts as 1
     if (device_ptr) PT_HIP(h, pt::launch_set_alpha(h->boundAccum, h->tilePixels(), h->stream));
-    return PT_OK;
+    return audit_forget(h);
 }
 
 PT_API int pt_set_stream(pt_handle h, void *hip_stream)
@@ -1149,6 +1188,34 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_build_sphere_grid
     box[9] = g.reach2;
     if (packed && capacity >= (int)g.packed.size() && !g.packed.empty()) std::memcpy(packed, g.packed.data(), g.packed.size());
     return (int)g.packed.size();
+}
+
+// Test aid (not declared in the public header): the hand-over audit of the -DPT_AUDIT build.  Drains the handle, then copies up to
+// max_records violation records (pt::kAuditRecordWords words each) and returns their number (all parts of a group together), or
+// -1000 when the library was built without PT_AUDIT.  The log is cleared.
+extern "C" __attribute__((visibility("default"))) int pt_debug_audit_read(pt_handle h, unsigned int *out_records, int max_records)
+{
+    PT_CHECK_HANDLE(h);
+#ifndef PT_AUDIT
+    (void)out_records;
+    (void)max_records;
+    return -1000;
+#else
+    if (int rc = pt_synchronize(h)) return rc;
+    int total = 0, copied = 0;
+    std::vector<pt_handle> hs = h->isGroup() ? h->parts : std::vector<pt_handle>{h};
+    for (pt_handle p : hs) {
+        volatile unsigned int *log = p->hostAuditLog;
+        if (!log) continue;
+        const int n = (int)log[0], kept = n < pt::kAuditLogRecords ? n : pt::kAuditLogRecords;
+        for (int i = 0; i < kept && copied < max_records && out_records; i++, copied++)
+            for (int k = 0; k < pt::kAuditRecordWords; k++)
+                out_records[(size_t)copied * pt::kAuditRecordWords + k] = log[4 + (size_t)i * pt::kAuditRecordWords + k];
+        total += n;
+        log[0] = 0;
+    }
+    return total;
+#endif
 }
 
 PT_API int pt_set_frame_batch(pt_handle h, int max_frames)

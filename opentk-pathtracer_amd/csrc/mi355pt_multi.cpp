@@ -374,7 +374,17 @@ PT_API int pt_multi_set_partition(pt_handle h, int band_rows)
     if (!h->isGroup()) return fail(h, PT_E_BAD_ARGUMENT, "not a group handle (pt_create_multi)");
     if (band_rows < 0 || (band_rows & 7)) return fail(h, PT_E_BAD_ARGUMENT, "band_rows must be 0 or a positive multiple of 8");
     h->groupBand = band_rows;
-    if ((int)h->parts.size() == 1) return pt_reset(h);
+    // presents of the old partition must have left the parts' slot images before their buffers are re-tiled (a part's row count
+    // can grow, and ensure_slot_device would free an image the root's copy stream is still pulling from)
+    if (int rc = root_device(h)) return rc;
+    PT_HIP(h, hipStreamSynchronize(h->copyStream));
+    for (PresentSlot &s : h->slots) s.inFlight = false;
+    if ((int)h->parts.size() == 1) { // the single part keeps the whole image: frame counter = 0 and zeroed, as documented
+        int rc = pt_set_tile(h->parts[0], 0, h->height);
+        if (rc != PT_OK) return part_fail(h, h->parts[0], rc);
+        h->frame = 0;
+        return PT_OK;
+    }
     return apply_partition(h);
 }
 

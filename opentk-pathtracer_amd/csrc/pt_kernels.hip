@@ -32,6 +32,74 @@ namespace pt {
 // ---------------------------------------------------------------------------------------------- kernels
 extern __shared__ float4 g_lds[];
 
+// ---- hand-over audit and chaos injection (tools/handover_stress.cpp; compiled out of the product library).
+// PT_AUDIT: every read-modify-write of an accumulation pixel (compute.glsl:126-129) is mirrored by ONE device-scope atomic
+// exchange on a 64-bit side word per pixel: (frames folded so far) << 32 | hash(colour stored).  The exchange returns what the
+// previous resolve of that pixel left there, so a resolve that ran out of order (frame f before f-1, or twice), or that folded
+// into a colour other than the one the previous resolve stored (a stale or torn 16-byte read), is caught the moment it happens,
+// independently of the alpha tags the product protocol relies on.  All-ones = history unknown (after a clear / reset / restore).
+// PT_CHAOS: pseudo-random s_sleep delays (0.4 us ... 100 us) at the protocol's decision points, to widen every race window.
+#ifdef PT_AUDIT
+PT_DEV uint32_t audit_hash(float x, float y, float z)
+{
+    uint32_t a = __float_as_uint(x), b = __float_as_uint(y), c = __float_as_uint(z);
+    uint32_t h = a * 0x9E3779B1u;
+    h = (h ^ (h >> 15)) + b * 0x85EBCA77u;
+    h = (h ^ (h >> 13)) + c * 0xC2B2AE3Du;
+    return h ^ (h >> 16);
+}
+// `p`: pixel index relative to a.accum; F: absolute frame being folded; `last`: the value that was loaded; `next`: the value
+// about to be stored; site: which resolve site of which kernel (for the log)
+PT_DEV void audit_resolve(const FrameArgs &a, size_t p, int F, float4 last, float4 next, int site)
+{
+    if (!a.audit) return;
+    const unsigned long long now = ((unsigned long long)(uint32_t)(F + 1) << 32) | audit_hash(next.x, next.y, next.z);
+    const unsigned long long old = atomicExch(a.audit + p, now);
+    if (old == ~0ull) return;
+    const uint32_t oldFrames = (uint32_t)(old >> 32), oldHash = (uint32_t)old, lastHash = audit_hash(last.x, last.y, last.z);
+    if (oldFrames == (uint32_t)F && (F == 0 || oldHash == lastHash)) return;
+    const unsigned int slot = atomicAdd(a.auditLog, 1u);
+    if (slot >= (unsigned int)kAuditLogRecords) return;
+    unsigned int *r = a.auditLog + 4 + slot * kAuditRecordWords;
+    r[0] = (unsigned int)site | (oldFrames != (uint32_t)F ? 0x100u : 0u) | (oldHash != lastHash ? 0x200u : 0u);
+    r[1] = (unsigned int)p;
+    r[2] = (unsigned int)F;
+    r[3] = oldFrames;
+    r[4] = oldHash;
+    r[5] = lastHash;
+    r[6] = __float_as_uint(last.w);
+    r[7] = a.launchSeq;
+    r[8] = (unsigned int)a.frame | ((unsigned int)a.batchFrames << 24);
+    r[9] = __float_as_uint(a.chainTag);
+    r[10] = blockIdx.x;
+    r[11] = (unsigned int)a.tagged | ((unsigned int)a.keepTags << 1) | ((unsigned int)a.variant << 8);
+}
+#define AUDIT_RESOLVE(a, p, F, last, next, site) audit_resolve(a, p, F, last, next, site)
+#else
+#define AUDIT_RESOLVE(a, p, F, last, next, site)
+#endif
+
+#ifdef PT_CHAOS
+// stateless: the wavefront's cycle counter hashed with the site; 3/4 of the calls do nothing, 3/16 sleep 0.4 - 3 us, 1/16 up to 100 us
+PT_DEV void chaos_point(unsigned int site)
+{
+    uint32_t r = (uint32_t)__builtin_readcyclecounter();
+    r = (r ^ (r >> 7)) * 0x9E3779B1u + site * 0x85EBCA6Bu;
+    r ^= r >> 15;
+    r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+    if ((r & 3u) != 0u) return;
+    const bool longNap = ((r >> 2) & 3u) == 0u;
+    const int n = (int)((r >> 4) & (longNap ? 31u : 7u)) + 1;
+    for (int i = 0; i < n; i++) {
+        if (longNap) __builtin_amdgcn_s_sleep(127);
+        else __builtin_amdgcn_s_sleep(16);
+    }
+}
+#define CHAOS(site) chaos_point(site)
+#else
+#define CHAOS(site)
+#endif
+
 // Stage + re-pack the scene into LDS (all 256 threads): std140 Sphere = 5 x float4 (geometry, 4 x material),
 // Cuboid = 6 x float4.  Ends with a workgroup barrier.
 PT_DEV SceneLds stage_scene(const FrameArgs &a)
@@ -117,7 +185,9 @@ __global__ __launch_bounds__(256) void pt_integrate_kernel(const FrameArgs a)
     if (px >= a.width || ly >= a.rows) return;
     const size_t idx = (size_t)ly * a.width + px;
     float4 last = a.accum[idx];                                  // imageLoad  (compute.glsl:126)
-    a.accum[idx] = shade_pixel(a, sc, env, px, global_row(a, ly), last); // imageStore (compute.glsl:129)
+    const float4 next = shade_pixel(a, sc, env, px, global_row(a, ly), last);
+    AUDIT_RESOLVE(a, idx, a.frame, last, next, 1);
+    a.accum[idx] = next;                                         // imageStore (compute.glsl:129)
 }
 
 // ---- variants 2..6: wave-level pixel pool with path regeneration.
@@ -199,7 +269,9 @@ __global__ __launch_bounds__(256) void pt_integrate_pool_kernel(const FrameArgs 
                     needRay = true;
                 } else {
                     float4 last = a.accum[pix];
-                    a.accum[pix] = resolve_pixel(a, irr, last);
+                    const float4 next = resolve_pixel(a, irr, last);
+                    AUDIT_RESOLVE(a, (size_t)pix, a.frame, last, next, 2);
+                    a.accum[pix] = next;
                     pix = -1;
                 }
             }
@@ -313,6 +385,7 @@ PT_DEV int queue_pop_tile(BlockQueue *q)
                 unsigned int ticket = 0;
                 ColdArgs ca = cold_args();
                 const int numTiles = ca->tilesX * ca->tilesY * ca->batchFrames, chunk = ca->queueChunk; // (frame, tile) pairs, frame-major
+                CHAOS(2);
                 if (leader) ticket = atomicAdd(ca->queue, 1u) - ca->queueBase;
                 ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
                 long long first = ((ca->tagged ? 0ll : (long long)gridDim.x) + ticket) * chunk; // tagged launches have no static chunks
@@ -393,6 +466,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         if (a.startedFlags) // "this workgroup is resident" (launch chaining): a system-scope store, the host polls the word
             __hip_atomic_store(a.startedFlags + blockIdx.x, a.launchSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    CHAOS(1);
     SceneLds sc = stage_scene(a); // ends with __syncthreads()
     EnvRef env{nullptr, (LdsFloats)sc.lut, 0, 0}; // descriptor is cold-loaded at the miss-shading site (bounce_step)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -450,13 +524,20 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         float4 *ptr = a.accum + rpix;
         if (!a.tagged) {
             float4 last = *ptr;
-            *ptr = fold(last, rirr, 0);
+            const float4 next = fold(last, rirr, 0);
+            AUDIT_RESOLVE(a, (size_t)rpix, a.frame, last, next, 3);
+            *ptr = next;
             return true;
         }
+        CHAOS(10);
         float4 last = load_pixel_sc1(ptr);
         const float expected = rfj > 0 ? frame_tag(a.frame + rfj - 1) : a.chainTag; // (0 = the launch's first frame has no predecessor in flight)
         if (expected != 0.0f && !force && last.w != expected) return false;
-        store_pixel_sc1(ptr, fold(last, rirr, rfj));
+        CHAOS(11);
+        const float4 next = fold(last, rirr, rfj);
+        AUDIT_RESOLVE(a, (size_t)rpix, a.frame + rfj, last, next, 4);
+        store_pixel_sc1(ptr, next);
+        CHAOS(12);
         return true;
     };
 
@@ -480,6 +561,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     // retry the parked resolves: lane l takes entry l; the ones that still have to wait are compacted to the front
     auto service_parked = [&](bool force) -> void {
         if (nparked == 0) return;
+        CHAOS(4);
         const bool mine = lane < nparked;
         ParkedResolve e = {0, 0, {0.0f, 0.0f, 0.0f}};
         bool keep = false;
@@ -603,6 +685,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                 if (exhausted) break;
                 if (SPP1 && avail == 0) continue; // every path of that tile ended at its first bounce: next tile
             }
+            CHAOS(3);
             if constexpr (SPP1) {
                 // ---- idle lanes pop paths (top down)
                 int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -900,6 +983,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         if (a.startedFlags) // "this workgroup is resident" (launch chaining): a system-scope store, the host polls the word
             __hip_atomic_store(a.startedFlags + blockIdx.x, a.launchSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    CHAOS(1);
     SceneLds sc = stage_scene(a); // ends with __syncthreads()
     EnvRef env{nullptr, (LdsFloats)sc.lut, 0, 0};
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -935,15 +1019,23 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         return make_float4(f_mix(last.x, rirr.x, w), f_mix(last.y, rirr.y, w), f_mix(last.z, rirr.z, w), alpha);
     };
     auto try_resolve = [&](int rpix, int rfj, v3 rirr, bool force) -> bool {
-        float4 *ptr = a.accum + ((rpix >> 16) * cold_args()->width + (rpix & 0xffff));
+        const size_t pidx = (size_t)((rpix >> 16) * cold_args()->width + (rpix & 0xffff));
+        float4 *ptr = a.accum + pidx;
         if (!a.tagged) {
-            *ptr = fold(*ptr, rirr, 0);
+            const float4 last = *ptr, next = fold(last, rirr, 0);
+            AUDIT_RESOLVE(a, pidx, a.frame, last, next, 5);
+            *ptr = next;
             return true;
         }
+        CHAOS(20);
         float4 last = load_pixel_sc1(ptr);
         const float expected = rfj > 0 ? frame_tag(a.frame + rfj - 1) : a.chainTag;
         if (expected != 0.0f && !force && last.w != expected) return false;
-        store_pixel_sc1(ptr, fold(last, rirr, rfj));
+        CHAOS(21);
+        const float4 next = fold(last, rirr, rfj);
+        AUDIT_RESOLVE(a, pidx, a.frame + rfj, last, next, 6);
+        store_pixel_sc1(ptr, next);
+        CHAOS(22);
         return true;
     };
 
@@ -976,10 +1068,21 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
     for (;;) {
         bool idle = pix < 0;
         unsigned long long m = __ballot(idle);
-        for (int pass = 0; pass < 16 && m != 0ull; pass++) {
-            if (avail == 0) {
+        // ---- forced batch pass (the progress guarantee of the pipelining).  When EVERY lane holds a finished pixel that waits for its
+        // previous frame, nothing pops the ring or runs a batch pass any more — and the work those lanes wait for may be parked in this
+        // wavefront's own queue.  A batch pass needs no idle lane (it computes in its own registers and only needs ring slots), so
+        // such a wavefront runs one over the oldest parked records anyway, appending the survivors to the ring.  Every record keeps
+        // exactly one place (lane, ring slot or queue slot), a pass that finds real work advances it by a bounce or a sample and
+        // leaves at least as much room in the queue as it put paths into the ring — so rescue() below can then free lanes for them.
+        // Waiting records it meets are retried and rotate to the back of the FIFO.  With the tickets handed out frame-major, all
+        // work of the oldest unfinished frame is therefore always executed by whichever wavefront holds it: no cycle of waits.
+        bool forcePass = parked > 0 && avail < 64 && __ballot(!(pix >= 0 && pending && !needRay)) == 0ull;
+        for (int pass = 0; pass < 16 && (m != 0ull || forcePass); pass++) {
+            if (avail == 0 || forcePass) {
                 // ---- batch pass: 64 parked continuations, or the next tile's 64 pixels (sample 0)
-                const bool fromQueue = parked >= CONT_BATCH_MIN || (exhausted && parked > 0);
+                const bool fromQueue = forcePass || parked >= CONT_BATCH_MIN || (exhausted && parked > 0);
+                forcePass = false;
+                const int base = avail; // ring entries already there (only a forced pass finds any)
                 int tile = -1;
                 if (!fromQueue) {
                     if (exhausted) break;
@@ -998,7 +1101,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                 uint32_t tseed = 0;
                 v3 tirr = V(0.0f, 0.0f, 0.0f);
                 if (fromQueue) {
-                    const int n = parked < 64 ? parked : 64;
+                    const int n = parked < 64 - base ? parked : 64 - base;
                     valid = lane < n;
                     if (valid) {
                         const ContEntry e = cq[qslot(lane)]; // oldest first: a parked pixel never waits behind younger ones
@@ -1038,7 +1141,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                 // 1. paths that continue go to the ring
                 const unsigned long long cm = __ballot(tcont);
                 if (tcont) {
-                    const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+                    const int slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
                     PathEntryM e;
                     e.pix = tpix; e.counters = 1 | (tsample << 12) | (tfj << 24); e.seed = tseed;
                     e.ro[0] = to.x; e.ro[1] = to.y; e.ro[2] = to.z;
@@ -1048,7 +1151,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                     e.irr[0] = tirr.x; e.irr[1] = tirr.y; e.irr[2] = tirr.z;
                     ring[slot] = e;
                 }
-                avail = __builtin_popcountll(cm);
+                avail = base + __builtin_popcountll(cm);
                 // 2. samples that ended at their first bounce: irradiance += Radiance (compute.glsl:122); more samples to go ->
                 // park the continuation; the pixel's last sample -> compute.glsl:125-129
                 const bool tfin = valid && !tcont;
@@ -1229,6 +1332,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         int numChunks = (int)(((long long)tiles * a.batchFrames + a.queueChunk - 1) / a.queueChunk); // (frame, tile) pairs
         if (nwg > numChunks) nwg = numChunks;
         if (nwg < 1) nwg = 1;
+        if (nwg > kStartedWords) a.startedFlags = nullptr; // (the roll call has kStartedWords words; the host then never chains on this launch)
         const bool spp1 = a.spp == 1; // tile-pass kernels (the ring holds 60-byte paths instead of 40-byte primary rays)
         // spp > 1: the batch-pass kernel (every sample's first bounce coherent and culled), unless drain compaction is asked
         // for (single-launch frames of the A/B variants and of caller-owned streams keep the in-lane sample chain)
@@ -1236,11 +1340,15 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         // ... and unless frames are pipelined over a SMALL image.  Inside a tagged launch a finished pixel may wait for its
         // previous frame; the batch-pass kernel keeps work outside the lanes (parked continuations), and when consecutive frames
         // of a tile meet in one wavefront — few tiles per frame for the ~5,000 resident wavefronts — every lane, and then the
-        // whole queue, can fill up with results that wait for exactly that parked work.  The kernel's rescue (park waiting
-        // results too) and stall bound turn that into a delay or, at worst, an error code, never a hang; but it HAS been seen
-        // (225 tiles per frame, 32 frames: 2-4 % of launches), so such launches use the in-lane sample chain, whose ring
-        // discipline cannot form that cycle.  16,384 tiles per frame (1024 x 1024) leave a wavefront 3-4 tiles per frame.
-        const bool smallPipelined = a.tagged && (long long)a.tilesX * a.tilesY < 16384;
+        // whole queue, can fill up with results that wait for exactly that parked work.  Round 2 saw that end in the stall bound's
+        // error code (225 tiles per frame, 32 frames: 2-4 % of launches).  Round 3: the kernel's FORCED BATCH PASS (a wavefront
+        // whose lanes all wait runs a pass over its oldest parked records anyway) makes the parked work progress whatever the lanes
+        // hold, so the cycle cannot form any more (tools/handover_stress --multisample with PT_BATCH_PASS_MIN_TILES=0 sends every
+        // such launch through this kernel).  Small images still take the in-lane sample chain — for speed: when consecutive frames
+        // of a tile meet in one wavefront all the time, the queue mostly rotates waiting records.  16,384 tiles per frame
+        // (1024 x 1024) leave a wavefront 3-4 tiles per frame.
+        static const long long batchPassMinTiles = std::getenv("PT_BATCH_PASS_MIN_TILES") ? std::atoll(std::getenv("PT_BATCH_PASS_MIN_TILES")) : 16384; // (0: stress runs)
+        const bool smallPipelined = a.tagged && (long long)a.tilesX * a.tilesY < batchPassMinTiles;
         const bool useBatchPass = !spp1 && a.drainCompaction == 0 && !noBatchPass && !smallPipelined;
         // the continuation queues take what a 5-per-CU workgroup has left next to the scene and the rings (<= 128 entries per wavefront)
         int park = 0;

@@ -62,7 +62,15 @@ struct FrameArgs {
     float gridLo[3], gridHi[3], gridCell[3], gridInvCell[3]; // box, cell size and its reciprocal per axis
     float gridCenter[3];    // a ray uses the grid when its origin lies within sqrt(gridReach2) of the box centre (see ray_trace_t)
     float gridReach2;
+    // Hand-over audit (only compiled into the -DPT_AUDIT build, tools/handover_stress.cpp; nullptr otherwise): one 64-bit word per
+    // accumulation pixel = (frames folded so far) << 32 | hash of the colour stored last, maintained with device-scope atomic
+    // exchanges next to every read-modify-write of the pixel — an independent, atomics-only record of compute.glsl:126-129's
+    // "one ordered read-modify-write per pixel per frame".  Violations go to auditLog (host-mapped): [0] = count, 12 words each.
+    unsigned long long *audit;
+    unsigned int *auditLog;
 };
+constexpr int kAuditLogRecords = 1024, kAuditRecordWords = 12;
+constexpr int kStartedWords = 4096; // capacity of FrameArgs::startedFlags (a launch with more workgroups does not report in)
 
 // the persistent kernel reads the camera block straight from its kernarg segment (see primary_ray_cam)
 static_assert(offsetof(FrameArgs, invProj) == 0 && offsetof(FrameArgs, invView) == 64 && offsetof(FrameArgs, viewPos) == 128 &&

@@ -18,7 +18,9 @@
 namespace ptimpl {
 constexpr uint32_t kAlive = 0x4d335054u; // "M3PT"
 constexpr int kMaxStripes = 4;
-constexpr int kStartedWords = 4096; // >= workgroups of any persistent launch (8 per CU)
+// global ticket counters of the persistent kernel: stripe j draws from word 16 * j, the chain stream from its own 128-byte line
+constexpr int kQueueWords = 128, kChainQueueWord = 64;
+constexpr int kStartedWords = pt::kStartedWords; // >= workgroups of any persistent launch (8 per CU)
 
 // One image of the non-blocking present path (pt_present_rgba8_async / pt_present_wait).
 struct PresentSlot {
@@ -107,6 +109,11 @@ struct pt_renderer {
     size_t rgba8Capacity = 0;     // in pixels
     size_t boundBytes = 0;
 
+    // hand-over audit (only allocated by the -DPT_AUDIT build, see pt_kernels.hip): side word per accumulation pixel + violation log
+    unsigned long long *dAudit = nullptr;
+    size_t auditCapacity = 0; // in pixels
+    unsigned int *hostAuditLog = nullptr, *devAuditLog = nullptr;
+
     hipStream_t ownStream = nullptr, stream = nullptr;
     // Stripes: one frame = `stripes` persistent kernels over contiguous row ranges of the tile, each on its own
     // stream, so that one stripe's frame-end drain overlaps the other stripe's main phase.
@@ -117,6 +124,7 @@ struct pt_renderer {
     bool stripePending[ptimpl::kMaxStripes] = {false, false, false, false};
     int stripeRow0[ptimpl::kMaxStripes] = {0, 0, 0, 0}, stripeRows[ptimpl::kMaxStripes] = {0, 0, 0, 0}; // rows of the last launch
     unsigned int stripeQueueBase[ptimpl::kMaxStripes] = {0, 0, 0, 0};
+    unsigned int chainQueueBase = 0; // same for the chain stream's counter
     hipEvent_t evBegin = nullptr, evEnd = nullptr;
 
     // non-blocking present

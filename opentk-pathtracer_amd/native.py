@@ -77,6 +77,41 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+# Diagnostic builds of the same sources (never loaded by the product path; tools/handover_stress.cpp and the GPU test that runs it):
+#   audit       -DPT_AUDIT            every pixel read-modify-write mirrored by a device-scope atomic side word (pt_kernels.hip)
+#   chaos       -DPT_CHAOS            pseudo-random s_sleep delays at the hand-over protocol's decision points
+#   audit_chaos both
+VARIANTS = {"audit": ["-DPT_AUDIT"], "chaos": ["-DPT_CHAOS"], "audit_chaos": ["-DPT_AUDIT", "-DPT_CHAOS"]}
+STRESS_BIN = os.path.join(REPO, "tools", "handover_stress.bin")
+
+
+def variant_path(name: str) -> str:
+    return os.path.join(HERE, f"libmi355pt_{name}.so")
+
+
+def build_variant(name: str, force: bool = False) -> str:
+    out = variant_path(name)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [HEADER]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    cmd = [hipcc_path()] + HIPCC_FLAGS + VARIANTS[name] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError(f"hipcc failed building {out}:\n" + p.stdout + p.stderr)
+    return out
+
+
+def build_stress_tool(force: bool = False) -> str:
+    """g++ tools/handover_stress.cpp (dlopens whichever build of the library it is pointed at)."""
+    src = os.path.join(REPO, "tools", "handover_stress.cpp")
+    if not force and os.path.exists(STRESS_BIN) and os.path.getmtime(src) <= os.path.getmtime(STRESS_BIN):
+        return STRESS_BIN
+    p = subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", src, "-ldl", "-o", STRESS_BIN], capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("g++ failed building handover_stress:\n" + p.stdout + p.stderr)
+    return STRESS_BIN
+
+
 HOST_DEMO = os.path.join(HERE, "host", "pt_host_demo")
 
 

@@ -1,0 +1,473 @@
+// handover_stress.cpp — native stress test of the frame hand-over machinery of libmi355pt.so (development / test tool).
+//
+// What it checks.  The reference performs ONE ordered read-modify-write per pixel per frame (compute.glsl:126-129).  The
+// library keeps that order per pixel while it pipelines frames inside a launch, chains launches over two streams, parks
+// resolves, tiles the image over the parts of a group handle and defers launches on the host.  This tool drives thousands of
+// random call sequences per minute through the C ABI — tiny images (consecutive frames of a tile in flight together all the
+// time), 1-200 frames, spp 1-4, group handles over 1-5 parts, uploads / resets / reads / presents / batch-size changes at
+// random frames, random host pauses — and compares every observed image BIT FOR BIT with the same call sequence rendered by
+// the simplest kernel there is (variant 1: one wavefront per tile, one plain launch per frame, nothing pipelined).
+// Both sides run on the GPU, so a case costs ~2 ms instead of the ~0.4 s of an oracle-checked fuzz case.
+//
+// Run against the audit / chaos builds (opentk-pathtracer_amd/native.py: build_variant) it also reads the kernels' own
+// hand-over audit (pt_debug_audit_read): out-of-order or stale resolves are reported even if the final image is right.
+//
+//   g++ -O2 -std=c++17 tools/handover_stress.cpp -ldl -o tools/handover_stress.bin
+//   tools/handover_stress.bin <libmi355pt*.so> <cases> <seed> [--only N] [--repeat N] [--verbose] [--devices 0,1,..]
+//                             [--max-parts N] [--no-ops] [--fresh] [--multisample (spp 2-7, up to 200x72)] [--ref-lib lib.so]
+// PT_BATCH_PASS_MIN_TILES=0 in the environment sends every pipelined spp > 1 launch through the batch-pass kernel.
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+typedef void *H;
+struct Api {
+    int (*create)(int, int, int, H *);
+    int (*create_multi)(const int *, int, int, int, H *);
+    int (*destroy)(H);
+    int (*set_partition)(H, int);
+    int (*set_size)(H, int, int);
+    int (*reset)(H);
+    int (*set_params)(H, int, int, int, int, float, float);
+    int (*upload_basic)(H, int, int, const void *);
+    int (*upload_objects)(H, int, int, const void *);
+    int (*set_env)(H, int, int, const void *const *);
+    int (*render)(H, int *);
+    int (*set_batch)(H, int);
+    int (*read)(H, float *, size_t);
+    int (*present)(H, uint8_t *, size_t);
+    int (*present_async)(H, int);
+    int (*present_wait)(H, int, const uint8_t **, size_t *, int *);
+    int (*sync)(H);
+    int (*devptr)(H, void **, size_t *);
+    int (*set_variant)(H, int);
+    int (*device_count)(void);
+    const char *(*last_error)(H);
+    int (*audit_read)(H, unsigned int *, int);
+};
+
+static bool load_api(const char *path, Api &a)
+{
+    void *so = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!so) {
+        std::fprintf(stderr, "dlopen %s: %s\n", path, dlerror());
+        return false;
+    }
+#define SYM(field, name)                                                                                               \
+    *(void **)&a.field = dlsym(so, name);                                                                              \
+    if (!a.field) {                                                                                                    \
+        std::fprintf(stderr, "%s lacks %s\n", path, name);                                                             \
+        return false;                                                                                                  \
+    }
+    SYM(create, "pt_create") SYM(create_multi, "pt_create_multi") SYM(destroy, "pt_destroy")
+    SYM(set_partition, "pt_multi_set_partition") SYM(set_size, "pt_set_size") SYM(reset, "pt_reset") SYM(set_params, "pt_set_params")
+    SYM(upload_basic, "pt_upload_basic_data") SYM(upload_objects, "pt_upload_game_objects") SYM(set_env, "pt_set_environment")
+    SYM(render, "pt_render") SYM(set_batch, "pt_set_frame_batch") SYM(read, "pt_read_result") SYM(present, "pt_present_rgba8")
+    SYM(present_async, "pt_present_rgba8_async") SYM(present_wait, "pt_present_wait") SYM(sync, "pt_synchronize")
+    SYM(devptr, "pt_result_device_ptr") SYM(set_variant, "pt_set_variant") SYM(device_count, "pt_device_count")
+    SYM(last_error, "pt_last_error") SYM(audit_read, "pt_debug_audit_read")
+#undef SYM
+    return true;
+}
+
+struct Rng {
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) { next(); next(); }
+    uint64_t next()
+    {
+        s ^= s >> 12; s ^= s << 25; s ^= s >> 27;
+        return s * 0x2545F4914F6CDD1Dull;
+    }
+    int below(int n) { return (int)(next() % (uint64_t)n); }
+    float uni() { return (float)((next() >> 40) * (1.0 / 16777216.0)); }
+    float range(float lo, float hi) { return lo + (hi - lo) * uni(); }
+    template <typename T, size_t N> T pick(const T (&v)[N]) { return v[below((int)N)]; }
+};
+
+enum OpKind { RENDER, READ, PRESENT, PRESENT_ASYNC, PRESENT_WAIT, CAMERA, SCENE, RESET, SYNC, BATCH, DEVPTR, JITTER, PARAMS };
+struct Op {
+    OpKind kind;
+    int i0 = 0, i1 = 0;
+    float f[4] = {0, 0, 0, 0};
+};
+
+struct Case {
+    int W, H, spp, depth, frames, parts, band, ns, nc, batch;
+    float focal, aperture;
+    std::vector<float> objects; // 26,624 bytes
+    float basic[36];
+    std::vector<float> env;     // 6 * 4 * 4 * 4 floats
+    std::vector<Op> ops;
+    std::string describe() const
+    {
+        char b[256];
+        std::snprintf(b, sizeof b, "%dx%d spp=%d depth=%d frames=%d parts=%d band=%d ns=%d nc=%d batch=%d ops=%zu", W, H, spp, depth, frames,
+                      parts, band, ns, nc, batch, ops.size());
+        return b;
+    }
+};
+
+static void put_material(float *m, Rng &r)
+{
+    const int kind = r.below(4);
+    float albedo[3] = {r.uni(), r.uni(), r.uni()}, emis[3] = {0, 0, 0}, absorb[3] = {0, 0, 0};
+    float specC = 0, specR = 0, refrC = 0, refrR = 0, ior = 1;
+    if (kind == 0 && r.below(3) == 0) for (float &e : emis) e = 3.0f * r.uni();
+    if (kind == 1) { specC = r.uni(); specR = r.below(3) ? r.uni() : 0.0f; }
+    if (kind >= 2) {
+        specC = 0.02f + 0.1f * r.uni(); ior = 1.0f + r.uni(); refrC = 0.9f * r.uni(); refrR = r.below(2) ? r.uni() : 0.0f;
+        for (float &v : absorb) v = 2.0f * r.uni();
+    }
+    m[0] = albedo[0]; m[1] = albedo[1]; m[2] = albedo[2]; m[3] = specC;
+    m[4] = emis[0]; m[5] = emis[1]; m[6] = emis[2]; m[7] = specR;
+    m[8] = absorb[0]; m[9] = absorb[1]; m[10] = absorb[2]; m[11] = refrC;
+    m[12] = refrR; m[13] = ior; m[14] = 0; m[15] = 0;
+}
+
+static void camera_blob(float *basic, int W, int H, const float pos[3])
+{
+    std::memset(basic, 0, 36 * sizeof(float));
+    const float ty = std::tan(0.5f * 1.7976f), tx = ty * (float)W / (float)H; // 103 degrees vertical, MainWindow.cs:278
+    basic[0] = tx; basic[5] = ty; basic[10] = 1.0f; basic[15] = 1.0f;         // InvProjection (only x / y scale matter: compute.glsl:354-355)
+    basic[16] = 1.0f; basic[21] = 1.0f; basic[26] = 1.0f; basic[31] = 1.0f;   // InvView = translation, looking down -z
+    basic[28] = pos[0]; basic[29] = pos[1]; basic[30] = pos[2];
+    basic[32] = pos[0]; basic[33] = pos[1]; basic[34] = pos[2];               // ViewPos
+}
+
+static Case make_case(Rng &r, int maxParts, bool withOps, bool multisample)
+{
+    Case c;
+    static const int Ws[] = {8, 8, 16, 24, 33}, Hs[] = {8, 8, 17, 24, 40}, spps[] = {1, 1, 2, 3, 4}, depths[] = {1, 2, 4, 8, 20};
+    static const int framesV[] = {5, 33, 64, 70, 130, 200}, partsV[] = {0, 0, 1, 2, 3, 3, 5}, bands[] = {-1, -1, 0, 8, 16};
+    static const int nsV[] = {0, 3, 17, 48, 64, 100, 200}, ncV[] = {0, 1, 7}, batches[] = {64, 64, 64, 32, 7, 2};
+    c.W = r.pick(Ws); c.H = r.pick(Hs); c.spp = r.pick(spps); c.depth = r.pick(depths); c.frames = r.pick(framesV);
+    c.parts = r.pick(partsV); c.band = r.pick(bands); c.ns = r.pick(nsV); c.nc = r.pick(ncV); c.batch = r.pick(batches);
+    if (multisample) { // the spp > 1 kernels, on images up to the size of the round-2 stall reproducer (200 x 72, 4 spp, 32 frames)
+        static const int Wm[] = {8, 16, 33, 64, 200}, Hm[] = {8, 17, 40, 72}, sm[] = {2, 3, 4, 7};
+        c.W = r.pick(Wm); c.H = r.pick(Hm); c.spp = r.pick(sm);
+    }
+    if (c.parts > maxParts) c.parts = maxParts;
+    if (c.parts > c.H) c.parts = 0;
+    c.focal = r.below(2) ? 20.0f : 5.0f;
+    c.aperture = r.below(2) ? 0.14f : 0.0f;
+    c.objects.assign(26624 / 4, 0.0f);
+    for (int i = 0; i < c.ns; i++) {
+        float *s = c.objects.data() + i * 20;
+        s[0] = r.range(-12, 12); s[1] = r.range(-8, 8); s[2] = r.range(-22, -4); s[3] = r.range(0.3f, 2.5f);
+        put_material(s + 4, r);
+    }
+    for (int i = 0; i < c.nc; i++) {
+        float *q = c.objects.data() + 5120 + i * 24;
+        float cx = r.range(-14, 14), cy = r.range(-10, 10), cz = r.range(-24, -6), dx = r.range(0.5f, 12), dy = r.range(0.5f, 12), dz = r.range(0.5f, 6);
+        if (i == 0) { cx = 0; cy = -10; cz = -14; dx = 40; dy = 0.5f; dz = 30; } // a floor
+        q[0] = cx - dx / 2; q[1] = cy - dy / 2; q[2] = cz - dz / 2; q[3] = 0;
+        q[4] = cx + dx / 2; q[5] = cy + dy / 2; q[6] = cz + dz / 2; q[7] = 0;
+        put_material(q + 8, r);
+    }
+    const float pos[3] = {r.range(-3, 3), r.range(-2, 4), r.range(-2, 3)};
+    camera_blob(c.basic, c.W, c.H, pos);
+    c.env.resize(6 * 16 * 4);
+    for (float &v : c.env) v = r.range(0.0f, 1.5f);
+    // ---- the call sequence
+    static const float opRates[] = {0.0f, 0.0f, 0.02f, 0.08f, 0.25f};
+    const float rate = withOps ? r.pick(opRates) : 0.0f;
+    const bool jitter = r.below(3) == 0;
+    int slotBusy[3] = {0, 0, 0};
+    for (int f = 0; f < c.frames; f++) {
+        Op op;
+        op.kind = RENDER;
+        c.ops.push_back(op);
+        if (jitter && r.below(4) == 0) {
+            static const int us[] = {2, 5, 20, 60, 150, 400};
+            op.kind = JITTER; op.i0 = r.pick(us);
+            c.ops.push_back(op);
+        }
+        for (int s = 0; s < 3; s++) // a slot presented earlier is waited for 1-3 renders later
+            if (slotBusy[s] > 0 && --slotBusy[s] == 0) { op.kind = PRESENT_WAIT; op.i0 = s; c.ops.push_back(op); }
+        if (r.uni() >= rate) continue;
+        switch (r.below(11)) {
+        case 0: op.kind = READ; break;
+        case 1: op.kind = PRESENT; break;
+        case 2: {
+            int s = r.below(3);
+            if (slotBusy[s] > 0) { op.kind = SYNC; break; }
+            op.kind = PRESENT_ASYNC; op.i0 = s; slotBusy[s] = 1 + r.below(3);
+            break;
+        }
+        case 3: op.kind = CAMERA; op.f[0] = r.range(-3, 3); op.f[1] = r.range(-2, 4); op.f[2] = r.range(-2, 3); break;
+        case 4: op.kind = SCENE; op.i0 = c.ns > 0 ? r.below(c.ns) : -1; op.f[0] = r.range(0.3f, 2.5f); break;
+        case 5: op.kind = RESET; break;
+        case 6: op.kind = SYNC; break;
+        case 7: op.kind = BATCH; op.i0 = 1 + r.below(64); break;
+        case 8: op.kind = DEVPTR; break;
+        case 9: op.kind = PARAMS; op.i0 = r.pick(spps); op.i1 = r.pick(depths); break;
+        default: op.kind = READ; break;
+        }
+        c.ops.push_back(op);
+    }
+    for (int s = 0; s < 3; s++)
+        if (slotBusy[s] > 0) { Op op; op.kind = PRESENT_WAIT; op.i0 = s; c.ops.push_back(op); }
+    Op fin; fin.kind = READ;
+    c.ops.push_back(fin);
+    return c;
+}
+
+struct Snapshot {
+    int opIndex;
+    std::vector<uint8_t> bytes;
+};
+
+static int g_failures = 0;
+#define CK(api, h, call)                                                                                               \
+    do {                                                                                                               \
+        int rc_ = (call);                                                                                              \
+        if (rc_ != 0) {                                                                                                \
+            std::printf("    %s -> %d (%s)\n", #call, rc_, (api).last_error(h));                                       \
+            return false;                                                                                              \
+        }                                                                                                              \
+    } while (0)
+
+// run the case's call sequence on one handle; `simple` = the comparison side (blocking equivalents only)
+static bool run_sequence(const Api &a, H h, const Case &c, bool simple, std::vector<Snapshot> &snaps)
+{
+    std::vector<float> objects = c.objects;
+    float basic[36];
+    std::memcpy(basic, c.basic, sizeof basic);
+    const void *faces[6];
+    for (int f = 0; f < 6; f++) faces[f] = c.env.data() + f * 64;
+    CK(a, h, a.set_env(h, 4, 0, faces));
+    CK(a, h, a.upload_objects(h, 0, 26624, objects.data()));
+    CK(a, h, a.upload_basic(h, 0, 144, basic));
+    int spp = c.spp, depth = c.depth;
+    CK(a, h, a.set_params(h, c.ns, c.nc, depth, spp, c.focal, c.aperture));
+    const size_t px = (size_t)c.W * c.H;
+    std::vector<uint8_t> slotImage[3];
+    for (size_t i = 0; i < c.ops.size(); i++) {
+        const Op &op = c.ops[i];
+        switch (op.kind) {
+        case RENDER: CK(a, h, a.render(h, nullptr)); break;
+        case READ: {
+            Snapshot s; s.opIndex = (int)i; s.bytes.resize(px * 16);
+            CK(a, h, a.read(h, (float *)s.bytes.data(), 0));
+            snaps.push_back(std::move(s));
+            break;
+        }
+        case PRESENT: {
+            Snapshot s; s.opIndex = (int)i; s.bytes.resize(px * 4);
+            CK(a, h, a.present(h, s.bytes.data(), 0));
+            snaps.push_back(std::move(s));
+            break;
+        }
+        case PRESENT_ASYNC:
+            if (simple) { // what the slot must show later: the image as it is now
+                slotImage[op.i0].resize(px * 4);
+                CK(a, h, a.present(h, slotImage[op.i0].data(), 0));
+            } else {
+                CK(a, h, a.present_async(h, op.i0));
+            }
+            break;
+        case PRESENT_WAIT: {
+            Snapshot s; s.opIndex = (int)i;
+            if (simple) {
+                s.bytes = slotImage[op.i0];
+            } else {
+                const uint8_t *img = nullptr; size_t pitch = 0; int fi = 0;
+                CK(a, h, a.present_wait(h, op.i0, &img, &pitch, &fi));
+                s.bytes.assign(img, img + px * 4);
+            }
+            snaps.push_back(std::move(s));
+            break;
+        }
+        case CAMERA: camera_blob(basic, c.W, c.H, op.f); CK(a, h, a.upload_basic(h, 0, 144, basic)); break;
+        case SCENE:
+            if (op.i0 >= 0) {
+                objects[op.i0 * 20 + 3] = op.f[0];
+                CK(a, h, a.upload_objects(h, op.i0 * 80, 16, objects.data() + op.i0 * 20));
+            }
+            break;
+        case RESET: CK(a, h, a.reset(h)); break;
+        case SYNC: if (!simple) CK(a, h, a.sync(h)); break;
+        case BATCH: if (!simple) CK(a, h, a.set_batch(h, op.i0)); break;
+        case DEVPTR: if (!simple) { void *p = nullptr; size_t n = 0; CK(a, h, a.devptr(h, &p, &n)); } break;
+        case JITTER:
+            if (!simple) {
+                const auto t0 = std::chrono::steady_clock::now();
+                while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(op.i0)) {}
+            }
+            break;
+        case PARAMS: spp = op.i0; depth = op.i1; CK(a, h, a.set_params(h, c.ns, c.nc, depth, spp, c.focal, c.aperture)); break;
+        }
+    }
+    return true;
+}
+
+static const char *kOpNames[] = {"render", "read", "present", "present_async", "present_wait", "camera", "scene", "reset", "sync", "batch", "devptr", "jitter", "params"};
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) {
+        std::fprintf(stderr, "usage: %s <lib.so> <cases> <seed> [--only N] [--repeat N] [--verbose] [--devices a,b,..] [--max-parts N] [--no-ops] [--fresh] [--multisample] [--ref-lib lib.so]\n", argv[0]);
+        return 2;
+    }
+    const char *libPath = argv[1], *refPath = argv[1];
+    const long cases = std::atol(argv[2]);
+    const uint64_t seed = std::strtoull(argv[3], nullptr, 10);
+    long only = -1;
+    int repeat = 1, maxParts = 5;
+    bool verbose = false, withOps = true, freshHandles = false, multisample = false;
+    std::vector<int> devices = {0};
+    for (int i = 4; i < argc; i++) {
+        std::string s = argv[i];
+        if (s == "--only" && i + 1 < argc) only = std::atol(argv[++i]);
+        else if (s == "--repeat" && i + 1 < argc) repeat = std::atoi(argv[++i]);
+        else if (s == "--verbose") verbose = true;
+        else if (s == "--no-ops") withOps = false;
+        else if (s == "--fresh") freshHandles = true;
+        else if (s == "--multisample") multisample = true;
+        else if (s == "--max-parts" && i + 1 < argc) maxParts = std::atoi(argv[++i]);
+        else if (s == "--ref-lib" && i + 1 < argc) refPath = argv[++i];
+        else if (s == "--devices" && i + 1 < argc) {
+            devices.clear();
+            for (char *tok = std::strtok(argv[++i], ","); tok; tok = std::strtok(nullptr, ",")) devices.push_back(std::atoi(tok));
+        }
+    }
+    Api a, ref;
+    if (!load_api(libPath, a)) return 2;
+    if (std::string(refPath) == libPath) ref = a;
+    else if (!load_api(refPath, ref)) return 2;
+    if (a.device_count() < 1) {
+        std::fprintf(stderr, "no HIP device\n");
+        return 2;
+    }
+    std::vector<unsigned int> records(64 * 12);
+    const bool haveAudit = a.audit_read != nullptr;
+    long auditViolations = 0, ran = 0, snapsCompared = 0, framesRendered = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    Rng master(seed);
+    // Handles are reused over many cases (pt_set_size / pt_multi_set_partition re-initialise them: creating a handle costs
+    // milliseconds, a case ~2 ms); every 16th use of a slot starts from a fresh handle (first launches, fresh allocations).
+    H cache[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int cacheUses[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    H refHandle = nullptr;
+    for (long ci = 0; ci < cases; ci++) {
+        Rng r(master.next());
+        Case c = make_case(r, maxParts, withOps, multisample);
+        if (only >= 0 && ci != only) continue;
+        for (int rep = 0; rep < repeat; rep++) {
+            if (verbose) std::printf("case %ld: %s\n", ci, c.describe().c_str());
+            bool ok = true;
+            // ---- the side under test: default kernels, pipelining, (maybe) a group handle
+            H &t = cache[c.parts];
+            int rc = 0;
+            if (t && (freshHandles || ++cacheUses[c.parts] >= 16)) {
+                a.destroy(t);
+                t = nullptr;
+                cacheUses[c.parts] = 0;
+            }
+            if (t) {
+                rc = a.set_size(t, c.W, c.H);
+                if (rc == 0 && c.parts > 0) rc = a.set_partition(t, c.band >= 0 ? c.band : 16);
+                if (rc == 0) rc = a.set_variant(t, 0);
+            } else if (c.parts > 0) {
+                std::vector<int> ids;
+                for (int k = 0; k < c.parts; k++) ids.push_back(devices[k % devices.size()]);
+                rc = a.create_multi(ids.data(), c.parts, c.W, c.H, &t);
+                if (rc == 0 && c.band >= 0) rc = a.set_partition(t, c.band);
+            } else {
+                rc = a.create(devices[0], c.W, c.H, &t);
+            }
+            if (rc != 0) {
+                std::printf("case %ld: create failed: %d %s : %s\n", ci, rc, a.last_error(nullptr), c.describe().c_str());
+                g_failures++;
+                continue;
+            }
+            std::vector<Snapshot> got, want;
+            if (a.set_batch(t, c.batch) != 0) ok = false;
+            if (ok && !run_sequence(a, t, c, false, got)) ok = false;
+            int nviol = 0;
+            if (haveAudit && ok) {
+                nviol = a.audit_read(t, records.data(), 64);
+                if (nviol == -1000) nviol = 0;
+            }
+            if (!ok) { // a handle that reported an error is not reused
+                a.destroy(t);
+                t = nullptr;
+            }
+            // ---- the comparison side: variant 1, one plain launch per frame, one device
+            H &s = refHandle;
+            if (!s && ref.create(devices[0], c.W, c.H, &s) != 0) { std::printf("case %ld: reference create failed\n", ci); g_failures++; continue; }
+            bool rok = ref.set_size(s, c.W, c.H) == 0 && ref.set_variant(s, 1) == 0 && ref.set_batch(s, 1) == 0 && run_sequence(ref, s, c, true, want);
+            ran++;
+            for (const Op &op : c.ops) framesRendered += op.kind == RENDER;
+            if (!ok || !rok) {
+                std::printf("case %ld (rep %d): library error on the %s side : %s\n", ci, rep, ok ? "comparison" : "tested", c.describe().c_str());
+                g_failures++;
+                continue;
+            }
+            bool same = got.size() == want.size();
+            for (size_t k = 0; same && k < got.size(); k++) {
+                snapsCompared++;
+                if (got[k].bytes.size() != want[k].bytes.size() || std::memcmp(got[k].bytes.data(), want[k].bytes.data(), got[k].bytes.size()) != 0) {
+                    same = false;
+                    const size_t unit = got[k].bytes.size() == (size_t)c.W * c.H * 16 ? 16 : 4;
+                    size_t nbad = 0, first = (size_t)-1;
+                    for (size_t p = 0; p < (size_t)c.W * c.H; p++)
+                        if (std::memcmp(got[k].bytes.data() + p * unit, want[k].bytes.data() + p * unit, unit) != 0) {
+                            nbad++;
+                            if (first == (size_t)-1) first = p;
+                        }
+                    int rendersBefore = 0;
+                    for (int q = 0; q < got[k].opIndex; q++) rendersBefore += c.ops[q].kind == RENDER;
+                    std::printf("case %ld (rep %d): MISMATCH at op %d (%s, after %d renders): %zu of %d pixels differ, first x=%zu y=%zu : %s\n", ci, rep,
+                                got[k].opIndex, kOpNames[c.ops[got[k].opIndex].kind], rendersBefore, nbad, c.W * c.H, first % c.W, first / c.W,
+                                c.describe().c_str());
+                    if (unit == 16) {
+                        const float *g = (const float *)(got[k].bytes.data() + first * 16), *w = (const float *)(want[k].bytes.data() + first * 16);
+                        std::printf("    got %.9g %.9g %.9g %.9g want %.9g %.9g %.9g %.9g\n", g[0], g[1], g[2], g[3], w[0], w[1], w[2], w[3]);
+                    }
+                    std::printf("    ops:");
+                    for (size_t q = 0; q < c.ops.size(); q++)
+                        if (c.ops[q].kind != RENDER) {
+                            int rb = 0;
+                            for (size_t z = 0; z < q; z++) rb += c.ops[z].kind == RENDER;
+                            std::printf(" %s@%d", kOpNames[c.ops[q].kind], rb);
+                        }
+                    std::printf("\n");
+                }
+            }
+            if (!same) g_failures++;
+            if (nviol > 0) {
+                auditViolations += nviol;
+                std::printf("case %ld (rep %d): %d AUDIT violation(s)%s : %s\n", ci, rep, nviol, same ? " (image correct)" : "", c.describe().c_str());
+                for (int k = 0; k < nviol && k < 8; k++) {
+                    const unsigned int *q = records.data() + k * 12;
+                    float tagSeen, chainTag;
+                    std::memcpy(&tagSeen, q + 6, 4);
+                    std::memcpy(&chainTag, q + 9, 4);
+                    std::printf("    site %u%s%s pix %u frame %u: side word says %u frames folded, hash %08x vs loaded %08x, tag seen %g; launch seq %u frames [%u,+%u) chainTag %g wg %u tagged %u keepTags %u variant %u\n",
+                                q[0] & 0xff, (q[0] & 0x100) ? " ORDER" : "", (q[0] & 0x200) ? " COLOUR" : "", q[1], q[2], q[3], q[4], q[5], tagSeen, q[7],
+                                q[8] & 0xffffff, q[8] >> 24, chainTag, q[10], q[11] & 1, (q[11] >> 1) & 1, q[11] >> 8);
+                }
+            }
+        }
+        if ((ci + 1) % 2000 == 0) {
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("... %ld cases, %d failures, %ld audit violations, %.0f s\n", ci + 1, g_failures, auditViolations, el);
+            std::fflush(stdout);
+        }
+    }
+    for (H &hh : cache)
+        if (hh) a.destroy(hh);
+    if (refHandle) ref.destroy(refHandle);
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("handover_stress: lib %s seed %llu: %ld cases run, %ld frames, %ld images compared, %d failures, %ld audit violations, %.1f s\n", libPath,
+                (unsigned long long)seed, ran, framesRendered, snapsCompared, g_failures, auditViolations, el);
+    return (g_failures || auditViolations) ? 1 : 0;
+}
