@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the hot path: Msamples/s of the path-tracing integrator on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a torchrun environment: bench.py starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
+
+Either way N > 1 means one process per GPU over RCCL, and the run FAILS if the box has fewer than N devices (it never
+degrades to fewer GPUs silently; --share-gpu is the explicit one-GPU debug mode).  `n_gpus` is the number of distinct devices that
+rendered (gathered from the ranks), `ranks` the RCCL world size.
 
 A "step" is one PathTracer.Render() — one pass of the integrator over the whole image with the inputs (scene
 UBO, camera UBO, environment cube, accumulation image) already resident in HBM; frames accumulate progressively
@@ -151,6 +155,39 @@ def cpu_baseline(pkg, scene, basic, env, width, height, depth, spp, workload_nam
     return out, st["bounces"] / max(1, st["samples"])
 
 
+def self_spawn(args) -> int:
+    """`python bench.py --gpus N` with no torchrun environment: start the N ranks here (one process per GPU, the same
+    environment torchrun would set), pass rank 0's JSON line through, fail if any rank fails or the box has fewer devices."""
+    import socket
+    import subprocess
+
+    pkg = graft.load_package()
+    if not os.path.exists(pkg.native.LIB_PATH):
+        graft.build()
+    have = pkg.native.load().pt_device_count()
+    if have < args.gpus and not args.share_gpu:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this box has {have} HIP device(s); refusing to report a {args.gpus}-GPU number "
+                         f"from fewer GPUs (use --share-gpu for the one-GPU debug mode)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:  # a rank died: the others may sit in a collective
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,10 +208,18 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N > 1: grow the 16:9 image to ~N x 2.07 Mpixel (weak scaling)")
     ap.add_argument("--no-4k", action="store_true", help="N > 1: skip the extra configs[3] measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steady-ms", type=float, default=500.0,
+                    help="after the timed K steps, render the same workload for at least this long in the same process and report it "
+                         "as `steady` (never the metric's value): what a short driver run looks like without its ramp and drain; 0 = off")
+    ap.add_argument("--no-group-check", action="store_true",
+                    help="N > 1: skip rendering the same frames through ONE in-process group handle (pt_create_multi over the N devices, "
+                         "peer copies over xGMI) and comparing it bit for bit with the RCCL-gathered image")
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: all ranks use cuda:0 and rendezvous over gloo (validates the N>1 logic on a 1-GPU box; "
                          "RCCL cannot put two ranks on one device)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_spawn(args))
     preset = CONFIGS[args.config or "C2"]
     scene_name = args.scene or preset[0]
     depth = args.depth if args.depth is not None else preset[1]
@@ -194,8 +239,11 @@ def main():
     from opentk_pathtracer_amd import distributed as D
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_env != args.gpus and world_env > 1:
+    if world_env != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
+    have = pkg.native.load().pt_device_count()
+    if have < args.gpus and not args.share_gpu:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this box has {have} HIP device(s); refusing to report a {args.gpus}-GPU number from fewer GPUs")
     rank, world, local = (D.init_from_env(backend="gloo" if args.share_gpu else None) if args.gpus > 1
                           else (0, 1, int(os.environ.get("LOCAL_RANK", "0"))))
     if args.share_gpu:
@@ -213,7 +261,7 @@ def main():
     csrc_hash = pkg.native.csrc_hash()
     frames_per_launch = args.frame_batch if args.variant == 0 else 1
 
-    def measure(W, H, steps, warmup, clock_warmup_ms):
+    def measure(W, H, steps, warmup, clock_warmup_ms, steady_ms=0.0, group_check=False):
         """One workload: create the renderer for this rank's rows of the W x H image, warm up, time `steps` Render() calls
         (barrier + synchronize on both sides, max over ranks), gather once.  -> dict (rank 0) with the raw measurements."""
         basic = pkg.camera.basic_data_ubo(cam, W, H)
@@ -282,10 +330,84 @@ def main():
         if world > 1:
             dist.all_reduce(times, op=dist.ReduceOp.MAX)
         elapsed_max, kernel_s_max = (float(v) for v in times.cpu())
+        # which devices rendered: every rank reports the PCI bus id of the device it used (distinct ids = distinct GPUs)
+        props = torch.cuda.get_device_properties(local)
+        me = (local, str(getattr(props, "uuid", "")), str(getattr(props, "pci_bus_id", "")))
+        ids = [None] * world
+        if world > 1:
+            dist.all_gather_object(ids, me)
+        else:
+            ids = [me]
+        devices_used = len(set(ids))
+
+        # ---- steady state of the same workload in the same process (never the metric's value): >= steady_ms of rendering
+        steady = None
+        if steady_ms > 0:
+            sync_all()
+            done, t_s = 0, time.perf_counter()
+            pt.TimerBegin()
+            while True:
+                for _ in range(256):
+                    pt.Render()
+                done += 256
+                if (time.perf_counter() - t_s) * 1e3 >= steady_ms and done >= 512:
+                    break
+            k_ms = pt.TimerEnd()
+            sync_local()
+            el = time.perf_counter() - t_s
+            st = torch.tensor([el, k_ms / 1e3], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
+            if world > 1:
+                dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            el, k_s = (float(v) for v in st.cpu())
+            steady = {"steps": done, "ms_per_step": round(el * 1e3 / done, 5), "kernel_ms": round(k_s * 1e3 / done, 5),
+                      "value": round(W * H * args.spp * done / el / 1e6, 2), "unit": "Msamples/s",
+                      "note": "same workload, same process, right after the timed region; the timed K-step region carries ~0.16 ms of "
+                              "clock ramp and drain that a long run amortises"}
+
+        # ---- N > 1: the same frames through ONE in-process group handle over the N devices (pt_create_multi: what the reference's
+        # single-process host would call; gather by hipMemcpyPeerAsync over xGMI), compared bit for bit with the RCCL gather
+        group = None
+        if group_check and world > 1 and rank == 0 and not args.share_gpu and have >= world:
+            frames = warmup + steps
+            gp = pkg.PathTracer(None, W, H, depth, args.spp, 20.0, 0.14, devices=list(range(world)))
+            gp.SetVariant(args.variant)
+            gp.SetFrameBatch(args.frame_batch)
+            if env_name == "atmosphere256":
+                gp.EnvironmentMap = pkg.AtmosphericScatterer(256, pkg.camera.atmospheric_data_ubo(), pkg.camera.atmosphere_light_pos(0.5), gp)
+            elif env_name == "sky2048":
+                gp.EnvironmentMap = pkg.envmap.synthetic_sky_srgb8(2048)
+            else:
+                gp.EnvironmentMap = pkg.envmap.synthetic_sky_rgba32f(64)
+            gp.UploadScene(scene)
+            gp.UploadBasicData(basic)
+            for _ in range(warmup):
+                gp.Render()
+            gp.Synchronize()
+            tg = time.perf_counter()
+            gp.TimerBegin()
+            for _ in range(steps):
+                gp.Render()
+            gk = gp.TimerEnd()
+            gp.Synchronize()
+            g_el = time.perf_counter() - tg
+            tr = time.perf_counter()
+            gimg = gp.Result  # peer copies to device 0 + one device-to-host copy
+            g_read = (time.perf_counter() - tr) * 1e3
+            same = bool(np.array_equal(gimg.view(np.uint32), full.cpu().numpy().view(np.uint32))) if full is not None else None
+            group = {"devices": list(range(world)), "frames": frames, "value": round(W * H * args.spp * steps / g_el / 1e6, 2), "unit": "Msamples/s",
+                     "ms_per_step": round(g_el * 1e3 / steps, 5), "kernel_ms_slowest_device": round(gk / steps, 5),
+                     "read_result_ms": round(g_read, 3), "equals_rccl_gather_bit_for_bit": same,
+                     "note": "ONE process, one pt_create_multi handle over all devices, run after the ranks' measurement while they idle"}
+            gp.Dispose()
+            if same is False:
+                raise SystemExit("bench.py: the in-process group handle's image differs from the RCCL-gathered image")
+        if world > 1:
+            dist.barrier()
         res = None
         if rank == 0:
             assert full is not None and tuple(full.shape) == (H, W, 4)
             res = {"W": W, "H": H, "rows": rows, "steps": steps, "elapsed": elapsed_max, "kernel_s": kernel_s_max, "present_ms": present_ms,
+                   "devices_used": devices_used, "steady": steady, "group": group,
                    "checks": {"finite": bool(torch.isfinite(full).all().item()), "alpha_one": bool((full[..., 3] == 1).all().item()),
                               "mean_radiance": round(float(full[..., :3].mean().item()), 5)},
                    "basic": basic, "env_cpu": (pt.ReadEnvironment() if env_name != "sky2048" else None)}
@@ -299,7 +421,7 @@ def main():
         (W, H), scaling = weak_image_size(world), "weak"
     else:
         W, H, scaling = 1920, 1080, "strong"  # the metric's image, split N ways (N = 1: the whole image on one GPU)
-    m = measure(W, H, args.steps, args.warmup, args.clock_warmup_ms)
+    m = measure(W, H, args.steps, args.warmup, args.clock_warmup_ms, steady_ms=args.steady_ms, group_check=not args.no_group_check)
     m4k = None
     if world > 1 and not (args.strong_4k or args.weak or args.no_4k):
         # BASELINE configs[3]: ONE 3840x2160 image over the N GPUs, same run, shorter (the clocks are warm)
@@ -323,7 +445,7 @@ def main():
         traffic, traffic_note = load_profile_number("traffic.json", wl_key, csrc_hash)
         out = {
             "metric": "Msamples/sec + ms/frame @1080p 8-bounce default scene, 1/2/4/8 GPU",
-            "value": round(samples / m["elapsed"] / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "value": round(samples / m["elapsed"] / 1e6, 2), "unit": "Msamples/s", "n_gpus": m["devices_used"], "ranks": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{scene_name} scene ({scene.num_spheres} spheres + {scene.num_cuboids} cuboids), {W}x{H}, "
@@ -351,6 +473,7 @@ def main():
                                  "--frame-batch 1 launches every frame on its own (2 overlapping row-stripe launches). "
                                  "The path is fp32-VALU bound, see `valu_issue`"},
             "present_ms": round(m["present_ms"], 3),
+            "steady": m["steady"],
             "clock_warmup_ms": args.clock_warmup_ms,
             "checks": m["checks"],
         }
@@ -368,6 +491,10 @@ def main():
         elif vi_note:
             out["roofline"]["valu_issue"] = None
             out["roofline"]["valu_issue_note"] = vi_note
+        if m["group"] is not None:
+            out["in_process_group"] = m["group"]
+        if args.share_gpu:
+            out["n_gpus"] = 1  # debug mode: all ranks shared cuda:0
         if m4k is not None:
             k4 = m4k["kernel_s"] * 1e3 / m4k["steps"]
             a4 = ALGO_BYTES_PER_PIXEL_FRAME * 3840 * m4k["rows"] / (k4 * 1e-3) / 1e9

@@ -524,6 +524,10 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     a.launchSeq = 0;
     a.audit = nullptr; // (set next to every a.accum below)
     a.auditLog = h->devAuditLog;
+    a.auditSabotage = 0;
+#ifdef PT_AUDIT
+    if (const char *sab = std::getenv("PT_AUDIT_SABOTAGE")) a.auditSabotage = std::atoi(sab);
+#endif
     a.timeline = h->dTimeline;
     // sphere grid of large scenes: rebuilt here, before the first launch that sees the changed scene.  Launches still in flight
     // read the old grid: join first, then the copy is ordered behind them on the main stream like a scene upload.

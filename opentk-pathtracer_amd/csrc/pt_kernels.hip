@@ -75,8 +75,10 @@ PT_DEV void audit_resolve(const FrameArgs &a, size_t p, int F, float4 last, floa
     r[11] = (unsigned int)a.tagged | ((unsigned int)a.keepTags << 1) | ((unsigned int)a.variant << 8);
 }
 #define AUDIT_RESOLVE(a, p, F, last, next, site) audit_resolve(a, p, F, last, next, site)
+#define AUDIT_SABOTAGED(a, pix, fj) ((a).auditSabotage > 0 && ((unsigned int)(pix) * 2654435761u + (unsigned int)(fj) * 40503u) % (unsigned int)(a).auditSabotage == 0u)
 #else
 #define AUDIT_RESOLVE(a, p, F, last, next, site)
+#define AUDIT_SABOTAGED(a, pix, fj) false
 #endif
 
 #ifdef PT_CHAOS
@@ -533,6 +535,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         float4 last = load_pixel_sc1(ptr);
         const float expected = rfj > 0 ? frame_tag(a.frame + rfj - 1) : a.chainTag; // (0 = the launch's first frame has no predecessor in flight)
         if (expected != 0.0f && !force && last.w != expected) return false;
+        if (AUDIT_SABOTAGED(a, rpix, rfj)) last.x += 1.0f; // (audit build + PT_AUDIT_SABOTAGE only: a simulated stale / torn read)
         CHAOS(11);
         const float4 next = fold(last, rirr, rfj);
         AUDIT_RESOLVE(a, (size_t)rpix, a.frame + rfj, last, next, 4);
@@ -1031,6 +1034,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         float4 last = load_pixel_sc1(ptr);
         const float expected = rfj > 0 ? frame_tag(a.frame + rfj - 1) : a.chainTag;
         if (expected != 0.0f && !force && last.w != expected) return false;
+        if (AUDIT_SABOTAGED(a, rpix, rfj)) last.x += 1.0f; // (audit build + PT_AUDIT_SABOTAGE only: a simulated stale / torn read)
         CHAOS(21);
         const float4 next = fold(last, rirr, rfj);
         AUDIT_RESOLVE(a, pidx, a.frame + rfj, last, next, 6);

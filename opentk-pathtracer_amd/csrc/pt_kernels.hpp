@@ -68,6 +68,7 @@ struct FrameArgs {
     // "one ordered read-modify-write per pixel per frame".  Violations go to auditLog (host-mapped): [0] = count, 12 words each.
     unsigned long long *audit;
     unsigned int *auditLog;
+    int auditSabotage;      // audit build, PT_AUDIT_SABOTAGE=n: every n-th (pixel, frame) folds into a perturbed colour, as a stale or torn read would — proves that the audit sees it
 };
 constexpr int kAuditLogRecords = 1024, kAuditRecordWords = 12;
 constexpr int kStartedWords = 4096; // capacity of FrameArgs::startedFlags (a launch with more workgroups does not report in)

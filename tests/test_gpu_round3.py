@@ -1,0 +1,201 @@
+"""GPU tests added in round 3.
+
+  * the hand-over machinery under its own audit: tools/handover_stress (native, thousands of random call sequences through the
+    C ABI, every observed image compared bit for bit with the same sequence rendered by the simplest kernel) against the
+    product library and against the -DPT_AUDIT -DPT_CHAOS build, whose kernels mirror every pixel read-modify-write with a
+    device-scope atomic side word and inject random delays at the protocol's decision points (csrc/pt_kernels.hip);
+  * the spp > 1 batch-pass kernel forced onto tiny pipelined images (PT_BATCH_PASS_MIN_TILES=0), where round 2 saw its
+    hand-over stall, and a pipelined spp > 1 launch at >= 16,384 tiles per frame (advisor finding, round 2);
+  * REAL peers: everything the group-handle / RCCL tests do with device 0 named several times, on distinct devices — skipped
+    on a one-GPU box, parametrised on pt_device_count() otherwise (the reference is single-GPU,
+    src/Render/PathTracer.cs:95-123);
+  * bench.py --gpus N without a torchrun environment starts its own ranks (one-GPU debug mode here).
+Run with `pytest -m gpu` on an MI355X.  Nothing here reads /root/reference.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import configs
+from test_gpu_abi_round2 import make_tracer
+from test_gpu_parity import assert_bit_exact, hip_render, oracle_render
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stress(pkg, lib, cases, seed, *extra, env=None, timeout=600):
+    tool = pkg.native.build_stress_tool()
+    e = dict(os.environ, **(env or {}))
+    p = subprocess.run([tool, lib, str(cases), str(seed), *extra], capture_output=True, text=True, timeout=timeout, env=e)
+    tail = "\n".join(p.stdout.strip().splitlines()[-25:])
+    assert p.returncode == 0, f"handover_stress failed (rc {p.returncode}):\n{tail}\n{p.stderr[-2000:]}"
+    assert "0 failures, 0 audit violations" in p.stdout, tail
+    return p.stdout.strip().splitlines()[-1]
+
+
+def test_handover_stress_product_library(pkg, native_lib):
+    """1,500 random call sequences (tiny images, up to 200 pipelined frames, groups of 1-5 parts, reads / presents / uploads /
+    resets at random frames) on the product library: every image equals the unpipelined tile-per-wave render."""
+    print(_stress(pkg, pkg.native.LIB_PATH, 1500, 301))
+
+
+def test_handover_stress_audit_chaos_build(pkg, native_lib):
+    """The same under the audit + chaos build: additionally NO resolve may run out of order or fold into a colour other than the
+    one the previous resolve of that pixel stored (device-scope atomic side word per pixel), with random delays injected at
+    the tag load / store, ring pop, park / service, ticket draw and workgroup start."""
+    lib = pkg.native.variant_path("audit_chaos")
+    if not os.path.exists(lib):
+        pkg.native.build_variant("audit_chaos")
+    print(_stress(pkg, lib, 1500, 302))
+
+
+def test_audit_build_detects_a_broken_handover(pkg, native_lib):
+    """The audit is not vacuous: PT_AUDIT_SABOTAGE makes the audit build fold every 97th tagged (pixel, frame) into a perturbed
+    colour, as a stale or torn 16-byte read would — the stress tool must then report audit violations and wrong images."""
+    lib = pkg.native.variant_path("audit")
+    if not os.path.exists(lib):
+        pkg.native.build_variant("audit")
+    tool = pkg.native.build_stress_tool()
+    p = subprocess.run([tool, lib, "200", "303", "--no-ops"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, PT_AUDIT_SABOTAGE="97"))
+    assert p.returncode == 1 and "AUDIT violation" in p.stdout, p.stdout[-2000:]
+
+
+def test_multisample_batch_pass_forced_onto_tiny_images(pkg, native_lib):
+    """Round 2's stall: pipelined spp > 1 launches over a few tiles through the batch-pass kernel (lanes and queue fill up with
+    results that wait for work parked in the same wavefront).  The forced batch pass must keep that work moving: no error
+    code, no slow case, every image right — product library and audit + chaos build."""
+    env = {"PT_BATCH_PASS_MIN_TILES": "0"}
+    print(_stress(pkg, pkg.native.LIB_PATH, 1200, 304, "--multisample", env=env))
+    print(_stress(pkg, pkg.native.variant_path("audit_chaos"), 600, 305, "--multisample", env=env))
+
+
+def test_round2_stall_reproducer_through_the_batch_pass_kernel(pkg, native_lib, oracle):
+    """The exact round-2 reproducer (200 spheres, 200x72, 2 bounces, 4 spp, 33 frames, 32 per launch: 2-4 % of such launches
+    ended in the stall bound's PT_E_HIP), 40 times in a subprocess that sends it through the batch-pass kernel."""
+    code = r"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import __graft_entry__ as g
+pkg = g.load_package(); oracle = g.load_oracle().Oracle(); S = pkg.scene
+rng = np.random.RandomState(5); sc = S.Scene()
+for i in range(200):
+    sc.spheres.append(S.Sphere(rng.uniform([-18, -11, -20], [18, 11, 0]).astype(np.float32), np.float32(0.6 * rng.uniform(0.2, 1.5)), i, S.Material(albedo=rng.rand(3))))
+sc.cuboids.append(S.Cuboid(S.vec3(0.0, -11.0, -10.0), S.vec3(30.0, 1.0, 30.0), 0, S.Material(albedo=S.vec3(0.7))))
+W, H, depth, spp, frames = 200, 72, 2, 4, 33
+basic = pkg.camera.basic_data_ubo(pkg.camera.Camera(), W, H); env = pkg.envmap.synthetic_sky_rgba32f(16)
+want = oracle.render(W, H, basic, sc.ubo_bytes(), env, num_spheres=200, num_cuboids=1, ray_depth=depth, spp=spp, focal_length=200.0, aperture=0.0, num_frames=frames)
+worst = 0.0
+for rep in range(40):
+    pt = pkg.PathTracer(env, W, H, depth, spp, 200.0, 0.0); pt.SetFrameBatch(32); pt.UploadScene(sc); pt.UploadBasicData(basic)
+    t = time.perf_counter()
+    for _ in range(frames): pt.Render()
+    got = pt.Result; worst = max(worst, time.perf_counter() - t); pt.Dispose()
+    assert (got.view(np.uint32) == want.view(np.uint32)).all(), rep
+print('OK worst %%.3f s' %% worst); assert worst < 2.0
+""" % (ROOT, ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PT_BATCH_PASS_MIN_TILES="0"))
+    assert p.returncode == 0 and "OK worst" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+
+
+def test_large_image_pipelined_multisample_equals_unpipelined(pkg, native_lib):
+    """A pipelined spp > 1 launch at 16,384 tiles per frame (1024 x 1024: where the batch-pass kernel is the default), 48 frames
+    in one launch, 3 spp — against the same frames rendered one plain launch at a time by the tile-per-wave kernel."""
+    w = configs.Workload("ms_big", "default", 1024, 1024, 8, "sky_f32_32", spp=3, frames=48)
+    pipelined = hip_render(pkg, w)
+    pt = make_tracer(pkg, w)
+    pt.SetVariant(1)
+    pt.SetFrameBatch(1)
+    for _ in range(w.frames):
+        pt.Render()
+    plain = pt.Result
+    pt.Dispose()
+    assert_bit_exact(pipelined, plain, "1024x1024, 3 spp, 48 pipelined frames vs one plain launch per frame")
+
+
+# ------------------------------------------------------------------------------------------------ real peers
+def _device_count(native_lib):
+    return native_lib.pt_device_count()
+
+
+@pytest.mark.parametrize("band", [16, 0], ids=["banded", "contiguous"])
+def test_group_handle_over_distinct_devices(pkg, native_lib, oracle, band):
+    """pt_create_multi over ALL devices of the box (hipDeviceEnablePeerAccess + hipMemcpyPeerAsync between different devices):
+    gathered RGBA32F image, RGBA8 present and the non-blocking present equal the one-GPU render bit for bit."""
+    n = _device_count(native_lib)
+    if n < 2:
+        pytest.skip("one HIP device: the same-device group tests of test_gpu_abi_round2.py cover the logic")
+    w = configs.Workload("peers", "default", 320, 184, 8, "sky_f32_32", frames=6)
+    pt = make_tracer(pkg, w, devices=list(range(n)))
+    if band != 16:
+        pt.SetPartition(band)
+    for f in range(w.frames):
+        pt.Render()
+        if f == 2:
+            pt.PresentAsync(0)
+    want3 = oracle_render(oracle, w, frames=3)
+    want = oracle_render(oracle, w)
+    img, fi = pt.PresentWait(0)
+    assert fi == 3 and np.array_equal(img, oracle.postprocess(want3)[1])
+    assert_bit_exact(pt.Result, want, f"group handle over {n} distinct devices")
+    assert np.array_equal(pt.Present(), oracle.postprocess(want)[1])
+    pt.Dispose()
+
+
+def test_group_handle_1080p_over_all_devices(pkg, native_lib):
+    n = _device_count(native_lib)
+    if n < 2:
+        pytest.skip("one HIP device")
+    w = configs.C2
+    single = hip_render(pkg, w, frames=3)
+    pt = make_tracer(pkg, w, devices=list(range(n)))
+    for _ in range(3):
+        pt.Render()
+    assert_bit_exact(pt.Result, single, f"1080p over {n} devices")
+    pt.Dispose()
+
+
+def test_handover_stress_on_distinct_devices(pkg, native_lib):
+    n = _device_count(native_lib)
+    if n < 2:
+        pytest.skip("one HIP device")
+    print(_stress(pkg, pkg.native.LIB_PATH, 600, 306, "--devices", ",".join(str(d) for d in range(n)), "--max-parts", str(min(n, 5))))
+
+
+def test_bench_rccl_ranks_over_all_devices(pkg, native_lib):
+    """`python bench.py --gpus N` (no torchrun environment): N self-started ranks, one per device, RCCL gather at present; the
+    line must say n_gpus == N, and the in-process group handle must equal the RCCL-gathered image bit for bit."""
+    n = _device_count(native_lib)
+    if n < 2:
+        pytest.skip("one HIP device")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "64", "--warmup", "64", "--no-4k",
+                        "--steady-ms", "0"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == n and line["ranks"] == n and line["checks"]["finite"] and line["checks"]["alpha_one"]
+    assert line["in_process_group"]["equals_rccl_gather_bit_for_bit"] is True
+
+
+# ------------------------------------------------------------------------------------------------ bench.py launch modes
+def test_bench_self_spawns_ranks_and_refuses_missing_devices(pkg, native_lib):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset used to report a one-GPU run; now it either runs 2 ranks or fails.  On a
+    one-GPU box: it must refuse (non-zero exit, no JSON line), and `--share-gpu` (explicit debug mode: both ranks on cuda:0 over
+    gloo) must run two self-started ranks and say n_gpus = 1, ranks = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    n = _device_count(native_lib)
+    if n < 2:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "64", "--warmup", "64"],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode != 0 and "refusing" in (p.stderr + p.stdout) and not any(l.startswith("{") for l in p.stdout.splitlines())
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "64", "--warmup", "64", "--no-4k",
+                        "--steady-ms", "100"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["ranks"] == 2 and line["n_gpus"] == 1 and line["checks"]["finite"] and line["steady"]["steps"] >= 512
