@@ -68,6 +68,9 @@ static inline float f_unbits(uint32_t u) { float f; memcpy(&f, &u, 4); return f;
 /* pt-f32 reciprocal: seed by exponent negation, three Newton steps; zero and denormals give +-inf */
 static inline float f_rcp(float x)
 {
+#ifdef PT_EXACT_DIVSQRT /* fidelity study only (oracle/Makefile): correctly rounded 1/x, 1/sqrt(x), sqrt(x) as llvmpipe's / and sqrt are */
+    return 1.0f / x;
+#endif
     float y = f_unbits(0x7EF311C7u - f_bits(x));
     float e = fmaf(-x, y, 1.0f); y = fmaf(y, e, y);
     e = fmaf(-x, y, 1.0f); y = fmaf(y, e, y);
@@ -78,6 +81,9 @@ static inline float f_rcp(float x)
 /* pt-f32 inverse square root: classic seed, three Newton steps; zero/denormal -> +inf, negative -> NaN */
 static inline float f_rsqrt(float x)
 {
+#ifdef PT_EXACT_DIVSQRT
+    return 1.0f / sqrtf(x);
+#endif
     float y = f_unbits(0x5F3759DFu - (f_bits(x) >> 1));
     float h = 0.5f * x, t;
     t = y * y; t = fmaf(-h, t, 1.5f); y = y * t;
@@ -91,6 +97,9 @@ static inline float f_rsqrt(float x)
  * (every call site guards its argument: discriminant >= 0, 1 - z*z >= 0, k >= 0, rand in [0,1]) */
 static inline float pt_sqrt(float x)
 {
+#ifdef PT_EXACT_DIVSQRT
+    return sqrtf(x);
+#endif
     float y = f_unbits(0x5F3759DFu - (f_bits(x) >> 1));
     float h = 0.5f * x, t;
     t = h * y; t = fmaf(-t, y, 1.5f); y = y * t;
@@ -631,15 +640,20 @@ PTO_API int pto_render_frame(const PtoParams *p, const float *basic144, const fl
     make_ctx(&c, p, basic144, objects26624, env);
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
+    if (nthreads > rows) nthreads = rows > 0 ? rows : 1; /* thread t renders rows t, t + nthreads, ...: more threads than rows would idle */
     pthread_t th[256];
+    int started[256];
     Job jobs[256];
     for (int t = 0; t < nthreads; t++) {
         Job j = { &c, image, y0, rows, frame, t, nthreads, { 0, 0, 0, 0, 0, 0 }, stats != NULL };
         jobs[t] = j;
-        if (nthreads > 1) pthread_create(&th[t], NULL, row_worker, &jobs[t]);
+        /* a thread that cannot be created (EAGAIN under a process limit) must not leave its rows unrendered: run them here */
+        started[t] = nthreads > 1 && pthread_create(&th[t], NULL, row_worker, &jobs[t]) == 0;
     }
-    if (nthreads == 1) row_worker(&jobs[0]);
-    else for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    for (int t = 0; t < nthreads; t++) {
+        if (started[t]) pthread_join(th[t], NULL);
+        else row_worker(&jobs[t]);
+    }
     if (stats) {
         memset(stats, 0, 6 * sizeof(uint64_t));
         for (int t = 0; t < nthreads; t++) {

@@ -14,12 +14,13 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "libpt_oracle.so")
 LIB_TRUEDIV_PATH = os.path.join(HERE, "_build", "libpt_oracle_truediv.so")
+LIB_EXACT_PATH = os.path.join(HERE, "_build", "libpt_oracle_exact.so")  # fidelity study: IEEE 1/x, sqrt, 1/sqrt, a/b
 
 
 def build(force: bool = False) -> None:
     src = os.path.join(HERE, "pt_oracle.c")
-    stale = (not os.path.exists(LIB_PATH) or not os.path.exists(LIB_TRUEDIV_PATH)
-             or os.path.getmtime(LIB_PATH) < os.path.getmtime(src))
+    stale = (not os.path.exists(LIB_PATH) or not os.path.exists(LIB_TRUEDIV_PATH) or not os.path.exists(LIB_EXACT_PATH)
+             or min(os.path.getmtime(p) for p in (LIB_PATH, LIB_TRUEDIV_PATH, LIB_EXACT_PATH)) < os.path.getmtime(src))
     if force or stale:
         subprocess.run(["make", "-C", HERE, "-B" if force else "-s", "all"], check=True, capture_output=True)
 
@@ -38,9 +39,9 @@ def _ptr(a, t=_fp):
 
 
 class Oracle:
-    def __init__(self, true_division: bool = False):
+    def __init__(self, true_division: bool = False, exact: bool = False):
         build()
-        self.lib = C.CDLL(LIB_TRUEDIV_PATH if true_division else LIB_PATH)
+        self.lib = C.CDLL(LIB_EXACT_PATH if exact else (LIB_TRUEDIV_PATH if true_division else LIB_PATH))
         L = self.lib
         L.pto_render_frame.restype = C.c_int
         L.pto_render_frame.argtypes = [C.POINTER(PtoParams), _fp, _fp, C.c_void_p, _fp, C.c_int, C.c_int, C.c_int,

@@ -121,7 +121,14 @@ C5 = Workload("C5_glass_1080p_d32", "glass", 1920, 1080, 32, "atmosphere_32")
 # the workload bench.py times at N = 1 (default scene + the reference's default ATMOSPHERE environment, MainWindow.cs:174-175,189),
 # with the cube computed by the reference's own AtmosphericScattering/compute.glsl (64^2 keeps the committed cube small)
 C2_ATMO = Workload("C2_default_1080p_d8_atmo", "default", 1920, 1080, 8, "atmosphere_64")
-FULL_SIZE = [C1, C2, C3, C5, C2_ATMO]
+FULL_SIZE = [C1, C2, C3, C5, C2_ATMO, C4]
+
+# ---- per-pixel convergence statistics of the reference (4,096 frames of a small image; tests/golden/make_golden.py convergence)
+CONVERGENCE = [
+    Workload("default_64x36_d8", "default", 64, 36, 8, "sky_f32_32"),
+    Workload("glass_64x36_d32_atmo", "glass", 64, 36, 32, "atmosphere_32"),
+    Workload("stress256_64x36_d8", "stress256", 64, 36, 8, "sky_f32_32"),
+]
 
 # ---- small full-frame parity cases -----------------------------------------------------------------------------
 SMALL_FRAMES = [

@@ -242,6 +242,31 @@ def gen_converged():
          env_key=np.array(w.env), iparams=ip, fparams=fp, expected=out[0, ..., :3].copy())
 
 
+def gen_convergence():
+    """Per-pixel convergence statistics of the REFERENCE (its own GLSL on llvmpipe) for the three scene families: 4,096 frames of
+    a 64x36 image rendered as 64 independent blocks of 64 consecutive frame indices (block b = frames 64b .. 64b+63; the
+    shader's running mean over a block that starts at frame index f0 on a zeroed image ends at sum / (f0 + 64), so the block
+    mean is that value * (f0 + 64) / 64).  Stored per pixel and channel: the mean over all 4,096 frames and its standard error
+    (std of the 64 block means / 8).  Pixels the reference itself turns NaN (normalize(0) paths) are kept as NaN."""
+    print("per-pixel convergence statistics (reference GLSL, 64 blocks x 64 frames):")
+    blocks, per = 64, 64
+    for w in configs.CONVERGENCE:
+        sc, basic, objs, env, kw = configs.inputs(w)
+        means = np.empty((blocks, w.height, w.width, 3), np.float64)
+        for b in range(blocks):
+            f0 = b * per
+            out = ref.run_pathtracer(w.width, w.height, basic, objs, env, frame_start=f0, num_frames=per, **kw)
+            means[b] = out[0, ..., :3].astype(np.float64) * ((f0 + per) / per)
+        mean = means.mean(axis=0)
+        se = means.std(axis=0, ddof=1) / np.sqrt(blocks)
+        ip, fp = params_array(w, kw)
+        ip[6] = blocks * per
+        print(f"   {w.name}: mean radiance {np.nanmean(mean):.5f}, median relative standard error {np.nanmedian(se / np.maximum(mean, 1e-6)):.4f}, "
+              f"NaN pixels {int(np.isnan(mean).any(-1).sum())}")
+        save("convergence_" + w.name, basic=np.frombuffer(basic, np.uint8), objects=np.frombuffer(objs, np.uint8),
+             env_key=np.array(w.env), iparams=ip, fparams=fp, mean=mean.astype(np.float32), stderr=se.astype(np.float32))
+
+
 def gen_bench_fixture():
     """Only what round 2 added (keeps every older fixture byte-identical): the atmosphere_64 cube + the sparse fixture of
     the exact workload bench.py times."""
@@ -254,7 +279,7 @@ def gen_bench_fixture():
     gen_sparse(only={configs.C2_ATMO.name})
 
 
-GROUPS = {"bench": gen_bench_fixture, "converged": gen_converged, "post": gen_post, "envs": gen_envs, "micro": gen_micro, "frames": gen_frames, "envonly": gen_envonly, "sparse": gen_sparse,
+GROUPS = {"bench": gen_bench_fixture, "converged": gen_converged, "convergence": gen_convergence, "post": gen_post, "envs": gen_envs, "micro": gen_micro, "frames": gen_frames, "envonly": gen_envonly, "sparse": gen_sparse,
           "atmo": gen_atmo}
 
 if __name__ == "__main__":

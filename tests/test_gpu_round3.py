@@ -21,6 +21,8 @@ import numpy as np
 import pytest
 
 import configs
+import fixtures
+import tolerances as tol
 from test_gpu_abi_round2 import make_tracer
 from test_gpu_parity import assert_bit_exact, hip_render, oracle_render
 
@@ -118,6 +120,24 @@ def test_large_image_pipelined_multisample_equals_unpipelined(pkg, native_lib):
     plain = pt.Result
     pt.Dispose()
     assert_bit_exact(pipelined, plain, "1024x1024, 3 spp, 48 pipelined frames vs one plain launch per frame")
+
+
+# ------------------------------------------------------------------------------------------------ per-pixel convergence
+@pytest.mark.parametrize("name", fixtures.names("convergence_"))
+def test_per_pixel_convergence_against_the_reference(pkg, native_lib, oracle, name):
+    """Default / glass (32 bounces, atmosphere cube) / 256-sphere scenes: 4,096 frames accumulated on the HIP path through the C ABI
+    (pipelined launches), every pixel and channel compared with the reference's own 4,096-frame mean in units of the reference's
+    own standard error (fixtures from the reference GLSL on llvmpipe).  Marks: tests/tolerances.py CONV_*."""
+    fx = fixtures.load(name)
+    pt = fixtures.hip_tracer(pkg, fx)
+    for _ in range(fx["frames"]):
+        pt.Render()
+    img = pt.Result[..., :3]
+    pt.Dispose()
+    st = tol.convergence_stats(fx["mean"], fx["stderr"], img)
+    print(name, st)
+    assert st["nan_mismatch"] == 0 and st["pixels"] == fx["width"] * fx["height"]
+    assert st["max_abs_z"] <= tol.CONV_MAX_ABS_Z and st["rms_z"] <= tol.CONV_RMS_Z and st["mean_rel_err"] <= tol.CONV_MEAN_REL_TOL, st
 
 
 # ------------------------------------------------------------------------------------------------ real peers
