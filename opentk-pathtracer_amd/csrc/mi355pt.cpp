@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <thread>
 #include <cstring>
 #include <new>
 
@@ -73,6 +74,7 @@ int join_stripes(pt_handle h)
         h->flushFinal = false;
         if (rc) return rc;
     }
+    h->snapFrame = -1;   // whoever joins may change the image or the frame counter: a present snapshot written earlier is stale
     h->mainDirty = true; // whoever joins is about to put other work on the main stream: the next striped frame orders behind it
     h->chainBroken = true; // ... and the next tagged launch re-joins the two launch streams before it starts
     if (h->chainPending) {
@@ -286,10 +288,13 @@ PT_API int pt_destroy(pt_handle h)
     h->pendingFrames = 0; // frames nobody can observe any more are not worth launching
     (void)hipSetDevice(h->device);
     if (h->copyStream) (void)hipStreamSynchronize(h->copyStream);
+    for (int k = 0; k < pt_renderer::kSnapshots; k++) {
+        if (h->snapRead[k]) (void)hipEventDestroy(h->snapRead[k]);
+        if (h->dSnap[k]) (void)hipFree(h->dSnap[k]);
+    }
     ptimpl::free_slots(h);
     if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
     if (h->gatherReady) (void)hipEventDestroy(h->gatherReady);
-    if (h->chainStream) { (void)hipStreamSynchronize(h->chainStream); (void)hipStreamDestroy(h->chainStream); }
     if (h->chainDone) (void)hipEventDestroy(h->chainDone);
     for (int j = 0; j < ptimpl::kMaxStripes; j++)
         if (h->stripeStream[j]) (void)hipStreamSynchronize(h->stripeStream[j]);
@@ -486,11 +491,14 @@ PT_API int pt_set_environment(pt_handle h, int face_size, int format, const void
 
 namespace {
 
+bool gpu_busy(pt_handle h);
+
 // Launch frames [firstFrame, firstFrame + n) with the handle's current inputs.  n == 1: the striped frame; n > 1: one
 // batch kernel on the main stream (pt_kernels.hip, frame pipelining).
 int launch_frames(pt_handle h, int firstFrame, int n)
 {
     if (int rc = bind_device(h)) return rc;
+    if (!h->snapshotTarget) h->snapFrame = -1; // frames rendered without a present snapshot: an older snapshot no longer shows the image
     pt::FrameArgs a;
     std::memcpy(a.invProj, h->basic, 64);
     std::memcpy(a.invView, h->basic + 64, 64);
@@ -522,6 +530,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     a.errorWord = h->devErrWord;
     a.startedFlags = nullptr;
     a.launchSeq = 0;
+    a.snapshot = nullptr; // (set next to every a.accum below when this launch feeds a present)
     a.audit = nullptr; // (set next to every a.accum below)
     a.auditLog = h->devAuditLog;
     a.auditSabotage = 0;
@@ -558,9 +567,18 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     // Tagged launches (pixels handed over through alpha tags): every launch of more than one frame, and — once the host has
     // pipelined frames on this handle — single frames too, so that they can overlap the launches around them (a host that
     // presents every frame, or only ever renders one frame at a time, keeps the faster single-frame stripes).
-    const bool chainable = h->variant == 0 && !h->externalStream() && h->maxBatch > 1 && h->dTimeline == nullptr;
-    const bool tagged = h->variant == 0 && (n > 1 || (chainable && h->sawBatch && h->presentCadence != 1));
-    if (tagged) { stripes = 1; kernelVariant = 10 + h->batchWorkgroupsPerCU - 1; h->batchLaunched = true; if (n > 1) h->sawBatch = true; }
+    // ... and single frames whenever the GPU still runs earlier frames of this handle: the frame then chains on the other stream and
+    // moves into the wavefront slots the previous launch's drain frees (0.154 ms per 1080p frame against 0.182 for the two row
+    // stripes); a host that lets the GPU run dry between its frames (blocking reads / presents) keeps the stripes, which are the
+    // faster way to render ONE frame on an idle machine.
+    static const bool noSingleTagged = std::getenv("PT_NO_SINGLE_TAGGED") != nullptr; // A/B runs
+    const bool chainable = h->variant == 0 && !h->externalStream() && h->dTimeline == nullptr;
+    const bool tagged = h->variant == 0 && (n > 1 || (chainable && !noSingleTagged && gpu_busy(h)));
+    // (short launches — the interactive modes — take 5 workgroups per CU: 112 instead of 32 free VGPRs per SIMD leave the present's
+    // tone map and the runtime's copy kernel room BESIDE the resident persistent wavefronts; 6 per CU starve them until the drain,
+    // measured: 0.28 instead of 0.16 ms per displayed frame; a single frame also renders 2 % faster with 5)
+    static const int shortWg = std::getenv("PT_SHORT_WG") ? std::atoi(std::getenv("PT_SHORT_WG")) : 5;
+    if (tagged) { stripes = 1; kernelVariant = 10 + (n < 8 ? shortWg : h->batchWorkgroupsPerCU) - 1; h->batchLaunched = true; if (n > 1) h->sawBatch = true; }
     else if (h->variant == 0 && h->externalStream()) { stripes = 1; kernelVariant = 14; } // everything ON the caller's stream
     else if (h->variant == 0) { stripes = 2; kernelVariant = 14; }
     else if (h->variant >= 20 && h->variant < 50) { stripes = h->variant / 10; kernelVariant = 10 + h->variant % 10; }
@@ -581,6 +599,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         a.rows = h->rows;
         a.accum = h->accum();
         a.audit = h->dAudit;
+        a.snapshot = h->snapshotTarget;
         a.tilesY = (h->rows + 7) / 8;
         a.keepTags = h->flushFinal ? 0 : 1;
         // Beside its predecessor (other stream) only if that launch is fully resident — then this launch can only ever get the slots
@@ -592,11 +611,23 @@ int launch_frames(pt_handle h, int firstFrame, int n)
             return true;
         };
         bool resident = mayChain && all_started();
-        if (mayChain && !resident && h->flushFinal) {
-            // the caller is about to wait for these frames anyway (read / synchronise / timer): give a predecessor that was launched
-            // a moment ago the few microseconds its workgroups need to report in (short render-N-then-read sequences)
+        // (small shares — a 1/8 share of 1080p has 4,050 tiles per frame — lose 4 % when two launches overlap: the second launch's first
+        // frames all wait for the first one's last; measured, tools/emulate_strong.py)
+        const bool bigShare = (long long)a.tilesX * a.tilesY >= 12000;
+        if (mayChain && !resident && (bigShare || h->flushFinal)) {
+            // Back-pressure (round 3): the host is more than one launch ahead of the GPU — the predecessor still queues behind ITS
+            // predecessor.  Launching behind it on the same stream would expose a full drain + ramp per launch (0.096 ms at 1080p);
+            // instead the call waits until the predecessor is resident (i.e. until the launch before it has left the machine) and
+            // then chains.  The host thread is never more than two launches ahead; bounded, so a GPU shared with another process
+            // falls back to the always-safe same-stream order.
+            static const long waitLimitUs = std::getenv("PT_CHAIN_WAIT_US") ? std::atol(std::getenv("PT_CHAIN_WAIT_US")) : 60000;
             const auto t0 = std::chrono::steady_clock::now();
-            while (!resident && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(60)) resident = all_started();
+            for (long spins = 0; !resident; spins++) {
+                const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+                if (waited >= waitLimitUs) break;
+                if (waited > 200) std::this_thread::sleep_for(std::chrono::microseconds(20)); // (long waits: do not burn the core)
+                resident = all_started();
+            }
         }
         int si = resident ? (h->lastStreamIdx ^ 1) : h->lastStreamIdx;
         if (h->chainBroken) {
@@ -611,13 +642,16 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         a.chainTag = h->tagsLive ? h->lastTag : 0.0f;
         hipStream_t st = h->stream;
         if (si == 1) {
-            if (!h->chainStream) PT_HIP(h, hipStreamCreateWithFlags(&h->chainStream, hipStreamNonBlocking));
-            st = h->chainStream;
+            // the chain stream IS the helper stream of stripe 1: the library keeps at most three streams busy (main, this one, copy) —
+            // HIP multiplexes streams onto 4 hardware queues, and two of the library's streams that share a queue execute in order
+            if (int rc = ptimpl::ensure_stripe(h, 1)) return rc;
+            st = h->stripeStream[1];
             if (h->chainNeedsInputs) {
                 PT_HIP(h, hipStreamWaitEvent(st, h->inputsReady, 0));
                 h->chainNeedsInputs = false;
             }
         }
+        if (a.snapshot && h->snapReadPending[h->snapshotIndex]) PT_HIP(h, hipStreamWaitEvent(st, h->snapRead[h->snapshotIndex], 0));
         a.startedFlags = h->devStarted;
         a.launchSeq = ++h->launchSeq;
         if (a.launchSeq == 0) a.launchSeq = ++h->launchSeq; // (0 is what a fresh array holds)
@@ -632,9 +666,11 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         if (si == 1) {
             PT_HIP(h, hipEventRecord(h->chainDone, st));
             h->chainInFlight = h->chainPending = true;
+            if (a.snapshot) h->snapLaunches.push_back({st, h->chainDone, 0, h->tilePixels()});
         } else {
             PT_HIP(h, hipEventRecord(h->mainDone, st));
             h->mainInFlight = true;
+            if (a.snapshot) h->snapLaunches.push_back({st, h->mainDone, 0, h->tilePixels()});
         }
         h->chainBroken = false; // (join_stripes above set it; this launch re-opens the chain)
         h->mainDirty = true;    // a striped frame that follows must order its helper stripe behind this launch
@@ -647,6 +683,8 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         a.rows = h->rows;
         a.accum = h->accum();
         a.audit = h->dAudit;
+        a.snapshot = kernelVariant >= 10 ? h->snapshotTarget : nullptr; // (only the persistent kernels write snapshots)
+        if (a.snapshot && h->snapReadPending[h->snapshotIndex]) PT_HIP(h, hipStreamWaitEvent(h->stream, h->snapRead[h->snapshotIndex], 0));
         a.tilesY = (h->rows + 7) / 8;
         a.queue = h->dQueue;
         a.queueBase = h->stripeQueueBase[0];
@@ -655,6 +693,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         h->stripeQueueBase[0] += tickets; // unsigned wrap-around is fine: the kernel subtracts queueBase modulo 2^32
         PT_HIP(h, hipEventRecord(h->mainDone, h->stream));
         h->mainInFlight = true;
+        if (a.snapshot) h->snapLaunches.push_back({h->stream, h->mainDone, 0, h->tilePixels()});
     } else {
         // inputs uploaded on the main stream (scene, environment, clears) must be visible to the stripe streams;
         // a stripe's frame f+1 follows its own frame f in stream order, which is the only dependency between frames
@@ -678,6 +717,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
             a.rows = r1 - r0;
             a.accum = h->accum() + (size_t)r0 * h->width;
             a.audit = h->dAudit ? h->dAudit + (size_t)r0 * h->width : nullptr;
+            a.snapshot = h->snapshotTarget ? h->snapshotTarget + (size_t)r0 * h->width : nullptr;
             a.tilesY = (a.rows + 7) / 8;
             a.queue = h->dQueue + 16 * j;
             a.queueBase = h->stripeQueueBase[j];
@@ -686,10 +726,12 @@ int launch_frames(pt_handle h, int firstFrame, int n)
             h->stripeRows[j] = r1 - r0;
             hipStream_t st = ptimpl::stripe_stream(h, j);
             if (j > 0 && orderHelpers) PT_HIP(h, hipStreamWaitEvent(st, h->inputsReady, 0));
+            if (a.snapshot && h->snapReadPending[h->snapshotIndex]) PT_HIP(h, hipStreamWaitEvent(st, h->snapRead[h->snapshotIndex], 0));
             unsigned int tickets = 0;
             PT_HIP(h, pt::launch_integrate(a, st, &tickets));
             h->stripeQueueBase[j] += tickets;
             PT_HIP(h, hipEventRecord(h->stripeDone[j], st));
+            if (a.snapshot) h->snapLaunches.push_back({st, h->stripeDone[j], (size_t)r0 * h->width, (size_t)(r1 - r0) * h->width});
             h->stripePending[j] = true;
             h->stripeInFlight[j] = true;
         }
@@ -795,6 +837,39 @@ int ensure_slot_host(pt_handle h, int slot, size_t pixels)
     return PT_OK;
 }
 
+// Launch the pending frames with a present snapshot attached: their launch stores its last frame's pixels into snapshot buffer
+// h->snapNext while it resolves them (FrameArgs::snapshot).  On return h->snapLaunches lists the launches that write it (empty if
+// a kernel variant without snapshot support rendered the frames) and h->snapFrame is the frame count the snapshot shows.
+int flush_with_snapshot(pt_handle h)
+{
+    const int k = h->snapNext;
+    const size_t pixels = h->tilePixels();
+    if (pixels > h->snapCapacity[k]) {
+        if (h->snapReadPending[k]) PT_HIP(h, hipEventSynchronize(h->snapRead[k]));
+        h->snapReadPending[k] = false;
+        if (h->dSnap[k]) PT_HIP(h, hipFree(h->dSnap[k]));
+        h->dSnap[k] = nullptr;
+        h->snapCapacity[k] = 0;
+        PT_HIP(h, hipMalloc((void **)&h->dSnap[k], pixels * sizeof(float4)));
+        h->snapCapacity[k] = pixels;
+    }
+    if (!h->snapRead[k]) PT_HIP(h, hipEventCreateWithFlags(&h->snapRead[k], hipEventDisableTiming));
+    h->snapshotTarget = h->dSnap[k];
+    h->snapshotIndex = k;
+    h->snapLaunches.clear();
+    h->snapFrame = -1;
+    const int rc = flush_frames(h);
+    h->snapshotTarget = nullptr;
+    if (rc) return rc;
+    if (!h->snapLaunches.empty()) {
+        h->snapFrame = h->frame;
+        // every snapshot launch takes the next buffer, presented or not: two launches that may run beside each other must never
+        // write the same snapshot (their plain stores to one pixel are not ordered by the tags)
+        h->snapNext = (k + 1) % pt_renderer::kSnapshots;
+    }
+    return PT_OK;
+}
+
 void free_slots(pt_handle h)
 {
     for (PresentSlot &s : h->slots) {
@@ -838,6 +913,12 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     h->pendingFrames++;
     h->frame++; // PathTracer.cs:117 post-increment
     if (out_total_samples) *out_total_samples = h->frame * h->spp; // PathTracer.cs:112
+    // Round 3: a host that presents every frame through pt_present_rgba8_async gets this frame launched BY that present call (a few
+    // microseconds from now), because the launch then also writes the present snapshot while it resolves its pixels
+    // (FrameArgs::snapshot) and the tone map never stands between two frames.  Any other call launches it as usual.
+    // (launched NOW, not by the present: a host that first waits for a present slot and then presents must find the GPU busy)
+    if (presentsEveryFrame && (h->variant == 0 || h->variant >= 10) && !h->externalStream() && h->dTimeline == nullptr)
+        return ptimpl::flush_with_snapshot(h);
     // Frames are only held back while the GPU still has integrator work of this handle in flight: deferring can then
     // never idle the device, and a host that leaves time between its frames gets every frame launched at once.
     if (!batchable || h->pendingFrames >= h->maxBatch || !gpu_busy(h)) return flush_frames(h);
@@ -924,6 +1005,42 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
     if (int rc = ptimpl::ensure_slot_events(h, slot)) return rc;
     if (int rc = ptimpl::ensure_slot_device(h, slot, pixels)) return rc;
     if (int rc = ptimpl::ensure_slot_host(h, slot, pixels)) return rc;
+    // ---- snapshot path: the launch of the frames shown writes its last frame into a snapshot buffer while it resolves the pixels;
+    // the tone map follows that launch on its stream, the copy on the copy stream, and nothing waits for them: the next pt_render
+    // chains its launch beside this one.
+    const bool snapshotCapable = (h->variant == 0 || h->variant >= 10) && !h->externalStream() && h->dTimeline == nullptr;
+    if (snapshotCapable && h->pendingFrames > 0)
+        if (int rc = ptimpl::flush_with_snapshot(h)) return rc;
+    if (snapshotCapable && h->pendingFrames == 0 && h->snapFrame == h->frame && !h->snapLaunches.empty()) {
+        // (the frames' launch — flushed just now, or by the pt_render before this call — wrote snapshot buffer snapshotIndex)
+        {
+            const int k = h->snapshotIndex;
+            // The tone map of a launch's rows runs ON that launch's stream, right behind it (a few microseconds: the kernel raises its
+            // wave priority, the next launch is already resident on the other stream).  Only the NEXT-BUT-ONE launch queues behind it.
+            // Not on the copy stream: tone map + 150 us copy in one queue would bound the display rate; not on a stream of its own: a
+            // fourth busy stream shares a hardware queue with a launch stream and would run behind the next launch.
+            for (const pt_renderer::SnapLaunch &l : h->snapLaunches) {
+                if (s.inFlight) PT_HIP(h, hipStreamWaitEvent(l.stream, s.copied, 0)); // the slot's previous copy still reads its device image
+                PT_HIP(h, pt::launch_postprocess(h->dSnap[k] + l.firstPixel, (char *)s.dRgba8 + l.firstPixel * 4, l.pixels, l.stream));
+                PT_HIP(h, hipEventRecord(l.done, l.stream)); // "launch done" now includes its tone map
+                PT_HIP(h, hipStreamWaitEvent(h->copyStream, l.done, 0));
+            }
+            PT_HIP(h, hipEventRecord(h->snapRead[k], h->copyStream)); // (behind every tone map that read the snapshot)
+            h->snapReadPending[k] = true;
+            PT_HIP(h, hipMemcpyAsync(s.host, s.dRgba8, pixels * 4, hipMemcpyDeviceToHost, h->copyStream));
+            PT_HIP(h, hipEventRecord(s.copied, h->copyStream));
+            s.inFlight = true;
+            s.valid = false;
+            s.frame = h->frame;
+            s.rows = h->rows;
+            s.width = h->width;
+            h->snapFrame = -1; // consumed
+            h->snapLaunches.clear();
+            return PT_OK;
+        }
+    }
+    // (nothing pending and no fresh snapshot — the frames were launched by another call, or by a kernel variant that writes none:
+    // present from the accumulation image)
     if (int rc = flush_frames(h)) return rc;
     bool striped = false;
     for (int j = 0; j < ptimpl::kMaxStripes; j++) striped = striped || h->stripePending[j];

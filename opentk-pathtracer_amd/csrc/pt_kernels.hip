@@ -529,6 +529,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             const float4 next = fold(last, rirr, 0);
             AUDIT_RESOLVE(a, (size_t)rpix, a.frame, last, next, 3);
             *ptr = next;
+            if (float4 *snap = cold_args()->snapshot) snap[rpix] = next; // (one frame per launch: it is the last)
             return true;
         }
         CHAOS(10);
@@ -540,6 +541,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         const float4 next = fold(last, rirr, rfj);
         AUDIT_RESOLVE(a, (size_t)rpix, a.frame + rfj, last, next, 4);
         store_pixel_sc1(ptr, next);
+        if (rfj == cold_args()->batchFrames - 1) // the launch's last frame: the present snapshot (plain store, read after the launch)
+            if (float4 *snap = cold_args()->snapshot) snap[rpix] = make_float4(next.x, next.y, next.z, 1.0f);
         CHAOS(12);
         return true;
     };
@@ -1028,6 +1031,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
             const float4 last = *ptr, next = fold(last, rirr, 0);
             AUDIT_RESOLVE(a, pidx, a.frame, last, next, 5);
             *ptr = next;
+            if (float4 *snap = cold_args()->snapshot) snap[pidx] = next;
             return true;
         }
         CHAOS(20);
@@ -1039,6 +1043,8 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         const float4 next = fold(last, rirr, rfj);
         AUDIT_RESOLVE(a, pidx, a.frame + rfj, last, next, 6);
         store_pixel_sc1(ptr, next);
+        if (rfj == cold_args()->batchFrames - 1)
+            if (float4 *snap = cold_args()->snapshot) snap[pidx] = make_float4(next.x, next.y, next.z, 1.0f);
         CHAOS(22);
         return true;
     };
@@ -1505,6 +1511,9 @@ hipError_t launch_env_to_float(const void *env, int envSize, int envFormat, cons
 // elementwise pass: 16 B read + 4 B written per pixel.
 __global__ __launch_bounds__(256) void pt_postprocess_kernel(const float4 *accum, uchar4 *out, size_t n)
 {
+    // a few microseconds of work that the present path launches BESIDE resident persistent wavefronts (mi355pt.cpp,
+    // pt_present_rgba8_async): take the issue slots first, or it runs at a sixth of its speed (75 instead of 11 us)
+    __builtin_amdgcn_s_setprio(3);
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     size_t stride = (size_t)gridDim.x * 256;
     for (; i < n; i += stride) {

@@ -62,6 +62,10 @@ struct FrameArgs {
     float gridLo[3], gridHi[3], gridCell[3], gridInvCell[3]; // box, cell size and its reciprocal per axis
     float gridCenter[3];    // a ray uses the grid when its origin lies within sqrt(gridReach2) of the box centre (see ray_trace_t)
     float gridReach2;
+    // Present snapshot (non-blocking present, mi355pt.cpp pt_present_rgba8_async): when set, the resolve of the launch's LAST frame
+    // also stores the pixel's new value here (same indexing as accum) — a consistent image of that frame that later frames never
+    // touch, so the tone map can read it while the next launch (chained, ordered per pixel by the tags) already overwrites accum.
+    float4 *snapshot;
     // Hand-over audit (only compiled into the -DPT_AUDIT build, tools/handover_stress.cpp; nullptr otherwise): one 64-bit word per
     // accumulation pixel = (frames folded so far) << 32 | hash of the colour stored last, maintained with device-scope atomic
     // exchanges next to every read-modify-write of the pixel — an independent, atomics-only record of compute.glsl:126-129's

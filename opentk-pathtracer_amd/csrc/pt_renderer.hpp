@@ -78,7 +78,7 @@ struct pt_renderer {
     // and `chainStream` and are ordered per PIXEL by the alpha tags, not by the streams, so a launch starts in the wavefront
     // slots the previous launch's drain frees.  While `tagsLive` the image's alpha channel holds tags: every entry point that
     // lets the host observe the image restores alpha = 1 first (fix_alpha).
-    hipStream_t chainStream = nullptr; // created on first use
+    // (the second launch stream is stripeStream[1]: the helper stream of the striped frames doubles as the chain stream)
     hipEvent_t chainDone = nullptr;    // recorded behind the last launch on chainStream
     // A launch may only run BESIDE its predecessor (on the other stream) when that predecessor is fully resident: a dependent launch
     // that got hold of the machine first would leave the launch it waits for a handful of workgroup slots (seen once: a 4K
@@ -130,6 +130,21 @@ struct pt_renderer {
     // non-blocking present
     hipStream_t copyStream = nullptr;
     ptimpl::PresentSlot slots[PT_PRESENT_SLOTS];
+    // Present snapshots (round 3): the launch that pt_present_rgba8_async flushes stores its last frame's pixels into one of these
+    // (FrameArgs::snapshot) while it resolves them, so the tone map reads a frame that no later launch touches and the next
+    // launch need not wait for it: it chains on the other stream like any pipelined launch.  Three buffers in rotation; a buffer
+    // is rewritten only after the tone map that read it (snapRead) has run.
+    static constexpr int kSnapshots = 3;
+    float4 *dSnap[kSnapshots] = {nullptr, nullptr, nullptr};
+    size_t snapCapacity[kSnapshots] = {0, 0, 0}; // in pixels
+    hipEvent_t snapRead[kSnapshots] = {nullptr, nullptr, nullptr};
+    bool snapReadPending[kSnapshots] = {false, false, false};
+    int snapNext = 0;
+    float4 *snapshotTarget = nullptr;            // set around the flush of pt_present_rgba8_async: the launch's FrameArgs::snapshot
+    int snapshotIndex = -1;
+    int snapFrame = -1;                          // frame counter value whose image the snapshot written last holds (-1: none)
+    struct SnapLaunch { hipStream_t stream; hipEvent_t done; size_t firstPixel, pixels; };
+    std::vector<SnapLaunch> snapLaunches;        // the launch(es) that write the snapshot: stream, its "done" event, the rows they cover
 
     // group handle (pt_create_multi): parts[i] renders its share on device_ids[i]; this struct then only carries the root
     // device's streams, the gather buffers and the present slots
