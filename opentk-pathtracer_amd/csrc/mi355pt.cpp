@@ -921,7 +921,12 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
         return ptimpl::flush_with_snapshot(h);
     // Frames are only held back while the GPU still has integrator work of this handle in flight: deferring can then
     // never idle the device, and a host that leaves time between its frames gets every frame launched at once.
-    if (!batchable || h->pendingFrames >= h->maxBatch || !gpu_busy(h)) return flush_frames(h);
+    // (a GPU that owns a small share of the image — fewer than 12,000 tiles per frame, e.g. 1/8 of 1080p — pipelines up to 256 frames
+    // per launch when the batch size was left at its default: every launch boundary costs ~0.1 ms of drain + ramp, 7 % of a 64-frame
+    // launch there; spp > 1 keeps 64, its kernels carry the frame index in 7 bits)
+    int maxBatch = h->maxBatch;
+    if (maxBatch == 64 && h->spp == 1 && (long long)((h->width + 7) / 8) * ((h->rows + 7) / 8) < 12000) maxBatch = 256;
+    if (!batchable || h->pendingFrames >= maxBatch || !gpu_busy(h)) return flush_frames(h);
     return PT_OK;
 }
 

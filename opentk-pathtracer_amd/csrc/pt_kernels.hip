@@ -299,7 +299,7 @@ constexpr float FRAME_TAG = 2.0f;
 // first one's drain frees) — the host restores alpha = 1 before anything can observe the image (pt_set_alpha_kernel).
 PT_DEV float frame_tag(int absFrame) { return FRAME_TAG + (float)(absFrame & 1023); }
 constexpr int FRAME_RETRY_LIMIT = 1 << 22;
-constexpr int MAX_BATCH_FRAMES = 64;
+constexpr int MAX_BATCH_FRAMES = 256; // (one workgroup fills the weight table: <= its 256 threads; tags cover 1,024 frames)
 
 PT_DEV float4 load_pixel_sc1(const float4 *p)
 {
@@ -337,10 +337,22 @@ struct RingEntry { // 40 bytes (spp > 1)
 // spp == 1 kernels: the ring holds paths AFTER their first bounce (see the tile pass in the kernel), 60 bytes each
 struct PathEntry {
     int pix;       // linear index into accum
-    int bounce;    // bounces done so far | frame of the batch << 16
+    int bounce;    // bounces done so far | frame of the batch << 16 | bit 30: `last` holds the pixel's current value
     uint32_t seed; // RNG state
     float ro[3], rd[3], thr[3], rad[3];
+#ifdef PT_CARRY_LAST
+    // The pixel's accumulation value, read by the TILE PASS with all 64 lanes (8 rows x 128 B: full lines) while the first bounce
+    // computes, and carried with the path: its resolve then needs no load (and no memory round trip) — nobody else writes the
+    // pixel between frame f-1's resolve and frame f's.  Only valid when the tile pass already saw the previous frame's tag.
+    float last[3];
+#endif
 };
+constexpr int PATH_HAS_LAST = 1 << 30;
+#ifdef PT_CARRY_LAST
+constexpr size_t kLaneLastBytes = 12; // per lane: the pixel value read by the tile pass (LDS slot, see the kernel)
+#else
+constexpr size_t kLaneLastBytes = 0;
+#endif
 
 // spp = 1, frame pipelining: a finished path whose pixel still holds an older frame used to keep its lane until the
 // previous frame's resolve arrived.  It now PARKS the result (pixel, frame of the batch, radiance: 20 bytes) in its
@@ -351,7 +363,7 @@ struct ParkedResolve {
     int pix, fj;
     float irr[3];
 };
-constexpr int PARKED_MAX = 64;
+constexpr int PARKED_MAX = 64; // upper bound; FrameArgs::parkedMax is what a launch uses
 
 struct BlockQueue {            // one per workgroup, in static LDS
     unsigned long long pair;   // (end << 32) | cursor : absolute tile indices of the current chunk
@@ -477,11 +489,19 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     char *ringBase = (char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, a.materialsInLds != 0, a.gridLdsBytes);
     RingEntry *ring = (RingEntry *)(ringBase + wave * 64 * ENTRY_BYTES);  // !SPP1: primary rays
     PathEntry *pring = (PathEntry *)(ringBase + wave * 64 * ENTRY_BYTES); //  SPP1: paths after their first bounce
-    PathState *pool = (PathState *)(ringBase + NWAVES * 64 * ENTRY_BYTES);
+#ifdef PT_CARRY_LAST
+    // per-lane slots for the pixel value the tile pass read (PathEntry::last travels here when a lane pops the path): three planes of
+    // 64 floats per wavefront, so that keeping it costs no registers across the bounce loop
+    constexpr int LANE_LAST_BYTES = SPP1 ? NWAVES * 3 * 64 * 4 : 0;
+    float *laneLast = (float *)(ringBase + NWAVES * 64 * ENTRY_BYTES) + wave * 3 * 64 + lane;
+#else
+    constexpr int LANE_LAST_BYTES = 0;
+#endif
+    PathState *pool = (PathState *)(ringBase + NWAVES * 64 * ENTRY_BYTES + LANE_LAST_BYTES);
     const bool compaction = a.drainCompaction != 0;
     // parked resolves of this wavefront (pipelined spp = 1 launches only; behind the rings — such launches have no drain pool)
-    ParkedResolve *parkedList = (ParkedResolve *)(ringBase + NWAVES * 64 * ENTRY_BYTES) + wave * PARKED_MAX;
-    const bool parking = SPP1 && a.tagged && !compaction;
+    ParkedResolve *parkedList = (ParkedResolve *)(ringBase + NWAVES * 64 * ENTRY_BYTES + LANE_LAST_BYTES) + wave * a.parkedMax;
+    const bool parking = SPP1 && a.tagged && !compaction && a.parkedMax > 0;
     int nparked = 0, parkSpins = 0; // wave-uniform
     const int donateMax = a.drainCompaction < DONATE_MAX ? a.drainCompaction : DONATE_MAX; // a wavefront this thin donates
     const bool leader = lane == 0;
@@ -504,6 +524,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     // frame" flag, and the number of failed resolve attempts
     int fj = 0, retries = 0;
     bool pending = false;
+    // (PT_CARRY_LAST: bit 14 of fj = the lane's slot of laneLast holds the pixel's accumulation value as the tile pass read it)
 
     // compute.glsl:125-129 for one finished path of frame `rfj` of the batch.  False = the pixel still holds an older
     // frame (only possible inside a batch): try again in the next iteration.
@@ -521,6 +542,18 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         const float alpha = (rfj == ca->batchFrames - 1 && !ca->keepTags) ? 1.0f : frame_tag(ca->frame + rfj);
         return make_float4(f_mix(last.x, rirr.x, w), f_mix(last.y, rirr.y, w), f_mix(last.z, rirr.z, w), alpha);
     };
+#ifdef PT_CARRY_LAST
+    // compute.glsl:126-129 with the pixel's value already in hand (read by the tile pass, which also checked the tag): no load
+    auto commit_resolve = [&](int rpix, int rfj, v3 rirr, v3 rlast) -> void {
+        const float4 last = make_float4(rlast.x, rlast.y, rlast.z, 0.0f);
+        const float4 next = fold(last, rirr, rfj);
+        AUDIT_RESOLVE(a, (size_t)rpix, a.frame + rfj, last, next, 7);
+        if (!a.tagged) a.accum[rpix] = next;
+        else store_pixel_sc1(a.accum + rpix, next);
+        if (rfj == cold_args()->batchFrames - 1)
+            if (float4 *snap = cold_args()->snapshot) snap[rpix] = make_float4(next.x, next.y, next.z, 1.0f);
+    };
+#endif
     // False = the pixel still holds an older frame (only possible inside a batch): try again in the next iteration.
     auto try_resolve = [&](int rpix, int rfj, v3 rirr, bool force) -> bool {
         float4 *ptr = a.accum + rpix;
@@ -552,7 +585,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         const unsigned long long wm = __ballot(want);
         if (wm == 0ull) return false;
         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u));
-        const int room = PARKED_MAX - nparked;
+        const int room = a.parkedMax - nparked;
         const bool fits = want && rank < room;
         if (fits) {
             ParkedResolve e;
@@ -625,11 +658,29 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         unsigned long long masks[4];
                         cull_spheres(sc, a.numSpheres, valid, to, td, masks);
                         bool tcont = false, tkeep = false; // tkeep: the path goes to the ring (it continues, or its resolve must wait)
+#ifdef PT_CARRY_LAST
+                        bool plastOk = false;
+                        float4 plast = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#endif
                         if (valid) {
                             if (0 < a.rayDepth)
                                 tcont = bounce_step_t<true, MATLDS>(sc, a.numSpheres, a.numCuboids, env, to, td, tthr, trad, tseed, masks PROF_DUMMY);
                             if (1 >= a.rayDepth) tcont = false;
                             tkeep = tcont;
+#ifdef PT_CARRY_LAST
+                            // imageLoad (compute.glsl:126) for the whole tile, all lanes together: 8 rows x 128 B = full lines, one memory
+                            // round trip per TILE instead of one per bounce iteration.  (After the first bounce: held across it, the four
+                            // registers spill.)  A plain load: a stale cached copy can only show an OLDER tag, and then the pixel takes the
+                            // coherent load of try_resolve when its path ends.
+                            plast = a.accum[tpix];
+                            {
+                                const float expected = tfj > 0 ? frame_tag(a.frame + tfj - 1) : a.chainTag;
+                                plastOk = !a.tagged || expected == 0.0f || plast.w == expected;
+                            }
+                            if (!tcont && plastOk) { // ended at its first bounce, previous frame already there: fold and store, no second load
+                                commit_resolve(tpix, tfj, v_add(V(0.0f, 0.0f, 0.0f), trad), V(plast.x, plast.y, plast.z));
+                            } else
+#endif
                             if (!tcont) { // the path ended at its first bounce: compute.glsl:125-129 right away
                                 v3 tirr = v_add(V(0.0f, 0.0f, 0.0f), trad);
                                 tkeep = !try_resolve(tpix, tfj, tirr, false);
@@ -649,6 +700,10 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                             e.rd[0] = td.x; e.rd[1] = td.y; e.rd[2] = td.z;
                             e.thr[0] = tthr.x; e.thr[1] = tthr.y; e.thr[2] = tthr.z;
                             e.rad[0] = trad.x; e.rad[1] = trad.y; e.rad[2] = trad.z;
+#ifdef PT_CARRY_LAST
+                            if (plastOk) e.bounce |= PATH_HAS_LAST;
+                            e.last[0] = plast.x; e.last[1] = plast.y; e.last[2] = plast.z;
+#endif
                             pring[slot] = e;
                         }
                         __builtin_amdgcn_wave_barrier(); // ring entries are read by other lanes of this wave below
@@ -699,7 +754,11 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                     PathEntry e = pring[avail - 1 - rank];
                     pix = e.pix;
                     bounce = e.bounce & 0xffff;
-                    fj = e.bounce >> 16;
+                    fj = (e.bounce >> 16) & 0x3fff;
+#ifdef PT_CARRY_LAST
+                    if (e.bounce & PATH_HAS_LAST) fj |= 0x4000;
+                    laneLast[0] = e.last[0]; laneLast[64] = e.last[1]; laneLast[128] = e.last[2];
+#endif
                     pending = false;
                     retries = 0;
                     seed = e.seed;
@@ -762,6 +821,12 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                             pending = (st.counters >> 25) & 1;
                             fj = (st.counters >> 26) & 0x3f;
                             retries = 0;
+#ifdef PT_CARRY_LAST
+                            if constexpr (SPP1) {
+                                if (st.counters & 1) fj |= 0x4000;
+                                laneLast[0] = st.irr[0]; laneLast[64] = st.irr[1]; laneLast[128] = st.irr[2];
+                            }
+#endif
                             seed = st.seed;
                             ro = V(st.ro[0], st.ro[1], st.ro[2]);
                             rd = V(st.rd[0], st.rd[1], st.rd[2]);
@@ -823,13 +888,19 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         PathState st;
                         st.pix = pix;
                         st.pxy = SPP1 ? 0 : (px | (py << 16));
-                        st.counters = (SPP1 ? 0 : (sample | ((needRay ? 1 : 0) << 24))) | (bounce << 12) | ((pending ? 1 : 0) << 25) | (fj << 26);
+                        st.counters = (SPP1 ? 0 : (sample | ((needRay ? 1 : 0) << 24))) | (bounce << 12) | ((pending ? 1 : 0) << 25) | ((fj & 0x3f) << 26);
+#ifdef PT_CARRY_LAST
+                        if (SPP1 && (fj & 0x4000)) st.counters |= 1; // (the sample field is unused with one sample per pixel)
+#endif
                         st.seed = seed;
                         st.ro[0] = ro.x; st.ro[1] = ro.y; st.ro[2] = ro.z;
                         st.rd[0] = rd.x; st.rd[1] = rd.y; st.rd[2] = rd.z;
                         st.thr[0] = throughput.x; st.thr[1] = throughput.y; st.thr[2] = throughput.z;
                         st.rad[0] = rad.x; st.rad[1] = rad.y; st.rad[2] = rad.z;
                         st.irr[0] = SPP1 ? 0.0f : irr.x; st.irr[1] = SPP1 ? 0.0f : irr.y; st.irr[2] = SPP1 ? 0.0f : irr.z;
+#ifdef PT_CARRY_LAST
+                        if constexpr (SPP1) { st.irr[0] = laneLast[0]; st.irr[1] = laneLast[64]; st.irr[2] = laneLast[128]; } // (irr is unused with one sample per pixel)
+#endif
                         st.pad = 0;
                         pool[base + rank] = st;
                     }
@@ -870,6 +941,13 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                 }
 #ifdef PT_PROFILE
                 prof_t = __builtin_readcyclecounter();
+#endif
+#ifdef PT_CARRY_LAST
+                if (pending && (fj & 0x4000)) { // the tile pass read the pixel (and saw the previous frame's tag): no load, cannot fail
+                    commit_resolve(pix, fj & 0x3fff, v_add(V(0.0f, 0.0f, 0.0f), rad), V(laneLast[0], laneLast[64], laneLast[128]));
+                    pix = -1;
+                    pending = false;
+                }
 #endif
                 if (pending) {
                     v3 firr = v_add(V(0.0f, 0.0f, 0.0f), rad);
@@ -1343,6 +1421,14 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         if (nwg > numChunks) nwg = numChunks;
         if (nwg < 1) nwg = 1;
         if (nwg > kStartedWords) a.startedFlags = nullptr; // (the roll call has kStartedWords words; the host then never chains on this launch)
+        // Parked resolves (pipelined spp = 1 launches): what a GPU that owns few tiles per frame needs (consecutive frames of a tile in
+        // flight together all the time: +20 % at a 1/8 share of 1080p) and a full image does not (+0.3 %).
+#ifdef PT_CARRY_LAST
+        a.parkedMax = (long long)tiles < 12000 ? 32 : 0; // (the lane slots of PT_CARRY_LAST take 3 KB of the workgroup's LDS budget)
+#else
+        a.parkedMax = PARKED_MAX;
+#endif
+        if (const char *pm = std::getenv("PT_PARKED_MAX")) a.parkedMax = std::atoi(pm) < 0 ? 0 : (std::atoi(pm) > PARKED_MAX ? PARKED_MAX : std::atoi(pm));
         const bool spp1 = a.spp == 1; // tile-pass kernels (the ring holds 60-byte paths instead of 40-byte primary rays)
         // spp > 1: the batch-pass kernel (every sample's first bounce coherent and culled), unless drain compaction is asked
         // for (single-launch frames of the A/B variants and of caller-owned streams keep the in-lane sample chain)
@@ -1373,8 +1459,8 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         a.contCapacity = park;
         a.contBatchMin = std::getenv("PT_PARK_MIN") ? std::atoi(std::getenv("PT_PARK_MIN")) : 40;
         const size_t queues = useBatchPass ? (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry))
-                              : (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) : sizeof(RingEntry)) + (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0) // no pool without drain compaction
-                                + (spp1 && a.tagged && a.drainCompaction == 0 ? (size_t)waves * PARKED_MAX * sizeof(ParkedResolve) : 0); // parked resolves of tagged launches
+                              : (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) + kLaneLastBytes : sizeof(RingEntry)) + (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0) // no pool without drain compaction
+                                + (spp1 && a.tagged && a.drainCompaction == 0 ? (size_t)waves * a.parkedMax * sizeof(ParkedResolve) : 0); // parked resolves of tagged launches
         // Large scenes: the generic bounce walks the sphere grid (ray_trace_t<GRID>); the grid rides in LDS next to the scene
         static const bool noGrid = std::getenv("PT_NO_SPHERE_GRID") != nullptr; // A/B runs
         const bool useGrid = a.grid != nullptr && a.gridBytes > 0 && !noGrid && !a.timeline;
@@ -1382,7 +1468,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         lds += (size_t)a.gridLdsBytes;
         size_t ldsTotal = lds + queues;
         // materials leave LDS when they would cost a resident workgroup (160 KB per CU; 64 B of static LDS per workgroup)
-        const size_t ldsPerCU = 160 * 1024, fixedLds = 64;
+        const size_t ldsPerCU = 160 * 1024, fixedLds = 1100; // (static LDS of the persistent kernels: queue, drain control, frame weights)
         const size_t ldsLean = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, false, a.gridLdsBytes) + queues;
         size_t wgFull = ldsPerCU / (ldsTotal + fixedLds), wgLean = ldsPerCU / (ldsLean + fixedLds);
         if (wgFull > (size_t)blocksPerCU) wgFull = (size_t)blocksPerCU;

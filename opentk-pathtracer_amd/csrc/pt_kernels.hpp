@@ -46,6 +46,7 @@ struct FrameArgs {
                             // frame of the previous, possibly still running launch); 0 = no such predecessor
     int contCapacity;       // set by the launch (spp > 1 batch-pass kernel): parked continuations per wavefront
     int contBatchMin;       // ... and how many of them make a batch pass worth running
+    int parkedMax;          // set by the launch (pipelined spp = 1 launches): parked resolves per wavefront (0 = waiting results keep their lanes)
     int materialsInLds;     // set by the launch: 1 = the 64-byte materials are staged in LDS, 0 = read from `objects` (large scenes)
     unsigned long long *timeline; // optional (tuning): per wavefront {start, queue exhausted, end, iterations} timestamps
     // Launch chaining: every workgroup of a tagged launch stores launchSeq into startedFlags[blockIdx.x] (host-visible memory)

@@ -6,7 +6,7 @@ R=/root/repo
 OUT=$R/gpurun_out/pmcq_$1
 mkdir -p $OUT
 cd /tmp
-BENCH="python $R/bench.py --steps 59 --warmup 5 --clock-warmup-ms 0 --no-cpu-baseline ${@:2}"
+BENCH="python $R/bench.py --steps 59 --warmup 5 --clock-warmup-ms 0 --steady-ms 0 --no-cpu-baseline ${@:2}"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq -o sq -- $BENCH > $OUT/sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_BRANCH --output-format csv -d $OUT/sq2 -o sq2 -- $BENCH > $OUT/sq2.log 2>&1
 python - <<PY

@@ -20,8 +20,8 @@ cd /tmp
 STEPS=${PROFILE_STEPS:-640}
 WARM=${PROFILE_WARMUP:-320}
 echo $((STEPS + WARM)) > $OUT/frames.txt
-BENCH="python $R/bench.py --steps $STEPS --warmup $WARM --clock-warmup-ms 0 --no-cpu-baseline ${@:2}"
-CAL="python $R/bench.py --steps $STEPS --warmup $WARM --clock-warmup-ms 0 --no-cpu-baseline --depth 0 ${@:2}"
+BENCH="python $R/bench.py --steps $STEPS --warmup $WARM --clock-warmup-ms 0 --steady-ms 0 --no-cpu-baseline ${@:2}"
+CAL="python $R/bench.py --steps $STEPS --warmup $WARM --clock-warmup-ms 0 --steady-ms 0 --no-cpu-baseline --depth 0 ${@:2}"
 run() { name=$1; opts=$2; cmd=$3; rocprofv3 --kernel-trace $opts --output-format csv -d $OUT/$name -o $name -- $cmd > $OUT/$name.log 2>&1; }
 run stats "--stats" "$BENCH"
 run fetch "--pmc FETCH_SIZE" "$BENCH"

@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/traffic_$TAG
 mkdir -p $OUT
 cd /tmp
 STEPS=${TRAFFIC_STEPS:-384}
-BENCH="python $R/bench.py --steps $STEPS --warmup 192 --no-cpu-baseline --clock-warmup-ms 0 ${@:2}"
+BENCH="python $R/bench.py --steps $STEPS --warmup 192 --no-cpu-baseline --clock-warmup-ms 0 --steady-ms 0 ${@:2}"
 export TRAFFIC_TOTAL_FRAMES=$((STEPS + 192))
 run() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $OUT/$1 -o $1 -- $BENCH > $OUT/$1.log 2>&1; }
 run rd "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
