@@ -4,6 +4,8 @@ frame count, batch size and (round 2) group handles over 1-3 parts; every image 
 FUZZ_FOCUS=pipelining: tiny images, many frames per launch.  FUZZ_FOCUS=grid: 64-256 spheres at 1 spp (the sphere grid of large
 scenes): planar / clustered / tiny / far-from-origin layouts, duplicate and degenerate spheres, cameras inside spheres and far away.
 FUZZ_BIAS=group_spp (with FUZZ_FOCUS=pipelining): always several samples per pixel and a group handle.
+MI355PT_LIB=opentk-pathtracer_amd/libmi355pt_audit.so runs it on the audit build: the kernels' own hand-over audit is read after every case.
+A mismatch keeps its evidence under gpurun_out/fuzz_failures/ (both reads, both oracle runs, all inputs).
 python tools/fuzz_parity.py [cases] [seed]"""
 import os, sys, time
 import numpy as np
@@ -75,6 +77,19 @@ def rand_scene():
         c = (rng.uniform([-18, -11, -20], [18, 11, 0]).astype(F) + off).astype(F)
         sc.cuboids.append(S.Cuboid(c, rng.uniform(0.2, 6.0, 3).astype(F), i, rand_material()))
     return sc
+
+def audit_violations(pt):
+    """> 0 only with the -DPT_AUDIT build of the library (MI355PT_LIB=.../libmi355pt_audit.so): its kernels mirror every pixel
+    read-modify-write with a device-scope atomic side word and log resolves that ran out of order or on a stale colour."""
+    import ctypes as C
+    fn = getattr(pt._lib, "pt_debug_audit_read", None)
+    if fn is None:
+        return 0
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.c_int]
+    fn.restype = C.c_int
+    n = fn(pt._h, None, 0)
+    return n if n > 0 else 0
+
 
 bad = 0
 grids_used = 0
@@ -155,11 +170,27 @@ for case in range(cases):
             want = oracle.render(W, H, basic, sc.ubo_bytes(), env, num_spheres=sc.num_spheres, num_cuboids=sc.num_cuboids, ray_depth=depth,
                                  spp=spp, focal_length=focal, aperture=aperture, num_frames=frames)
         same = (got.view(np.uint32) == want.view(np.uint32)).all(-1)
+        nviol = audit_violations(pt)
+        if nviol:
+            print(f"case {case}: {nviol} hand-over AUDIT violation(s) reported by the kernels: {desc}", flush=True)
+            bad += 1
         if not same.all():
             bad += 1
             ys, xs = np.nonzero(~same)
             print(f"case {case}" + (f" (repetition {rep})" if REPEAT > 1 else "") + f": {int((~same).sum())}/{same.size} pixels differ: {desc}; first at x={xs[0]} y={ys[0]}: "
                   f"got {got[ys[0], xs[0]]} want {want[ys[0], xs[0]]}", flush=True)
+            # keep the evidence (round 2 lost it): what was read, a second read of the same image (a transient read-back error looks
+            # different from a wrong accumulation), the oracle's image, the oracle's image computed AGAIN single-threaded, all inputs
+            again = pt.Result
+            want1 = oracle.render(W, H, basic, sc.ubo_bytes(), env, num_spheres=sc.num_spheres, num_cuboids=sc.num_cuboids, ray_depth=depth,
+                                  spp=spp, focal_length=focal, aperture=aperture, num_frames=frames, threads=1)
+            os.makedirs("gpurun_out/fuzz_failures", exist_ok=True)
+            path = f"gpurun_out/fuzz_failures/seed{sys.argv[2] if len(sys.argv) > 2 else 1}_case{case}_rep{rep}.npz"
+            np.savez_compressed(path, got=got, got_second_read=again, want=want, want_single_thread=want1, basic=np.frombuffer(basic, np.uint8),
+                                objects=np.frombuffer(sc.ubo_bytes(), np.uint8), env=env, desc=np.array(desc))
+            print(f"    second read identical to the first: {bool((again.view(np.uint32) == got.view(np.uint32)).all())}; oracle single-threaded identical "
+                  f"to multi-threaded: {bool((want1.view(np.uint32) == want.view(np.uint32)).all())}; second read equals the oracle: "
+                  f"{bool((again.view(np.uint32) == want.view(np.uint32)).all())}; saved {path}", flush=True)
     pt.Dispose()
 print(f"{cases} cases, {bad} with differences, {time.time() - t0:.1f} s" + (f", {grids_used} of them walked a sphere grid" if GRID else ""))
 sys.exit(1 if bad else 0)
