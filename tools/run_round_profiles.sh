@@ -21,9 +21,10 @@ export PROFILE_NO_CAL=1
 prof ${RND}_perframe default_1920x1080_d8_spp1_atmosphere256_g1_fb1 ${RND}_default --frame-batch 1
 prof ${RND}_C3 stress256_1920x1080_d8_spp1_atmosphere256_g1 ${RND}_default --config C3
 prof ${RND}_C5 glass_1920x1080_d32_spp1_atmosphere256_g1 ${RND}_default --config C5
-PROFILE_STEPS=192 PROFILE_WARMUP=64 prof ${RND}_spp4 default_1920x1080_d8_spp4_atmosphere256_g1 ${RND}_default --spp 4
-PROFILE_STEPS=192 PROFILE_WARMUP=64 prof ${RND}_tilewave default_1920x1080_d8_spp1_atmosphere256_g1_variant1 ${RND}_default --variant 1
-unset PROFILE_NO_CAL
+export PROFILE_STEPS=192 PROFILE_WARMUP=64
+prof ${RND}_spp4 default_1920x1080_d8_spp4_atmosphere256_g1 ${RND}_default --spp 4
+prof ${RND}_tilewave default_1920x1080_d8_spp1_atmosphere256_g1_variant1 ${RND}_default --variant 1
+unset PROFILE_NO_CAL PROFILE_STEPS PROFILE_WARMUP
 bash tools/bench_configs.sh > gpurun_out/$RND/bench_configs.log 2>&1; cp gpurun_out/bench_configs.jsonl gpurun_out/$RND/
 python bench.py --steps 20 --warmup 5 > gpurun_out/$RND/driver_command_bench.json 2> gpurun_out/$RND/driver_command_bench.err
 python tools/emulate_strong.py gpurun_out/$RND/emulate_strong.json > gpurun_out/$RND/emulate_strong.log 2>&1
