@@ -142,7 +142,11 @@ PT_API int pt_set_environment(pt_handle h, int face_size, int format, const void
  * pt_set_frame_batch frames).  A frame is only held back while earlier frames of this handle are still running on the GPU
  * (so deferral never idles the device); the launch happens when the GPU has drained, when the batch is full, or at the next call of any other entry point
  * (uploads and parameter changes apply to LATER frames only, exactly as with one launch per call; every read,
- * pt_synchronize and pt_timer_* first launch what is pending).  The image is bit-identical either way. */
+ * pt_synchronize and pt_timer_* first launch what is pending).  The image is bit-identical either way.
+ * Back-pressure: consecutive launches overlap on two internal streams (the second moves into the wavefront slots the first one's
+ * drain frees), which needs the first one resident; a host that is more than two launches ahead of the GPU is therefore held in
+ * pt_render until the launch before last has left the machine (bounded; like a full command queue).  A single frame is launched
+ * that way too whenever the GPU still runs the previous one. */
 PT_API int pt_render(pt_handle h, int *out_total_samples);
 /* Largest number of frames one launch may pipeline (1..64, default 64).  1 = every pt_render launches at once (lowest
  * latency for a host that never calls anything else between frames, e.g. one that presents through interop). */
@@ -169,7 +173,10 @@ PT_API int pt_postprocess_device(pt_handle h, void **out_device_ptr, size_t *out
  * pt_present_wait blocks until the slot's copy has landed and returns the pinned image (tightly packed rows, row 0 =
  * bottom, valid until the next pt_present_rgba8_async on the same slot or pt_set_size/pt_destroy) and the frame index
  * (= number of accumulated frames) it shows.  Typical loop: render; present_async(f % 2); present_wait((f + 1) % 2) ->
- * upload to the GL texture -> swap.  Works on group handles (the gather of the RGBA8 rows happens on the copy stream). */
+ * upload to the GL texture -> swap.  Works on group handles (the gather of the RGBA8 rows happens on the copy stream).
+ * On a single-GPU handle the presented frame comes from a SNAPSHOT that the integrator launch writes while it resolves that
+ * frame's pixels, so the next pt_render does not wait for the tone map; once a host is seen to present every frame, pt_render
+ * launches each frame with the snapshot attached (the image is unchanged; three internal buffers of width x rows x 16 bytes). */
 PT_API int pt_present_rgba8_async(pt_handle h, int slot);
 PT_API int pt_present_wait(pt_handle h, int slot, const uint8_t **out_host_rgba8, size_t *out_row_pitch_bytes,
                            int *out_frame_index);
