@@ -364,6 +364,8 @@ struct ParkedResolve {
     float irr[3];
 };
 constexpr int PARKED_MAX = 64; // upper bound; FrameArgs::parkedMax is what a launch uses
+// LDS bytes of the per-launch table of running-mean weights (spp = 1 persistent kernels), 16-byte aligned
+__host__ __device__ constexpr size_t frame_weight_bytes(int batchFrames) { return (size_t)((batchFrames + 63) & ~63) * 4; }
 
 struct BlockQueue {            // one per workgroup, in static LDS
     unsigned long long pair;   // (end << 32) | cursor : absolute tile indices of the current chunk
@@ -458,9 +460,19 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     __shared__ __attribute__((aligned(16))) DrainControl drain; // 32 B
     const int numTilesFrame = a.tilesX * a.tilesY;
     const int numTiles = numTilesFrame * a.batchFrames;         // (frame, tile) pairs, frame-major
-    __shared__ float frameWeight[SPP1 ? MAX_BATCH_FRAMES : 1];  // 1 / (frame + j + 1): running-mean weight of the batch's frame j
-    if (SPP1 && (int)threadIdx.x < a.batchFrames && threadIdx.x < MAX_BATCH_FRAMES)
-        frameWeight[threadIdx.x] = f_div_ieee(1.0f, (float)(a.frame + (int)threadIdx.x + 1));
+    // 1 / (frame + j + 1): running-mean weight of the batch's frame j.  In DYNAMIC LDS between the scene and the rings, sized by the
+    // launch (64 entries; 256 only for the long batches of small shares): as a static 1 KB table it cost the 256-sphere scene its
+    // sixth workgroup per CU (27.9 instead of 27.2 KB)
+    // (the table's address is re-derived from the kernarg segment where it is read — see cold_args — instead of living in a register
+    // across the bounce loop)
+    auto frame_weights = [&]() -> float * {
+        ColdArgs ca = cold_args();
+        return (float *)((char *)g_lds + scene_lds_bytes(ca->numSpheres, ca->numCuboids, ca->envFormat, ca->materialsInLds != 0, ca->gridLdsBytes));
+    };
+    if (SPP1) {
+        float *fw = frame_weights();
+        for (int j = (int)threadIdx.x; j < a.batchFrames; j += (int)blockDim.x) fw[j] = f_div_ieee(1.0f, (float)(a.frame + j + 1));
+    }
     if (threadIdx.x == 0) {
         // One frame per launch: the workgroup's first chunk is static (chunk index = workgroup index).  A pipelined batch
         // hands out EVERY chunk through the global counter instead: frames depend on each other per pixel, and a workgroup
@@ -486,7 +498,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // the ring lives behind the staged scene in dynamic LDS
     constexpr int ENTRY_BYTES = SPP1 ? (int)sizeof(PathEntry) : (int)sizeof(RingEntry);
-    char *ringBase = (char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, a.materialsInLds != 0, a.gridLdsBytes);
+    char *ringBase = (char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, a.materialsInLds != 0, a.gridLdsBytes) +
+                     (SPP1 ? frame_weight_bytes(a.batchFrames) : 0);
     RingEntry *ring = (RingEntry *)(ringBase + wave * 64 * ENTRY_BYTES);  // !SPP1: primary rays
     PathEntry *pring = (PathEntry *)(ringBase + wave * 64 * ENTRY_BYTES); //  SPP1: paths after their first bounce
 #ifdef PT_CARRY_LAST
@@ -534,7 +547,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         ColdArgs ca = cold_args();
         float w;
         if constexpr (SPP1) { // irradiance / 1 is exact (x * 1.0f == x bit for bit): skipped; weight from the per-batch table
-            w = frameWeight[rfj];
+            w = frame_weights()[rfj];
         } else {
             rirr = v_scale(rirr, f_div_ieee(1.0f, (float)ca->spp));
             w = f_div_ieee(1.0f, (float)(ca->frame + rfj + 1));
@@ -1459,7 +1472,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         a.contCapacity = park;
         a.contBatchMin = std::getenv("PT_PARK_MIN") ? std::atoi(std::getenv("PT_PARK_MIN")) : 40;
         const size_t queues = useBatchPass ? (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry))
-                              : (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) + kLaneLastBytes : sizeof(RingEntry)) + (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0) // no pool without drain compaction
+                              : (spp1 ? frame_weight_bytes(a.batchFrames) : 0) + (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) + kLaneLastBytes : sizeof(RingEntry)) + (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0) // no pool without drain compaction
                                 + (spp1 && a.tagged && a.drainCompaction == 0 ? (size_t)waves * a.parkedMax * sizeof(ParkedResolve) : 0); // parked resolves of tagged launches
         // Large scenes: the generic bounce walks the sphere grid (ray_trace_t<GRID>); the grid rides in LDS next to the scene
         static const bool noGrid = std::getenv("PT_NO_SPHERE_GRID") != nullptr; // A/B runs
@@ -1468,7 +1481,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         lds += (size_t)a.gridLdsBytes;
         size_t ldsTotal = lds + queues;
         // materials leave LDS when they would cost a resident workgroup (160 KB per CU; 64 B of static LDS per workgroup)
-        const size_t ldsPerCU = 160 * 1024, fixedLds = 1100; // (static LDS of the persistent kernels: queue, drain control, frame weights)
+        const size_t ldsPerCU = 160 * 1024, fixedLds = 64; // (static LDS of the persistent kernels: queue, drain control)
         const size_t ldsLean = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, false, a.gridLdsBytes) + queues;
         size_t wgFull = ldsPerCU / (ldsTotal + fixedLds), wgLean = ldsPerCU / (ldsLean + fixedLds);
         if (wgFull > (size_t)blocksPerCU) wgFull = (size_t)blocksPerCU;
