@@ -467,9 +467,11 @@ def main():
                                  "step (= frame) from HIP events on the library's streams. The default kernel pipelines up to "
                                  "frames_per_launch consecutive frames inside ONE launch (achieved = algorithmic_bytes_per_launch "
                                  "/ (frames_per_launch x kernel_ms)). Consecutive launches OVERLAP pairwise on two streams (launch "
-                                 "chaining: a launch starts in the wavefront slots its predecessor's drain frees), so rocprofv3's "
-                                 "per-launch durations add up to more than the elapsed time: profiles/<round>/*_summary.json report "
-                                 "their sum AND the union of the launch intervals per frame; the union is what kernel_ms measures. "
+                                 "chaining: a launch is enqueued as soon as its predecessor is resident and starts in the wavefront slots that "
+                                 "one's drain frees; rocprofv3 stamps a launch's start when the command processor begins the dispatch, so its "
+                                 "duration includes the wait beside the predecessor), so rocprofv3's per-launch durations add up to ~2x the "
+                                 "elapsed time: profiles/<round>/*_summary.json report their sum AND the union of the launch intervals per "
+                                 "frame; the union is what kernel_ms measures. "
                                  "--frame-batch 1 launches every frame on its own (2 overlapping row-stripe launches). "
                                  "The path is fp32-VALU bound, see `valu_issue`"},
             "present_ms": round(m["present_ms"], 3),

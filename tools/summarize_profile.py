@@ -87,6 +87,10 @@ summary = {
     "tag": tag, "workload": key, "csrc_hash": CSRC_HASH, "frames_profiled": frames,
     "kernel_ns_per_frame_rocprof_union_of_launch_intervals": (union_ns / frames if union_ns and frames else None),
     "launch_overlap_factor": (total_ns / union_ns if union_ns else None),
+    "note_sum_vs_union": "since round 3 every pipelined launch is enqueued as soon as its predecessor is resident (back-pressure chaining) and waits beside "
+                         "it for the wavefront slots its drain frees; rocprofv3's start timestamp is the moment the command processor begins the dispatch, so "
+                         "a launch's duration includes that wait and the SUM of durations is ~2x the elapsed time: the UNION of the launch intervals / frames "
+                         "is the GPU time per frame (it agrees with bench.py's HIP-event kernel_ms)",
     "integrator_launches": calls, "kernels": [{"name": r["Name"][:96], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])} for r in kstats],
     "kernel_ns_per_frame_rocprof_sum_of_launch_durations": total_ns / frames if frames else None,
     "frames_per_launch_mean": frames / calls if calls else None,
