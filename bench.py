@@ -261,6 +261,43 @@ def main():
     csrc_hash = pkg.native.csrc_hash()
     frames_per_launch = args.frame_batch if args.variant == 0 else 1
 
+    def group_handle_check(W, H, basic, warmup, steps, full):
+        """The same W + K frames through ONE in-process pt_create_multi handle over all devices (peer copies over xGMI), compared bit for
+        bit with the RCCL-gathered image `full` of the one-process-per-GPU path."""
+        frames = warmup + steps
+        devs = [0] * world if args.share_gpu else list(range(world))  # (--share-gpu: the same code on one device)
+        gp = pkg.PathTracer(None, W, H, depth, args.spp, 20.0, 0.14, devices=devs)
+        gp.SetVariant(args.variant)
+        gp.SetFrameBatch(args.frame_batch)
+        if env_name == "atmosphere256":
+            gp.EnvironmentMap = pkg.AtmosphericScatterer(256, pkg.camera.atmospheric_data_ubo(), pkg.camera.atmosphere_light_pos(0.5), gp)
+        elif env_name == "sky2048":
+            gp.EnvironmentMap = pkg.envmap.synthetic_sky_srgb8(2048)
+        else:
+            gp.EnvironmentMap = pkg.envmap.synthetic_sky_rgba32f(64)
+        gp.UploadScene(scene)
+        gp.UploadBasicData(basic)
+        for _ in range(warmup):
+            gp.Render()
+        gp.Synchronize()
+        tg = time.perf_counter()
+        gp.TimerBegin()
+        for _ in range(steps):
+            gp.Render()
+        gk = gp.TimerEnd()
+        gp.Synchronize()
+        g_el = time.perf_counter() - tg
+        tr = time.perf_counter()
+        gimg = gp.Result  # peer copies to device 0 + one device-to-host copy
+        g_read = (time.perf_counter() - tr) * 1e3
+        same = bool(np.array_equal(gimg.view(np.uint32), full.cpu().numpy().view(np.uint32))) if full is not None else None
+        group = {"devices": devs, "frames": frames, "value": round(W * H * args.spp * steps / g_el / 1e6, 2), "unit": "Msamples/s",
+                 "ms_per_step": round(g_el * 1e3 / steps, 5), "kernel_ms_slowest_device": round(gk / steps, 5),
+                 "read_result_ms": round(g_read, 3), "equals_rccl_gather_bit_for_bit": same,
+                 "note": "ONE process, one pt_create_multi handle over all devices, run after the ranks' measurement while they idle"}
+        gp.Dispose()
+        return group
+
     def measure(W, H, steps, warmup, clock_warmup_ms, steady_ms=0.0, group_check=False):
         """One workload: create the renderer for this rank's rows of the W x H image, warm up, time `steps` Render() calls
         (barrier + synchronize on both sides, max over ranks), gather once.  -> dict (rank 0) with the raw measurements."""
@@ -367,40 +404,12 @@ def main():
         # ---- N > 1: the same frames through ONE in-process group handle over the N devices (pt_create_multi: what the reference's
         # single-process host would call; gather by hipMemcpyPeerAsync over xGMI), compared bit for bit with the RCCL gather
         group = None
-        if group_check and world > 1 and rank == 0 and not args.share_gpu and have >= world:
-            frames = warmup + steps
-            gp = pkg.PathTracer(None, W, H, depth, args.spp, 20.0, 0.14, devices=list(range(world)))
-            gp.SetVariant(args.variant)
-            gp.SetFrameBatch(args.frame_batch)
-            if env_name == "atmosphere256":
-                gp.EnvironmentMap = pkg.AtmosphericScatterer(256, pkg.camera.atmospheric_data_ubo(), pkg.camera.atmosphere_light_pos(0.5), gp)
-            elif env_name == "sky2048":
-                gp.EnvironmentMap = pkg.envmap.synthetic_sky_srgb8(2048)
-            else:
-                gp.EnvironmentMap = pkg.envmap.synthetic_sky_rgba32f(64)
-            gp.UploadScene(scene)
-            gp.UploadBasicData(basic)
-            for _ in range(warmup):
-                gp.Render()
-            gp.Synchronize()
-            tg = time.perf_counter()
-            gp.TimerBegin()
-            for _ in range(steps):
-                gp.Render()
-            gk = gp.TimerEnd()
-            gp.Synchronize()
-            g_el = time.perf_counter() - tg
-            tr = time.perf_counter()
-            gimg = gp.Result  # peer copies to device 0 + one device-to-host copy
-            g_read = (time.perf_counter() - tr) * 1e3
-            same = bool(np.array_equal(gimg.view(np.uint32), full.cpu().numpy().view(np.uint32))) if full is not None else None
-            group = {"devices": list(range(world)), "frames": frames, "value": round(W * H * args.spp * steps / g_el / 1e6, 2), "unit": "Msamples/s",
-                     "ms_per_step": round(g_el * 1e3 / steps, 5), "kernel_ms_slowest_device": round(gk / steps, 5),
-                     "read_result_ms": round(g_read, 3), "equals_rccl_gather_bit_for_bit": same,
-                     "note": "ONE process, one pt_create_multi handle over all devices, run after the ranks' measurement while they idle"}
-            gp.Dispose()
-            if same is False:
-                raise SystemExit("bench.py: the in-process group handle's image differs from the RCCL-gathered image")
+        if group_check and world > 1 and rank == 0 and (have >= world or args.share_gpu):
+            # (never fatal: the ranks' measurement above is the metric; a problem on this second path is REPORTED in the line)
+            try:
+                group = group_handle_check(W, H, basic, warmup, steps, full)
+            except Exception as e:  # noqa: BLE001
+                group = {"devices": list(range(world)), "error": f"{type(e).__name__}: {e}", "equals_rccl_gather_bit_for_bit": None}
         if world > 1:
             dist.barrier()
         res = None

@@ -219,3 +219,5 @@ def test_bench_self_spawns_ranks_and_refuses_missing_devices(pkg, native_lib):
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["ranks"] == 2 and line["n_gpus"] == 1 and line["checks"]["finite"] and line["steady"]["steps"] >= 512
+    # the in-process group handle (here: device 0 twice) rendered the same frames and equals the gathered image of the two ranks
+    assert line["in_process_group"].get("error") is None and line["in_process_group"]["equals_rccl_gather_bit_for_bit"] is True
