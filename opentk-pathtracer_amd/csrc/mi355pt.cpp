@@ -287,6 +287,10 @@ PT_API int pt_destroy(pt_handle h)
     if (h->isGroup()) return ptimpl::group_destroy(h);
     h->pendingFrames = 0; // frames nobody can observe any more are not worth launching
     (void)hipSetDevice(h->device);
+    // (launches may still write present snapshots, tone maps read them: every stream of the handle is drained before they are freed)
+    for (int j = 0; j < ptimpl::kMaxStripes; j++)
+        if (h->stripeStream[j]) (void)hipStreamSynchronize(h->stripeStream[j]);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copyStream) (void)hipStreamSynchronize(h->copyStream);
     for (int k = 0; k < pt_renderer::kSnapshots; k++) {
         if (h->snapRead[k]) (void)hipEventDestroy(h->snapRead[k]);
@@ -847,6 +851,10 @@ int flush_with_snapshot(pt_handle h)
     const int k = h->snapNext;
     const size_t pixels = h->tilePixels();
     if (pixels > h->snapCapacity[k]) {
+        // (a launch queued earlier may still write the old buffer, a tone map may still read it: drain the handle's streams first)
+        for (int j = 0; j < ptimpl::kMaxStripes; j++)
+            if (h->stripeStream[j]) PT_HIP(h, hipStreamSynchronize(h->stripeStream[j]));
+        PT_HIP(h, hipStreamSynchronize(h->stream));
         if (h->snapReadPending[k]) PT_HIP(h, hipEventSynchronize(h->snapRead[k]));
         h->snapReadPending[k] = false;
         if (h->dSnap[k]) PT_HIP(h, hipFree(h->dSnap[k]));
@@ -915,10 +923,10 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     h->pendingFrames++;
     h->frame++; // PathTracer.cs:117 post-increment
     if (out_total_samples) *out_total_samples = h->frame * h->spp; // PathTracer.cs:112
-    // Round 3: a host that presents every frame through pt_present_rgba8_async gets this frame launched BY that present call (a few
-    // microseconds from now), because the launch then also writes the present snapshot while it resolves its pixels
-    // (FrameArgs::snapshot) and the tone map never stands between two frames.  Any other call launches it as usual.
-    // (launched NOW, not by the present: a host that first waits for a present slot and then presents must find the GPU busy)
+    // Round 3: a host that presents every frame through pt_present_rgba8_async gets this frame launched with a present snapshot
+    // attached: the launch stores the frame's pixels a second time while it resolves them (FrameArgs::snapshot), the present that
+    // follows tone-maps that copy, and the tone map never stands between two frames.  (Launched NOW, not by the present: a host
+    // that first waits for a present slot and then presents must find the GPU busy.  If no present follows, the copy is ignored.)
     if (presentsEveryFrame && (h->variant == 0 || h->variant >= 10) && !h->externalStream() && h->dTimeline == nullptr)
         return ptimpl::flush_with_snapshot(h);
     // Frames are only held back while the GPU still has integrator work of this handle in flight: deferring can then
