@@ -266,3 +266,21 @@ def test_screenshot_png_is_flipped_like_the_reference(pkg, tmp_path):
     assert rgb.shape == (4, 9, 3)
     assert np.array_equal(rgb, t.Present()[::-1, :, :3])
     assert np.array_equal(ck.decode_png_rgb8(ck.encode_png(t.Present(), flip_vertically=False)), t.Present()[..., :3])
+
+
+def test_bench_refuses_to_report_fewer_gpus_than_asked(tmp_path):
+    """`python bench.py --gpus N` with no torchrun environment must never degrade to a smaller run silently (round 2 did): without N HIP
+    devices it exits non-zero with a message and prints no JSON line.  (This container has no GPU at all: N = 2 and N = 1 both refuse.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for n in ("2", "1"):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", n, "--steps", "4", "--warmup", "1"], capture_output=True, text=True,
+                           timeout=300, env=env)
+        import ctypes
+        have = ctypes.CDLL(os.path.join(root, "opentk-pathtracer_amd", "libmi355pt.so")).pt_device_count()
+        if have >= int(n):
+            continue  # (a GPU box: nothing to refuse)
+        assert p.returncode != 0 and "refusing" in (p.stdout + p.stderr), p.stderr[-500:]
+        assert not any(line.startswith("{") for line in p.stdout.splitlines())
