@@ -123,3 +123,17 @@ def test_contract_reciprocal_root_accuracy(oracle):
     assert sp[0] == 0.0 and sp[1] == 1.0 and sp[2] == 2.0 and not np.isfinite(sp[3:]).any()
     assert np.isinf(oracle.rcp(np.array([0.0], np.float32)))[0] and np.isinf(oracle.rsqrt(np.array([0.0], np.float32)))[0]
     assert np.isnan(oracle.rsqrt(np.array([-1.0], np.float32)))[0]
+
+
+def test_thread_count_never_changes_the_image(oracle):
+    """The row-parallel driver (oracle/pt_oracle.c, pto_render_frame) must render every row exactly once whatever thread count is
+    asked for — more threads than rows (256 on the GPU box for an 8-row fuzz image), one thread, an odd count — and a worker that
+    cannot be started must not leave its rows unrendered (round 3: thread creation is checked, the caller renders those rows)."""
+    import numpy as np
+    import configs
+    w = configs.Workload("threads", "default", 24, 8, 4, "sky_f32_32", frames=3)
+    sc, basic, objs, env, kw = configs.inputs(w)
+    ref = oracle.render(w.width, w.height, basic, objs, env, num_frames=w.frames, threads=1, **kw)
+    for threads in (2, 3, 8, 64, 256, 1000):
+        img = oracle.render(w.width, w.height, basic, objs, env, num_frames=w.frames, threads=threads, **kw)
+        assert (img.view(np.uint32) == ref.view(np.uint32)).all(), threads

@@ -159,3 +159,20 @@ def test_set_rule_equals_in_order_loop_for_any_visiting_order():
                 if j > L and (t1[j] < gT or (t1[j] == gT and gw != L and j < gw)):
                     gT, gw = t1[j], j
         assert (gw, gT) == (winner, T), (trial, winner, T, gw, gT)
+
+
+def test_grid_walk_cost_model_runs_and_orders_the_control_structures():
+    """tools/grid_walk_model.py (the numbers behind DESIGN.md section 3.5 / 9: why the lock-step walk was not replaced by a flattened
+    state machine or a per-phase job pool) stays runnable on the library's own grid builder, and its ordering holds: a walk loop that
+    never drains < pooled refill < lock-step rounds < flattened state machine, all above the ideal."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "grid_walk_model.py"), "6400", "3"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-1500:]
+    num = lambda label: float(re.search(re.escape(label) + r"\s+(\d+)", p.stdout).group(1))
+    ideal, lock, flat, cont = num("ideal (all lanes busy)"), num("lock-step rounds (today)"), num("flattened per-lane state machine"), num("continuous refill (no phase end)")
+    pool64 = num("refill from a pool of 64 + 64 rays")
+    assert ideal < cont < pool64 < lock < flat, p.stdout
