@@ -290,6 +290,9 @@ static rgb env_texel_wrapped(const Ctx *c, int face, int ix, int iy)
 
 static rgb sample_env(const Ctx *c, v3 d)
 {
+#ifdef PT_ORACLE_MARK_NAN_ENV /* diagnostic build only (oracle/Makefile): flag the paths that end in texture(env, NaN direction) */
+    if (d.x != d.x || d.y != d.y || d.z != d.z) { rgb mark = { 1000.0f, 1000.0f, 1000.0f }; return mark; }
+#endif
     int S = c->envSize, face;
     float sc, tc, ma;
     dir_to_face(d.x, d.y, d.z, &face, &sc, &tc, &ma);

@@ -15,12 +15,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "libpt_oracle.so")
 LIB_TRUEDIV_PATH = os.path.join(HERE, "_build", "libpt_oracle_truediv.so")
 LIB_EXACT_PATH = os.path.join(HERE, "_build", "libpt_oracle_exact.so")  # fidelity study: IEEE 1/x, sqrt, 1/sqrt, a/b
+LIB_NANMARK_PATH = os.path.join(HERE, "_build", "libpt_oracle_nanmark.so")  # diagnostic: env lookups with a NaN direction return 1000
 
 
 def build(force: bool = False) -> None:
     src = os.path.join(HERE, "pt_oracle.c")
-    stale = (not os.path.exists(LIB_PATH) or not os.path.exists(LIB_TRUEDIV_PATH) or not os.path.exists(LIB_EXACT_PATH)
-             or min(os.path.getmtime(p) for p in (LIB_PATH, LIB_TRUEDIV_PATH, LIB_EXACT_PATH)) < os.path.getmtime(src))
+    libs = (LIB_PATH, LIB_TRUEDIV_PATH, LIB_EXACT_PATH, LIB_NANMARK_PATH)
+    stale = not all(os.path.exists(p) for p in libs) or min(os.path.getmtime(p) for p in libs) < os.path.getmtime(src)
     if force or stale:
         subprocess.run(["make", "-C", HERE, "-B" if force else "-s", "all"], check=True, capture_output=True)
 
@@ -39,9 +40,9 @@ def _ptr(a, t=_fp):
 
 
 class Oracle:
-    def __init__(self, true_division: bool = False, exact: bool = False):
+    def __init__(self, true_division: bool = False, exact: bool = False, mark_nan_env: bool = False):
         build()
-        self.lib = C.CDLL(LIB_EXACT_PATH if exact else (LIB_TRUEDIV_PATH if true_division else LIB_PATH))
+        self.lib = C.CDLL(LIB_NANMARK_PATH if mark_nan_env else LIB_EXACT_PATH if exact else (LIB_TRUEDIV_PATH if true_division else LIB_PATH))
         L = self.lib
         L.pto_render_frame.restype = C.c_int
         L.pto_render_frame.argtypes = [C.POINTER(PtoParams), _fp, _fp, C.c_void_p, _fp, C.c_int, C.c_int, C.c_int,

@@ -61,3 +61,36 @@ def test_oracle_vs_fresh_reference_run_on_unseen_inputs(oracle, pkg, seed):
     assert ok.mean() >= tol.PIXEL_FRACTION, f"seed {seed}: {100 * ok.mean():.2f}% within tolerance"
     fin = np.isfinite(r).all(-1) & np.isfinite(o).all(-1)
     assert abs(r[fin].mean() - o[fin].mean()) <= 5 * tol.MEAN_REL_TOL * abs(r[fin].mean())
+
+
+def test_edge_scene_differences_are_nan_direction_environment_lookups():
+    """The one scene whose accumulation does NOT converge onto the reference's within its sampling error (max |z| 13, image mean off by
+    6e-4 after 4,096 frames) is the quirk scene: a glass cuboid and a camera-containing glass sphere with zero roughness produce total
+    internal reflection -> refract() = 0 -> normalize(vec3(0)) = NaN direction (compute.glsl:210-211), and the path ends in
+    texture(SamplerEnvironment, NaN) (compute.glsl:177) — undefined in GL.  llvmpipe returns a deterministic texel average that depends
+    on the NaN's sign bit (probed with a test main); the contract clamps the coordinate.  This test shows that this is ALL there is to
+    it: per sample, every gross difference between the oracle and the reference either ends in such a lookup (flagged by the oracle's
+    diagnostic build) or belongs to the usual branch-flip budget (< 0.03 % of the samples)."""
+    import __graft_entry__ as graft
+    O = graft.load_oracle()
+    plain, marked = O.Oracle(), O.Oracle(mark_nan_env=True)
+    w = configs.Workload("edge_64x36_d16", "edge", 64, 36, 16, "sky_f32_32")
+    sc, basic, objs, env, kw = configs.inputs(w)
+    n = 96
+    acc = [x(w.width, w.height, basic, objs, env, num_frames=n, dump_each=True, **kw)[..., :3].astype(np.float64)
+           for x in (ref.run_pathtracer, plain.render, marked.render)]
+
+    def samples(a):  # per-frame samples from the running means
+        s = np.empty_like(a)
+        s[0] = a[0]
+        for k in range(1, len(a)):
+            s[k] = (k + 1) * a[k] - k * a[k - 1]
+        return s
+    sr, so, sm = (samples(a) for a in acc)
+    gross = np.abs(so - sr).max(-1) > 1e-2 * np.maximum(1.0, np.abs(sr).max(-1))
+    nan_env = np.abs(sm - so).max(-1) > 10.0
+    assert nan_env.sum() > 100, "the scene no longer exercises the quirk"
+    assert (gross & ~nan_env).sum() <= 3e-4 * gross.size, (int(gross.sum()), int(nan_env.sum()), int((gross & ~nan_env).sum()))
+    # without those samples the two accumulations agree like every other scene's
+    so_masked, sr_masked = np.where(nan_env[..., None], 0.0, so), np.where(nan_env[..., None], 0.0, sr)
+    assert abs(so_masked.mean() - sr_masked.mean()) <= 2e-4 * sr_masked.mean()
