@@ -132,6 +132,10 @@ CONVERGENCE = [
     # (An sRGB-environment variant is no use here: llvmpipe decodes sRGB8 texels with a cubic approximation, and pixels that see only
     # sky have a standard error of ~1e-9, so its deterministic 1e-7 difference reads as |z| in the hundreds.)
     Workload("randmat_64x36_d13", "randmat", 64, 36, 13, "sky_f32_32"),
+    # several samples per pixel per frame (one RNG stream per pixel per frame continued across the samples, compute.glsl:106-124), the
+    # reference's shipped depth, a wide lens and another camera
+    Workload("default_64x36_d13_spp4", "default", 64, 36, 13, "sky_f32_32", spp=4, aperture=0.6, focal_length=12.0, look=(20.0, -10.0),
+             position=(5.0, 2.0, -3.0)),
 ]
 
 # ---- small full-frame parity cases -----------------------------------------------------------------------------
