@@ -180,6 +180,13 @@ PT_API int pt_postprocess_device(pt_handle h, void **out_device_ptr, size_t *out
 PT_API int pt_present_rgba8_async(pt_handle h, int slot);
 PT_API int pt_present_wait(pt_handle h, int slot, const uint8_t **out_host_rgba8, size_t *out_row_pitch_bytes,
                            int *out_frame_index);
+/* Interop-style present (the library side of SURVEY section 8f row 4; no reference counterpart — the reference samples its GL
+ * texture in place, src/Render/ScreenEffect.cs:29-37): make caller-owned DEVICE memory (>= rows*width*4 bytes, e.g. a GL buffer
+ * registered with hipGraphicsGLRegisterBuffer and mapped) the image of present slot `slot`; NULL restores the library's own images.
+ * pt_present_rgba8_async(slot) then tone-maps the frame straight into that memory and copies nothing to the host — the 8.3 MB
+ * that a 1080p frame otherwise sends over PCIe; pt_present_wait(slot) returns once the image is complete there (out_host_rgba8
+ * receives NULL, the frame index as usual).  Single-GPU handles only. */
+PT_API int pt_present_bind_device_image(pt_handle h, int slot, void *device_rgba8, size_t bytes);
 
 /* Resume support (no reference counterpart; the reference discards accumulation on every event): replace the
  * accumulation image of this tile and set the frame counter.  Alpha is stored as 1 whatever the source holds (the

@@ -1018,8 +1018,13 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
     h->presentCadence = h->rendersSincePresent;
     h->rendersSincePresent = 0;
     if (int rc = ptimpl::ensure_slot_events(h, slot)) return rc;
-    if (int rc = ptimpl::ensure_slot_device(h, slot, pixels)) return rc;
-    if (int rc = ptimpl::ensure_slot_host(h, slot, pixels)) return rc;
+    if (s.boundDev) { // the displayed image stays on the device (interop-style present): no slot images of the library's own
+        if (s.boundBytes < pixels * 4) return fail(h, PT_E_BAD_ARGUMENT, "bound device image is smaller than rows*width*4 bytes");
+    } else {
+        if (int rc = ptimpl::ensure_slot_device(h, slot, pixels)) return rc;
+        if (int rc = ptimpl::ensure_slot_host(h, slot, pixels)) return rc;
+    }
+    void *const image = s.boundDev ? s.boundDev : s.dRgba8;
     // ---- snapshot path: the launch of the frames shown writes its last frame into a snapshot buffer while it resolves the pixels;
     // the tone map follows that launch on its stream, the copy on the copy stream, and nothing waits for them: the next pt_render
     // chains its launch beside this one.
@@ -1036,13 +1041,13 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
             // fourth busy stream shares a hardware queue with a launch stream and would run behind the next launch.
             for (const pt_renderer::SnapLaunch &l : h->snapLaunches) {
                 if (s.inFlight) PT_HIP(h, hipStreamWaitEvent(l.stream, s.copied, 0)); // the slot's previous copy still reads its device image
-                PT_HIP(h, pt::launch_postprocess(h->dSnap[k] + l.firstPixel, (char *)s.dRgba8 + l.firstPixel * 4, l.pixels, l.stream));
+                PT_HIP(h, pt::launch_postprocess(h->dSnap[k] + l.firstPixel, (char *)image + l.firstPixel * 4, l.pixels, l.stream));
                 PT_HIP(h, hipEventRecord(l.done, l.stream)); // "launch done" now includes its tone map
                 PT_HIP(h, hipStreamWaitEvent(h->copyStream, l.done, 0));
             }
             PT_HIP(h, hipEventRecord(h->snapRead[k], h->copyStream)); // (behind every tone map that read the snapshot)
             h->snapReadPending[k] = true;
-            PT_HIP(h, hipMemcpyAsync(s.host, s.dRgba8, pixels * 4, hipMemcpyDeviceToHost, h->copyStream));
+            if (!s.boundDev) PT_HIP(h, hipMemcpyAsync(s.host, s.dRgba8, pixels * 4, hipMemcpyDeviceToHost, h->copyStream));
             PT_HIP(h, hipEventRecord(s.copied, h->copyStream));
             s.inFlight = true;
             s.valid = false;
@@ -1069,25 +1074,43 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
             hipStream_t st = ptimpl::stripe_stream(h, j);
             if (s.inFlight) PT_HIP(h, hipStreamWaitEvent(st, s.copied, 0));
             const size_t first = (size_t)h->stripeRow0[j] * h->width, count = (size_t)h->stripeRows[j] * h->width;
-            PT_HIP(h, pt::launch_postprocess(h->accum() + first, (char *)s.dRgba8 + first * 4, count, st));
+            PT_HIP(h, pt::launch_postprocess(h->accum() + first, (char *)image + first * 4, count, st));
             PT_HIP(h, hipEventRecord(h->stripeDone[j], st)); // "stripe done" now includes its tone map
             PT_HIP(h, hipStreamWaitEvent(h->copyStream, h->stripeDone[j], 0));
         }
     } else {
         if (int rc = join_stripes(h)) return rc;
         if (s.inFlight) PT_HIP(h, hipStreamWaitEvent(h->stream, s.copied, 0));
-        PT_HIP(h, pt::launch_postprocess(h->accum(), s.dRgba8, pixels, h->stream));
+        PT_HIP(h, pt::launch_postprocess(h->accum(), image, pixels, h->stream));
         PT_HIP(h, hipEventRecord(s.toneMapped, h->stream));
         // later frames only wait for the tone-map pass (stream order); the PCIe copy runs beside them on the copy stream
         PT_HIP(h, hipStreamWaitEvent(h->copyStream, s.toneMapped, 0));
     }
-    PT_HIP(h, hipMemcpyAsync(s.host, s.dRgba8, pixels * 4, hipMemcpyDeviceToHost, h->copyStream));
+    if (!s.boundDev) PT_HIP(h, hipMemcpyAsync(s.host, s.dRgba8, pixels * 4, hipMemcpyDeviceToHost, h->copyStream));
     PT_HIP(h, hipEventRecord(s.copied, h->copyStream));
     s.inFlight = true;
     s.valid = false;
     s.frame = h->frame;
     s.rows = h->rows;
     s.width = h->width;
+    return PT_OK;
+}
+
+PT_API int pt_present_bind_device_image(pt_handle h, int slot, void *device_rgba8, size_t bytes)
+{
+    PT_CHECK_HANDLE(h);
+    if (slot < 0 || slot >= PT_PRESENT_SLOTS) return fail(h, PT_E_BAD_ARGUMENT, "slot must be 0..PT_PRESENT_SLOTS-1");
+    if (h->isGroup()) return fail(h, PT_E_BAD_ARGUMENT, "pt_present_bind_device_image is not available on a group handle");
+    if (device_rgba8 && bytes < h->tilePixels() * 4) return fail(h, PT_E_BAD_ARGUMENT, "device image smaller than rows*width*4 bytes");
+    if (int rc = bind_device(h)) return rc;
+    ptimpl::PresentSlot &s = h->slots[slot];
+    if (s.inFlight) { // a present into the slot's previous image may still be running
+        PT_HIP(h, hipEventSynchronize(s.copied));
+        s.inFlight = false;
+    }
+    s.valid = false;
+    s.boundDev = device_rgba8;
+    s.boundBytes = device_rgba8 ? bytes : 0;
     return PT_OK;
 }
 
@@ -1113,7 +1136,7 @@ PT_API int pt_present_wait(pt_handle h, int slot, const uint8_t **out_host_rgba8
             }
         }
     }
-    if (out_host_rgba8) *out_host_rgba8 = s.host;
+    if (out_host_rgba8) *out_host_rgba8 = s.boundDev ? nullptr : s.host; // (a bound slot's image is in the caller's device memory)
     if (out_row_pitch_bytes) *out_row_pitch_bytes = (size_t)s.width * 4;
     if (out_frame_index) *out_frame_index = s.frame;
     return PT_OK;

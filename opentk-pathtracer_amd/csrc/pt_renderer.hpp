@@ -25,6 +25,8 @@ constexpr int kStartedWords = pt::kStartedWords; // >= workgroups of any persist
 // One image of the non-blocking present path (pt_present_rgba8_async / pt_present_wait).
 struct PresentSlot {
     void *dRgba8 = nullptr;       // device RGBA8 image: this handle's rows (compact), or the whole image on a group handle
+    void *boundDev = nullptr;     // caller-owned device image (pt_present_bind_device_image): the tone map writes here, nothing is copied
+    size_t boundBytes = 0;
     size_t devPixels = 0;         // capacity of dRgba8
     uint8_t *host = nullptr;      // pinned host image (absent on the parts of a group: only the group handle copies to the host)
     size_t hostPixels = 0;

@@ -203,6 +203,7 @@ def load() -> C.CDLL:
         "pt_device_count_of": [vp, ip],
         "pt_present_rgba8_async": [vp, C.c_int],
         "pt_present_wait": [vp, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), ip],
+        "pt_present_bind_device_image": [vp, C.c_int, vp, C.c_size_t],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

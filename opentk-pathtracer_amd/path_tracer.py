@@ -204,12 +204,18 @@ class PathTracer:
         rc = self._lib.pt_present_wait(self._h, slot, C.byref(ptr), C.byref(pitch), C.byref(frame))
         if rc:
             check(rc, self._h)
+        if not ptr:  # a slot bound to caller-owned device memory (BindPresentImage): the image is there, nothing came to the host
+            return None, frame.value
         key = (slot, C.addressof(ptr.contents), self.rows, self.Width)
         img = st["views"].get(key)
         if img is None:  # one numpy view per pinned slot image (building it costs more than the call itself)
             assert pitch.value == self.Width * 4
             img = st["views"][key] = np.ctypeslib.as_array(ptr, shape=(self.rows, self.Width, 4))
         return img, frame.value
+
+    def BindPresentImage(self, slot: int, device_ptr, nbytes: int = 0) -> None:
+        """pt_present_bind_device_image: present slot `slot` tone-maps into caller-owned device memory (interop-style); None restores."""
+        check(self._lib.pt_present_bind_device_image(self._h, slot, C.c_void_p(device_ptr) if device_ptr else None, nbytes), self._h)
 
     def SetPartition(self, band_rows: int) -> None:
         """Group handles: block-cyclic bands of `band_rows` image rows per device (0 = contiguous row blocks)."""

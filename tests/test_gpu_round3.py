@@ -221,3 +221,44 @@ def test_bench_self_spawns_ranks_and_refuses_missing_devices(pkg, native_lib):
     assert line["ranks"] == 2 and line["n_gpus"] == 1 and line["checks"]["finite"] and line["steady"]["steps"] >= 512
     # the in-process group handle (here: device 0 twice) rendered the same frames and equals the gathered image of the two ranks
     assert line["in_process_group"].get("error") is None and line["in_process_group"]["equals_rccl_gather_bit_for_bit"] is True
+
+
+# ------------------------------------------------------------------------------------------------ interop-style present
+def test_present_into_bound_device_images(pkg, native_lib, oracle):
+    """pt_present_bind_device_image: the present slots tone-map into CALLER-OWNED device memory (what a host that registered a GL buffer
+    with HIP would pass) and nothing is copied to the host.  Every presented frame — read back from that memory by the test — must
+    equal the oracle's post-process of the oracle's accumulation after exactly that many frames, with the frames chained as in the
+    copying path; unbinding restores the pinned host images; a group handle and a short buffer are refused."""
+    torch = pytest.importorskip("torch")
+    w = configs.Workload("bound_present", "default", 224, 126, 8, "sky_f32_32")
+    sc, basic, objs, env, kw = configs.inputs(w)
+    pt = make_tracer(pkg, w)
+    frames = 9
+    acc = oracle.render(w.width, w.height, basic, objs, env, num_frames=frames, dump_each=True, **kw)
+    bufs = [torch.zeros((w.height, w.width, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for s, b in enumerate(bufs):
+        pt.BindPresentImage(s, b.data_ptr(), b.numel())
+    for f in range(frames):
+        pt.Render()
+        pt.PresentAsync(f % 2)
+        if f >= 1:
+            img, idx = pt.PresentWait((f - 1) % 2)
+            assert img is None and idx == f
+            assert np.array_equal(bufs[(f - 1) % 2].cpu().numpy(), oracle.postprocess(acc[f - 1])[1]), f"frame {f}"
+    img, idx = pt.PresentWait((frames - 1) % 2)
+    assert img is None and idx == frames and np.array_equal(bufs[(frames - 1) % 2].cpu().numpy(), oracle.postprocess(acc[frames - 1])[1])
+    # back to the library's own images
+    pt.BindPresentImage(0, None)
+    pt.Render()
+    pt.PresentAsync(0)
+    img, idx = pt.PresentWait(0)
+    want = oracle.render(w.width, w.height, basic, objs, env, frame_start=frames, num_frames=1, image=acc[-1].copy(), **kw)
+    assert idx == frames + 1 and np.array_equal(img, oracle.postprocess(want)[1])
+    N = pkg.native
+    assert native_lib.pt_present_bind_device_image(pt._h, 1, bufs[1].data_ptr(), 16) == N.PT_E_BAD_ARGUMENT
+    assert native_lib.pt_present_bind_device_image(pt._h, 7, bufs[1].data_ptr(), bufs[1].numel()) == N.PT_E_BAD_ARGUMENT
+    pt.Dispose()
+    g = make_tracer(pkg, w, devices=[0, 0])
+    assert native_lib.pt_present_bind_device_image(g._h, 0, bufs[0].data_ptr(), bufs[0].numel()) == N.PT_E_BAD_ARGUMENT
+    g.Dispose()

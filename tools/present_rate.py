@@ -77,6 +77,22 @@ def every4(i):
 rate("4 x render + async present (a display slower than the renderer)", every4, n=a.frames // 4)
 results["4 x render + async present (a display slower than the renderer)"]["ms_per_rendered_frame"] = round(
     results["4 x render + async present (a display slower than the renderer)"]["ms_per_displayed_frame"] / 4, 4)
+if not a.devices:
+    # interop-style present: the slots tone-map into caller-owned DEVICE memory (pt_present_bind_device_image), nothing crosses PCIe —
+    # what a host pays whose GL context lives on the same GPU and displays a HIP-registered buffer
+    import torch
+    bufs = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for s_, b_ in enumerate(bufs): pt.BindPresentImage(s_, b_.data_ptr(), b_.numel())
+    seen2 = [False, False]
+    def bound(i):
+        pt.Render()
+        if seen2[i & 1]: pt.PresentWait(i & 1)
+        pt.PresentAsync(i & 1)
+        seen2[i & 1] = True
+    rate("render + async present into BOUND DEVICE images (no host copy; interop-style)", bound)
+    for s_ in range(2):
+        pt.PresentWait(s_); pt.BindPresentImage(s_, None)
 if a.json:
     os.makedirs(os.path.dirname(a.json) or ".", exist_ok=True)
     json.dump({"image": [W, H], "devices": extra.get("devices", [0]), "csrc_hash": pkg.native.csrc_hash(), "results": results}, open(a.json, "w"), indent=1)

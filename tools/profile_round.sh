@@ -22,7 +22,9 @@ WARM=${PROFILE_WARMUP:-320}
 echo $((STEPS + WARM)) > $OUT/frames.txt
 BENCH="python $R/bench.py --steps $STEPS --warmup $WARM --clock-warmup-ms 0 --steady-ms 0 --no-cpu-baseline ${@:2}"
 CAL="python $R/bench.py --steps $STEPS --warmup $WARM --clock-warmup-ms 0 --steady-ms 0 --no-cpu-baseline --depth 0 ${@:2}"
-run() { name=$1; opts=$2; cmd=$3; rocprofv3 --kernel-trace $opts --output-format csv -d $OUT/$name -o $name -- $cmd > $OUT/$name.log 2>&1; }
+# PROFILE_PASSES="stats fetch write sq" restricts the passes (a reduced re-profile after a host-only change); default: all
+run() { name=$1; opts=$2; cmd=$3; if [ -n "$PROFILE_PASSES" ] && [[ " $PROFILE_PASSES " != *" $name "* ]]; then return; fi
+        rocprofv3 --kernel-trace $opts --output-format csv -d $OUT/$name -o $name -- $cmd > $OUT/$name.log 2>&1; }
 run stats "--stats" "$BENCH"
 run fetch "--pmc FETCH_SIZE" "$BENCH"
 run write "--pmc WRITE_SIZE" "$BENCH"
@@ -34,7 +36,7 @@ if [ -z "$PROFILE_NO_CAL" ]; then
   run cal_fetch "--pmc FETCH_SIZE" "$CAL"
   run cal_write "--pmc WRITE_SIZE" "$CAL"
 fi
-python $R/bench.py ${@:2} > $OUT/bench.json 2> $OUT/bench.err
+python $R/bench.py $PROFILE_BENCH_EXTRA ${@:2} > $OUT/bench.json 2> $OUT/bench.err
 tail -c 400 $OUT/bench.json
 # only the small files travel back (the raw traces are large): per-kernel stats + counter tables, and the integrator's rows of
 # the stats run's kernel trace (start / end of every launch: consecutive launches OVERLAP on two streams, see summarize_profile.py)

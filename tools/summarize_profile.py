@@ -63,9 +63,21 @@ W, H = bench.get("config", {}).get("image", [1920, 1080])
 pixels = W * H
 total_ns = sum(float(r["TotalDurationNs"]) for r in kstats)
 calls = sum(int(r["Calls"]) for r in kstats)
-known = 16.0 * pixels  # calibration: the depth-0 launch reads 16 B and writes 16 B per pixel, nothing else of size
+# calibration: the depth-0 launch reads 16 B and writes 16 B per pixel, nothing else of size (the calibration run's OWN image size:
+# several workloads share one calibration, and they need not have its resolution)
+_cb = os.path.join(cal_src, "bench.json")
+_cal_img = json.load(open(_cb)).get("config", {}).get("image", [1920, 1080]) if os.path.exists(_cb) else [W, H]
+known = 16.0 * _cal_img[0] * _cal_img[1]
 fetch_factor = known / (cal["FETCH_SIZE"] * 1024.0) if cal["FETCH_SIZE"] else None
 write_factor = known / (cal["WRITE_SIZE"] * 1024.0) if cal["WRITE_SIZE"] else None
+if fetch_factor is None or write_factor is None:
+    # the calibration run's raw counters are not here (gpurun_out/ does not travel to the GPU box): take the factors from the committed
+    # summary of the calibration tag, which does
+    _cs = os.path.join(dst, f"{cal_tag}_summary.json")
+    if os.path.exists(_cs):
+        _c = json.load(open(_cs)).get("calibration_depth0", {})
+        fetch_factor, write_factor = _c.get("fetch_bytes_per_counted_byte"), _c.get("write_bytes_per_counted_byte")
+        cal = {"FETCH_SIZE": _c.get("FETCH_SIZE_KiB"), "WRITE_SIZE": _c.get("WRITE_SIZE_KiB")}
 # Consecutive pipelined launches overlap pairwise (launch chaining: two streams, ordered per pixel by tags), so the SUM of the
 # launch durations counts the overlapped time twice.  The machine time per frame is the UNION of the launch intervals / frames.
 launches_path = os.path.join(src, "stats", "integrator_launches.csv")
