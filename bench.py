@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--no-group-check", action="store_true",
                     help="N > 1: skip rendering the same frames through ONE in-process group handle (pt_create_multi over the N devices, "
                          "peer copies over xGMI) and comparing it bit for bit with the RCCL-gathered image")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="tuning knob of the library (csrc/pt_tuning.hpp) set through pt_debug_set before any renderer exists, e.g. "
+                         "--tune no_sphere_grid=1; the library itself reads no environment variables")
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: all ranks use cuda:0 and rendezvous over gloo (validates the N>1 logic on a 1-GPU box; "
                          "RCCL cannot put two ranks on one device)")
@@ -237,6 +240,9 @@ def main():
                 time.sleep(1.0)
             time.sleep(2.0)
     from opentk_pathtracer_amd import distributed as D
+    for kv in args.tune:
+        key, _, val = kv.partition("=")
+        pkg.native.debug_set(key, int(val))
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != args.gpus:
@@ -444,7 +450,7 @@ def main():
         kernel_ms = m["kernel_s"] * 1e3 / args.steps
         algo_bytes = ALGO_BYTES_PER_PIXEL_FRAME * W * rows  # per frame on one GPU (rank 0's rows)
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        wl_key = f"{scene_name}_{W}x{H}_d{depth}_spp{args.spp}_{env_name}_g{world}" + (f"_variant{args.variant}" if args.variant else "") + (f"_fb{args.frame_batch}" if args.frame_batch != 64 else "") + ("_strong4k" if args.strong_4k else "") + ("_weak" if args.weak and world > 1 else "") + ("_nogrid" if os.environ.get("PT_NO_SPHERE_GRID") else "")
+        wl_key = f"{scene_name}_{W}x{H}_d{depth}_spp{args.spp}_{env_name}_g{world}" + (f"_variant{args.variant}" if args.variant else "") + (f"_fb{args.frame_batch}" if args.frame_batch != 64 else "") + ("_strong4k" if args.strong_4k else "") + ("_weak" if args.weak and world > 1 else "") + ("_nogrid" if "no_sphere_grid=1" in args.tune else "")
         if world == 1:
             where = "one GPU" + (f" (BASELINE configs[{baseline_index}])" if baseline_index is not None and (W, H) == (1920, 1080) else "")
         else:
@@ -460,7 +466,7 @@ def main():
             "config": {"workload": f"{scene_name} scene ({scene.num_spheres} spheres + {scene.num_cuboids} cuboids), {W}x{H}, "
                                    f"{depth} bounces, {args.spp} spp, progressive accumulate, env {env_name}, {where}",
                        "image": [W, H], "ray_depth": depth, "spp": args.spp, "parallelism": f"rowbands{world}",
-                       "kernel_variant": args.variant, "csrc_hash": csrc_hash},
+                       "kernel_variant": args.variant, "csrc_hash": csrc_hash, **({"tuning": args.tune} if args.tune else {})},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          # measured HBM bytes per LAUNCH (calibrated PMC passes; profiles/traffic.json holds bytes per frame)

@@ -205,18 +205,12 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     pt_renderer *h = new (std::nothrow) pt_renderer();
     if (!h) return fail(nullptr, PT_E_OUT_OF_MEMORY, "host allocation failed");
     h->device = device_id;
-    if (const char *dcv = std::getenv("PT_DRAIN_COMPACTION")) h->drainCompaction = std::atoi(dcv);
-    if (const char *bw = std::getenv("PT_BATCH_WG")) {
-        int v = std::atoi(bw);
-        if (v >= 1 && v <= 8) h->batchWorkgroupsPerCU = v;
-    }
-    if (const char *fb = std::getenv("PT_FRAME_BATCH")) {
-        int v = std::atoi(fb);
-        if (v >= 1 && v <= 64) h->maxBatch = v;
-    }
-    if (const char *qc = std::getenv("PT_QUEUE_CHUNK")) {
-        int v = std::atoi(qc);
-        if (v >= 1 && v <= 1024) h->queueChunk = v;
+    { // tuning knobs (pt_tuning.hpp: set through pt_debug_set only; the library reads no environment variables)
+        const pt::Tuning &t = pt::tuning();
+        if (t.drainCompaction >= -1) h->drainCompaction = t.drainCompaction;
+        if (t.batchWorkgroupsPerCU >= 1 && t.batchWorkgroupsPerCU <= 8) h->batchWorkgroupsPerCU = t.batchWorkgroupsPerCU;
+        if (t.frameBatch >= 1 && t.frameBatch <= 64) h->maxBatch = t.frameBatch;
+        if (t.queueChunk >= 1 && t.queueChunk <= 1024) h->queueChunk = t.queueChunk;
     }
     h->width = width;
     h->height = height;
@@ -539,7 +533,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     a.auditLog = h->devAuditLog;
     a.auditSabotage = 0;
 #ifdef PT_AUDIT
-    if (const char *sab = std::getenv("PT_AUDIT_SABOTAGE")) a.auditSabotage = std::atoi(sab);
+    a.auditSabotage = pt::tuning().auditSabotage;
 #endif
     a.timeline = h->dTimeline;
     // sphere grid of large scenes: rebuilt here, before the first launch that sees the changed scene.  Launches still in flight
@@ -547,6 +541,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     if (h->gridDirty) {
         h->gridDirty = false;
         h->grid = ptgrid::build((const float *)h->objectsShadow, h->numSpheres);
+        ptgrid::sphere_runs((const float *)h->objectsShadow, h->numSpheres, h->sphereRunStart);
         if (h->grid.valid) {
             if (int rc = join_stripes(h)) return rc;
             PT_HIP(h, hipMemcpyAsync(h->dGrid, h->grid.packed.data(), h->grid.packed.size(), hipMemcpyHostToDevice, h->stream));
@@ -564,6 +559,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         a.gridCenter[k] = h->grid.center[k];
     }
     a.gridReach2 = h->grid.reach2;
+    std::memcpy(a.sphereRunStart, h->sphereRunStart, sizeof(a.sphereRunStart));
 
     // variant -> (kernel variant, stripes): 0 = default (2 stripes x 5 workgroups/CU); 20+k / 30+k / 40+k = 2 / 3 / 4
     // stripes of the persistent kernel with k+1 workgroups per CU; everything else = one kernel on the main stream
@@ -575,7 +571,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     // moves into the wavefront slots the previous launch's drain frees (0.154 ms per 1080p frame against 0.182 for the two row
     // stripes); a host that lets the GPU run dry between its frames (blocking reads / presents) keeps the stripes, which are the
     // faster way to render ONE frame on an idle machine.
-    static const bool noSingleTagged = std::getenv("PT_NO_SINGLE_TAGGED") != nullptr; // A/B runs
+    const bool noSingleTagged = pt::tuning().noSingleTagged != 0; // A/B runs
     const bool chainable = h->variant == 0 && !h->externalStream() && h->dTimeline == nullptr;
     // (also the first frame of a burst on an idle GPU once the host has pipelined frames before: the batch that follows then chains
     // on it instead of waiting behind two joined stripes — the driver's `--steps 20` command: 15.4 instead of 14.8 Gsamples/s)
@@ -583,7 +579,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     // (short launches — the interactive modes — take 5 workgroups per CU: 112 instead of 32 free VGPRs per SIMD leave the present's
     // tone map and the runtime's copy kernel room BESIDE the resident persistent wavefronts; 6 per CU starve them until the drain,
     // measured: 0.28 instead of 0.16 ms per displayed frame; a single frame also renders 2 % faster with 5)
-    static const int shortWg = std::getenv("PT_SHORT_WG") ? std::atoi(std::getenv("PT_SHORT_WG")) : 5;
+    const int shortWg = pt::tuning().shortWorkgroupsPerCU;
     if (tagged) { stripes = 1; kernelVariant = 10 + (n < 8 ? shortWg : h->batchWorkgroupsPerCU) - 1; h->batchLaunched = true; if (n > 1) h->sawBatch = true; }
     else if (h->variant == 0 && h->externalStream()) { stripes = 1; kernelVariant = 14; } // everything ON the caller's stream
     else if (h->variant == 0) { stripes = 2; kernelVariant = 14; }
@@ -626,7 +622,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
             // instead the call waits until the predecessor is resident (i.e. until the launch before it has left the machine) and
             // then chains.  The host thread is never more than two launches ahead; bounded, so a GPU shared with another process
             // falls back to the always-safe same-stream order.
-            static const long waitLimitUs = std::getenv("PT_CHAIN_WAIT_US") ? std::atol(std::getenv("PT_CHAIN_WAIT_US")) : 60000;
+            const long waitLimitUs = pt::tuning().chainWaitUs;
             const auto t0 = std::chrono::steady_clock::now();
             for (long spins = 0; !resident; spins++) {
                 const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -1311,6 +1307,14 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_timeline(pt_handl
     }
     PT_HIP(h, hipStreamSynchronize(h->stream));
     if (host_out) PT_HIP(h, hipMemcpy(host_out, h->dTimeline, (size_t)max_waves * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+// Tuning aid (not declared in the public header): set one of pt_tuning.hpp's knobs for this process.  The library reads no environment
+// variables; this is the only way a knob changes.  Affects renderers created / frames launched afterwards.
+extern "C" __attribute__((visibility("default"))) int pt_debug_set(const char *key, long long value)
+{
+    if (!key || !pt::tuning_set(key, value)) return fail(nullptr, PT_E_BAD_ARGUMENT, "pt_debug_set: unknown knob");
     return PT_OK;
 }
 

@@ -354,10 +354,7 @@ PT_API int pt_create_multi(const int *device_ids, int n_devices, int width, int 
         }
         (void)hipGetLastError();
     }
-    if (const char *b = std::getenv("PT_GROUP_BAND")) {
-        int v = std::atoi(b);
-        if (v == 0 || (v >= 8 && (v & 7) == 0)) g->groupBand = v;
-    }
+    if (const int v = pt::tuning().groupBand; v == 0 || (v >= 8 && (v & 7) == 0)) g->groupBand = v; // (tuning knob, pt_tuning.hpp)
     int rc = apply_partition(g);
     if (rc != PT_OK) {
         std::string msg = g->error;

@@ -245,13 +245,29 @@ PT_DEV Material load_material(const float4 *m)
 // so it is listed in the cell that contains the hit point and has been tested when the walk reaches that cell.  Lanes the
 // argument does not cover — origin out of reach, non-finite or non-unit direction, an inside sphere met after the first
 // cell — take the in-order loop afterwards (needBrute).
-template <bool MASKED, bool MATLDS, bool GRID = false>
-PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, const unsigned long long *masks PROF_PARAM)
+// SHARE (the default kernel's generic bounce): the in-order sphere loop shares what consecutive spheres with equal centre x and z
+// have in common (sphere runs, below).
+// WALK SLICES (GRID): the lanes of a wavefront walk in lock step, one cell per round, so a wavefront pays for its longest walk
+// (10.9 cells for the slowest of 64 rays of the 256-sphere scene, 3.3 on average: tools/grid_walk_model.py).  A call therefore walks at
+// most PT_WALK_ROUNDS cells; a lane that is not done by then returns with walkFrom = the parameter at which its ray leaves the last
+// cell it processed, takes no part in the rest of the bounce, and the caller traces the SAME ray again in its next iteration, entering
+// the grid at walkFrom — beside lanes that meanwhile took fresh paths, so every round runs with (nearly) all lanes.  Nothing found
+// before walkFrom needs to be remembered: an unfinished walk means T > the exit of every processed cell, so the accepted sphere's hit
+// point, and every better one, lies in a cell from walkFrom on and is listed there (the set rule above does not depend on the order);
+// a sphere that contains the origin and reaches past walkFrom is met again with first == false and sends the lane through the
+// in-order loop, as an inside sphere after the first cell always did.
+#ifndef PT_WALK_ROUNDS
+#define PT_WALK_ROUNDS 6
+#endif
+
+template <bool MASKED, bool MATLDS, bool GRID = false, bool SHARE = false>
+PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, const unsigned long long *masks, float &walkFrom PROF_PARAM)
 {
     PROF_BEGIN
     float T = FLOAT_MAX, wt2 = 0.0f;
     int winner = -1;
     bool needBrute = true;
+    float wf = -1.0f; // GRID: >= 0 when this call leaves the walk unfinished (see WALK SLICES below)
     if (GRID && !MASKED && sc.gridStarts != nullptr) {
         ColdArgs ca = cold_args();
         const v3 rel = V(o.x - ca->gridCenter[0], o.y - ca->gridCenter[1], o.z - ca->gridCenter[2]);
@@ -267,7 +283,9 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
             const float ax0 = (ca->gridLo[0] - o.x) * ix_, ax1 = (ca->gridHi[0] - o.x) * ix_;
             const float ay0 = (ca->gridLo[1] - o.y) * iy_, ay1 = (ca->gridHi[1] - o.y) * iy_;
             const float az0 = (ca->gridLo[2] - o.z) * iz_, az1 = (ca->gridHi[2] - o.z) * iz_;
-            const float tn = f_max(0.0f, f_max(f_min(ax0, ax1), f_max(f_min(ay0, ay1), f_min(az0, az1))));
+            float tn = f_max(0.0f, f_max(f_min(ax0, ax1), f_max(f_min(ay0, ay1), f_min(az0, az1))));
+            const bool resumed = walkFrom >= 0.0f;
+            tn = resumed ? f_max(tn, walkFrom) : tn;
             const float tf = f_min(f_max(ax0, ax1), f_min(f_max(ay0, ay1), f_max(az0, az1)));
             if (tn <= tf) { // (else: the ray misses the box that holds every sphere)
                 const int nx = ca->gridDims[0], ny = ca->gridDims[1], nz = ca->gridDims[2];
@@ -288,9 +306,9 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
                 int cell = (cz * ny + cy) * nx + cx;
                 const int sx = px ? 1 : -1, sy = py ? nx : -nx, sz = pz ? nx * ny : -(nx * ny);
                 int L = -1, viol = 0; // (flags carried through divergent loops live in VGPRs: a bool would cost mask bookkeeping per round)
-                bool first = true; // (wave-uniform: the lanes walk in lock step, one cell per round)
+                bool first = !resumed; // (a resumed walk is past its first cell)
                 int k = sc.gridStarts[cell], kEnd = sc.gridStarts[cell + 1];
-                for (;;) {
+                for (int round = 0;; round++) {
                     // Where the ray goes next does not depend on this cell's tests: decide it first and fetch the next cell's list
                     // bounds now, so that their LDS latency is covered by the tests (only the stop criterion needs T).
                     const bool xm = mx <= my && mx <= mz, ym = !xm && my <= mz;
@@ -332,6 +350,7 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
                     }
                     first = false;
                     if (T <= texit || !more) break; // nothing listed only in later cells can be nearer / left the box
+                    if (round == PT_WALK_ROUNDS - 1) { wf = texit; break; } // WALK SLICES: the rest of this ray's walk runs in the next bounce iteration
                     mx = xm ? mx + dx : mx;
                     my = ym ? my + dy : my;
                     mz = (xm || ym) ? mz : mz + dz;
@@ -345,7 +364,7 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
                 needBrute = viol != 0;
             }
         }
-        if (needBrute) { T = FLOAT_MAX; wt2 = 0.0f; winner = -1; }
+        if (needBrute) { T = FLOAT_MAX; wt2 = 0.0f; winner = -1; wf = -1.0f; }
     }
     // Sphere pass, 4 spheres per step: the four discriminants are computed branch-free from four broadcast LDS
     // reads issued together (ILP instead of one exposed LDS latency per sphere); only lanes with a real
@@ -382,29 +401,84 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
         i = ns;
     }
     if (!GRID || needBrute) { // (GRID: only the lanes the grid could not serve)
-    for (; i + 4 <= ns; i += 4) {
-        float4 s0 = sc.sph[i], s1 = sc.sph[i + 1], s2 = sc.sph[i + 2], s3 = sc.sph[i + 3];
-        float b[4], c[4], disc[4];
-        const float4 sv[4] = {s0, s1, s2, s3};
+    // Runs (FrameArgs::sphereRunStart): a sphere whose centre has the same x and z BITS as its predecessor's reuses o.x - c.x,
+    // o.z - c.z and the products d.x * oc.x, oc.x * oc.x that start the two dot-product chains of v_dot — identical binary32 values,
+    // 7 instead of 11 operations for that sphere.  The run bits are wave-uniform (scalar load, scalar branches).  The two fused
+    // multiply-adds that CONSUME the shared products are written as instructions: the compiler's two-address v_fmac would overwrite
+    // the product (and then copy it for the next sphere: three moves per sphere); `volatile` keeps them in program order between the
+    // run headers.  Four spheres per step as before: four broadcast LDS reads issued together, one exposed LDS latency per step.
+    if constexpr (!SHARE) {
+    // the plain loop, four spheres per step: four broadcast LDS reads issued together, one wave-level branch per sphere
+        for (; i + 4 <= ns; i += 4) {
+            const float4 sv[4] = {sc.sph[i], sc.sph[i + 1], sc.sph[i + 2], sc.sph[i + 3]};
+            float b[4], c[4], disc[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            v3 oc = V(o.x - sv[k].x, o.y - sv[k].y, o.z - sv[k].z);
-            b[k] = v_dot(d, oc);
-            c[k] = f_fma(-sv[k].w, sv[k].w, v_dot(oc, oc));
-            disc[k] = f_fma(b[k], b[k], -c[k]);
+            for (int k = 0; k < 4; k++) {
+                v3 oc = V(o.x - sv[k].x, o.y - sv[k].y, o.z - sv[k].z);
+                b[k] = v_dot(d, oc);
+                c[k] = f_fma(-sv[k].w, sv[k].w, v_dot(oc, oc));
+                disc[k] = f_fma(b[k], b[k], -c[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) candidate(i + k, b[k], c[k], disc[k]);
         }
+        for (; i < ns; i++) {
+            float4 s = sc.sph[i];
+            v3 oc = V(o.x - s.x, o.y - s.y, o.z - s.z);
+            float b = v_dot(d, oc);
+            float c = f_fma(-s.w, s.w, v_dot(oc, oc));
+            candidate(i, b, c, f_fma(b, b, -c));
+        }
+    } else if (i < ns) {
+        ColdArgs rca = cold_args();
+        unsigned int runs = 0u;
+        float ocz = 0.0f, bx = 0.0f, cx = 0.0f;
+#define PT_RUN_SPHERE(S, K)                                                                                              \
+        if (runs & (1u << (K))) {                                                                                        \
+            float ocx;                                                                                                   \
+            asm volatile("v_sub_f32 %0, %1, %2" : "=v"(ocx) : "v"(o.x), "v"(S.x));                                       \
+            ocz = o.z - S.z;                                                                                             \
+            bx = d.x * ocx;                                                                                              \
+            cx = ocx * ocx;                                                                                              \
+        }                                                                                                                \
+        {                                                                                                                \
+            const float ocy = o.y - S.y;                                                                                 \
+            float t1, u1;                                                                                                \
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(d.y), "v"(ocy), "v"(bx));   /* fma(d.y, oc.y, d.x * oc.x) */  \
+            asm volatile("v_fma_f32 %0, %1, %1, %2" : "=v"(u1) : "v"(ocy), "v"(cx));             /* fma(oc.y, oc.y, oc.x * oc.x) */ \
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(b[K]) : "v"(d.z), "v"(ocz), "v"(t1)); /* == v_dot(d, oc) */             \
+            asm volatile("v_fma_f32 %0, %1, %1, %2" : "=v"(u1) : "v"(ocz), "v"(u1));             /* == v_dot(oc, oc) */            \
+            c[K] = f_fma(-S.w, S.w, u1);                                                          /* ... - r * r */                \
+            disc[K] = f_fma(b[K], b[K], -c[K]);                                                                          \
+        }
+        for (; i + 4 <= ns; i += 4) {
+            if ((i & 31) == 0) runs = ((const __attribute__((address_space(4))) unsigned int *)rca->sphereRunStart)[i >> 5];
+            const float4 s0 = sc.sph[i], s1 = sc.sph[i + 1], s2 = sc.sph[i + 2], s3 = sc.sph[i + 3];
+            float b[4], c[4], disc[4];
+            asm volatile("" ::"v"(s0.x), "v"(s0.z), "v"(s1.x), "v"(s1.z), "v"(s2.x), "v"(s2.z), "v"(s3.x), "v"(s3.z)); // (whole float4 reads, all four at once)
+            PT_RUN_SPHERE(s0, 0)
+            PT_RUN_SPHERE(s1, 1)
+            PT_RUN_SPHERE(s2, 2)
+            PT_RUN_SPHERE(s3, 3)
+            runs >>= 4;
 #pragma unroll
-        for (int k = 0; k < 4; k++) candidate(i + k, b[k], c[k], disc[k]); // one wave-level branch per sphere
-    }
-    for (; i < ns; i++) {
-        float4 s = sc.sph[i];
-        v3 oc = V(o.x - s.x, o.y - s.y, o.z - s.z);
-        float b = v_dot(d, oc);
-        float c = f_fma(-s.w, s.w, v_dot(oc, oc));
-        candidate(i, b, c, f_fma(b, b, -c));
+            for (int k = 0; k < 4; k++) candidate(i + k, b[k], c[k], disc[k]); // one wave-level branch per sphere
+        }
+#undef PT_RUN_SPHERE
+        for (; i < ns; i++) { // (ns % 4 spheres: evaluated on their own)
+            float4 s = sc.sph[i];
+            v3 oc = V(o.x - s.x, o.y - s.y, o.z - s.z);
+            float b = v_dot(d, oc);
+            float c = f_fma(-s.w, s.w, v_dot(oc, oc));
+            candidate(i, b, c, f_fma(b, b, -c));
+        }
     }
     }
     PROF_MARK(1) // sphere pass
+    if constexpr (GRID) {
+        walkFrom = wf;
+        if (wf >= 0.0f) return false; // (unfinished walk: the caller re-traces this bounce from walkFrom; nothing else of the bounce has happened)
+    }
     v3 invd = V(f_rcp(d.x), f_rcp(d.y), f_rcp(d.z)); // slab test by reciprocal (pt-f32 contract)
     for (int i = 0; i < nc; i++) {
         float4 mn = sc.cmin[i], mx = sc.cmax[i];
@@ -443,7 +517,8 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
 }
 PT_DEV bool ray_trace(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h PROF_PARAM)
 {
-    return ray_trace_t<false, true>(sc, ns, nc, o, d, h, nullptr PROF_PASS);
+    float fresh = -1.0f;
+    return ray_trace_t<false, true>(sc, ns, nc, o, d, h, nullptr, fresh PROF_PASS);
 }
 
 // ---- per-tile sphere culling for a wavefront of (nearly) coherent rays
@@ -585,18 +660,22 @@ PT_DEV float bsdf(v3 &ro, v3 &rd, const Hit &h, bool &isRefractive, uint32_t &se
 
 // One iteration of Radiance's bounce loop (compute.glsl:140-180) for one path.  Returns true when the path
 // continues (hit, survived Russian roulette), false when it ended (miss -> environment, or roulette kill).
-template <bool MASKED, bool MATLDS, bool GRID = false>
+template <bool MASKED, bool MATLDS, bool GRID = false, bool SHARE = false>
 PT_DEV bool bounce_step_t(const SceneLds &sc, int ns, int nc, const EnvRef &env, v3 &ro, v3 &rd, v3 &throughput, v3 &rad,
-                          uint32_t &seed, const unsigned long long *masks PROF_PARAM)
+                          uint32_t &seed, const unsigned long long *masks, float &walkFrom PROF_PARAM)
 {
     Hit h;
-    if (ray_trace_t<MASKED, MATLDS, GRID>(sc, ns, nc, ro, rd, h, masks PROF_PASS)) {
+    const bool hit = ray_trace_t<MASKED, MATLDS, GRID, SHARE>(sc, ns, nc, ro, rd, h, masks, walkFrom PROF_PASS);
+    if constexpr (GRID) {
+        if (walkFrom >= 0.0f) return true; // the walk was cut short (WALK SLICES): the path is unchanged, the caller repeats this bounce
+    }
+    if (hit) {
         PROF_BEGIN
         if (h.fromInside) { // Beer's law, compute.glsl:145-149
             h.normal = v_neg(h.normal);
-            throughput.x *= pt_exp(-h.m.absorbance.x * h.T);
-            throughput.y *= pt_exp(-h.m.absorbance.y * h.T);
-            throughput.z *= pt_exp(-h.m.absorbance.z * h.T);
+            throughput.x *= pt_exp<SHARE>(-h.m.absorbance.x * h.T);
+            throughput.y *= pt_exp<SHARE>(-h.m.absorbance.y * h.T);
+            throughput.z *= pt_exp<SHARE>(-h.m.absorbance.z * h.T);
         }
         PROF_MARK(4) // Beer
         bool isRefractive;
@@ -627,7 +706,8 @@ PT_DEV bool bounce_step_t(const SceneLds &sc, int ns, int nc, const EnvRef &env,
 PT_DEV bool bounce_step(const SceneLds &sc, int ns, int nc, const EnvRef &env, v3 &ro, v3 &rd, v3 &throughput, v3 &rad,
                         uint32_t &seed PROF_PARAM)
 {
-    return bounce_step_t<false, true>(sc, ns, nc, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
+    float fresh = -1.0f;
+    return bounce_step_t<false, true>(sc, ns, nc, env, ro, rd, throughput, rad, seed, nullptr, fresh PROF_PASS);
 }
 
 // compute.glsl:132-182 Radiance

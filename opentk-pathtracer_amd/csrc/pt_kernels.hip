@@ -20,12 +20,11 @@
 //
 // Arithmetic: the "pt-f32" contract of pt_math.hpp (bit-identical to oracle/pt_oracle.c).
 // Build flags (see __graft_entry__.build): -O3 -ffp-contract=off -fno-fast-math --offload-arch=gfx950
-#include <cstdlib>
-
 #include "pt_atmosphere.hpp"
 #include "pt_device.hpp"
 #include "pt_kernels.hpp"
 #include "pt_math.hpp"
+#include "pt_tuning.hpp"
 
 namespace pt {
 
@@ -535,8 +534,13 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     v3 ro = V(0, 0, 0), rd = V(0, 0, 1), throughput = V(1, 1, 1), rad = V(0, 0, 0), irr = V(0, 0, 0);
     // SPP1 / frame pipelining: index of the path's frame inside the batch, "ended, waiting for its pixel's previous
     // frame" flag, and the number of failed resolve attempts
-    int fj = 0, retries = 0;
+    int fj = 0;
     bool pending = false;
+    // One register, two lives.  While the lane's path is being traced (!pending): GRID kernels keep the parameter from which the grid walk
+    // of the current bounce continues (>= 0 while it is unfinished, else -1: pt_device.hpp, WALK SLICES).  Once the path has ended and
+    // waits for its pixel (pending): the bits count the failed resolve attempts.
+    float walkFrom = -1.0f, walkFresh = -1.0f;
+    auto retries = [&]() -> int { return __float_as_int(walkFrom); };
     // (PT_CARRY_LAST: bit 14 of fj = the lane's slot of laneLast holds the pixel's accumulation value as the tile pass read it)
 
     // compute.glsl:125-129 for one finished path of frame `rfj` of the batch.  False = the pixel still holds an older
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
 #endif
                         if (valid) {
                             if (0 < a.rayDepth)
-                                tcont = bounce_step_t<true, MATLDS>(sc, a.numSpheres, a.numCuboids, env, to, td, tthr, trad, tseed, masks PROF_DUMMY);
+                                tcont = bounce_step_t<true, MATLDS>(sc, a.numSpheres, a.numCuboids, env, to, td, tthr, trad, tseed, masks, walkFresh PROF_DUMMY);
                             if (1 >= a.rayDepth) tcont = false;
                             tkeep = tcont;
 #ifdef PT_CARRY_LAST
@@ -773,7 +777,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                     laneLast[0] = e.last[0]; laneLast[64] = e.last[1]; laneLast[128] = e.last[2];
 #endif
                     pending = false;
-                    retries = 0;
+                    walkFrom = -1.0f;
                     seed = e.seed;
                     ro = V(e.ro[0], e.ro[1], e.ro[2]);
                     rd = V(e.rd[0], e.rd[1], e.rd[2]);
@@ -800,7 +804,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         sample = 0;
                         fj = e.pad;
                         pending = false;
-                        retries = 0;
+                        walkFrom = -1.0f;
                         bounce = 0;
                         needRay = false;
                     }
@@ -833,7 +837,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                             bounce = (st.counters >> 12) & 0xfff;
                             pending = (st.counters >> 25) & 1;
                             fj = (st.counters >> 26) & 0x3f;
-                            retries = 0;
+                            walkFrom = pending ? 0.0f : -1.0f;
 #ifdef PT_CARRY_LAST
                             if constexpr (SPP1) {
                                 if (st.counters & 1) fj |= 0x4000;
@@ -948,9 +952,12 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             if (active) {
                 if (!pending) {
                     bool cont = false;
-                    if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
-                    bounce++;
-                    pending = !cont || bounce >= a.rayDepth;
+                    if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID, (MATLDS && !GRID)>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr, walkFrom PROF_PASS);
+                    if (!(GRID && walkFrom >= 0.0f)) { // (else: the grid walk of this bounce continues in the next iteration, pt_device.hpp WALK SLICES)
+                        bounce++;
+                        pending = !cont || bounce >= a.rayDepth;
+                        if (pending) walkFrom = 0.0f; // (= no failed resolve attempt yet)
+                    }
                 }
 #ifdef PT_PROFILE
                 prof_t = __builtin_readcyclecounter();
@@ -964,13 +971,13 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
 #endif
                 if (pending) {
                     v3 firr = v_add(V(0.0f, 0.0f, 0.0f), rad);
-                    const bool force = retries > FRAME_RETRY_LIMIT;
+                    const bool force = retries() > FRAME_RETRY_LIMIT;
                     if (try_resolve(pix, fj, firr, force)) {
                         if (force) atomicOr(cold_args()->errorWord, 1u); // host-visible error word
                         pix = -1;
                         pending = false;
                     } else {
-                        retries++;
+                        walkFrom = __int_as_float(retries() + 1);
                     }
                 }
             }
@@ -996,26 +1003,27 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         if (active) {
             if (!pending) {
                 bool cont = false;
-                if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr PROF_PASS);
-                bounce++;
-                if (!cont || bounce >= a.rayDepth) {
+                if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr, walkFrom PROF_PASS);
+                const bool sliced = GRID && walkFrom >= 0.0f; // (the grid walk of this bounce continues in the next iteration)
+                if (!sliced) bounce++;
+                if (!sliced && (!cont || bounce >= a.rayDepth)) {
                     irr = v_add(irr, rad);
                     sample++;
                     if (sample < a.spp) needRay = true;
-                    else pending = true; // the pixel's last sample: fold into the accumulation image
+                    else { pending = true; walkFrom = 0.0f; } // the pixel's last sample: fold into the accumulation image (no failed attempt yet)
                 }
             }
 #ifdef PT_PROFILE
             prof_t = __builtin_readcyclecounter();
 #endif
             if (pending) {
-                const bool force = retries > FRAME_RETRY_LIMIT;
+                const bool force = retries() > FRAME_RETRY_LIMIT;
                 if (try_resolve(pix, fj, irr, force)) {
                     if (force) atomicOr(cold_args()->errorWord, 1u);
                     pix = -1;
                     pending = false;
                 } else {
-                    retries++;
+                    walkFrom = __int_as_float(retries() + 1);
                 }
             }
         }
@@ -1105,6 +1113,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
     bool exhausted = false;
     int pix = -1, sample = 0, bounce = 0, fj = 0;
     bool needRay = false, pending = false;
+    float walkFrom = -1.0f, walkFresh = -1.0f; // (WALK SLICES, as in the persistent kernel)
     uint32_t seed = 0;
     v3 ro = V(0, 0, 0), rd = V(0, 0, 1), throughput = V(1, 1, 1), rad = V(0, 0, 0), irr = V(0, 0, 0);
 
@@ -1236,7 +1245,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                 cull_spheres(sc, a.numSpheres, valid, to, td, masks);
                 bool tcont = false;
                 if (valid) {
-                    if (0 < a.rayDepth) tcont = bounce_step_t<true, MATLDS>(sc, a.numSpheres, a.numCuboids, env, to, td, tthr, trad, tseed, masks);
+                    if (0 < a.rayDepth) tcont = bounce_step_t<true, MATLDS>(sc, a.numSpheres, a.numCuboids, env, to, td, tthr, trad, tseed, masks, walkFresh);
                     if (1 >= a.rayDepth) tcont = false;
                 }
                 // 1. paths that continue go to the ring
@@ -1315,6 +1324,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                 fj = (e.counters >> 24) & 0x7f;
                 needRay = e.counters < 0;
                 pending = false;
+                walkFrom = -1.0f; // (a fresh path: no unfinished grid walk)
                 seed = e.seed;
                 ro = V(e.ro[0], e.ro[1], e.ro[2]);
                 rd = V(e.rd[0], e.rd[1], e.rd[2]);
@@ -1328,14 +1338,20 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
             idle = pix < 0;
             m = __ballot(idle);
         }
-        const bool active = pix >= 0;
+        bool active = pix >= 0;
         if (__ballot(active) == 0ull) {
             if (exhausted && avail == 0 && parked == 0) break;
             stalled++; // (only waiting records left in the queue: they are retried by the batch passes above)
             if (parked > 0 && avail == 0) __builtin_amdgcn_s_sleep(8);
             continue;
         }
-        if (__ballot(!(active && pending && !needRay)) == 0ull && (avail > 0 || parked > 0)) rescue(); // every lane waits: see above
+        if (__ballot(!(active && pending && !needRay)) == 0ull && (avail > 0 || parked > 0)) {
+            rescue(); // every lane waits: see above
+            // (round 4: the lanes rescue() has just emptied are NOT active any more.  They used to run one bounce of their dead path below —
+            // harmless while a bounce left nothing behind in the lane, but a grid walk cut short (WALK SLICES) leaves walkFrom, and the
+            // path the lane pops next would have resumed someone else's walk: found by tools/handover_stress --multisample)
+            active = pix >= 0;
+        }
         // (a wavefront that has done nothing but wait for FRAME_RETRY_LIMIT iterations in a row gives up the hand-over: waiting
         // records move between lanes, ring and queue, so the bound is kept per wavefront, not per lane)
         stalled = __ballot(pix >= 0 && !pending) == 0ull ? stalled + 1 : 0;
@@ -1350,9 +1366,10 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         bool wantPark = false;
         if (active && !pending) {
             bool cont = false;
-            if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr);
-            bounce++;
-            if (!cont || bounce >= a.rayDepth) {
+            if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr, walkFrom);
+            const bool sliced = GRID && walkFrom >= 0.0f; // (the grid walk of this bounce continues in the next iteration: pt_device.hpp, WALK SLICES)
+            if (!sliced) bounce++;
+            if (!sliced && (!cont || bounce >= a.rayDepth)) {
                 irr = v_add(irr, rad); // compute.glsl:122
                 sample++;
                 if (sample < a.spp) wantPark = true;
@@ -1441,11 +1458,12 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
 #else
         a.parkedMax = PARKED_MAX;
 #endif
-        if (const char *pm = std::getenv("PT_PARKED_MAX")) a.parkedMax = std::atoi(pm) < 0 ? 0 : (std::atoi(pm) > PARKED_MAX ? PARKED_MAX : std::atoi(pm));
+        const Tuning &tune = tuning(); // (pt_tuning.hpp: A/B knobs, set through pt_debug_set only)
+        if (tune.parkedMax >= 0) a.parkedMax = tune.parkedMax > PARKED_MAX ? PARKED_MAX : tune.parkedMax;
         const bool spp1 = a.spp == 1; // tile-pass kernels (the ring holds 60-byte paths instead of 40-byte primary rays)
         // spp > 1: the batch-pass kernel (every sample's first bounce coherent and culled), unless drain compaction is asked
         // for (single-launch frames of the A/B variants and of caller-owned streams keep the in-lane sample chain)
-        static const bool noBatchPass = std::getenv("PT_NO_BATCH_PASS") != nullptr; // A/B runs
+        const bool noBatchPass = tune.noBatchPass != 0; // A/B runs
         // ... and unless frames are pipelined over a SMALL image.  Inside a tagged launch a finished pixel may wait for its
         // previous frame; the batch-pass kernel keeps work outside the lanes (parked continuations), and when consecutive frames
         // of a tile meet in one wavefront — few tiles per frame for the ~5,000 resident wavefronts — every lane, and then the
@@ -1456,7 +1474,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         // such launch through this kernel).  Small images still take the in-lane sample chain — for speed: when consecutive frames
         // of a tile meet in one wavefront all the time, the queue mostly rotates waiting records.  16,384 tiles per frame
         // (1024 x 1024) leave a wavefront 3-4 tiles per frame.
-        static const long long batchPassMinTiles = std::getenv("PT_BATCH_PASS_MIN_TILES") ? std::atoll(std::getenv("PT_BATCH_PASS_MIN_TILES")) : 16384; // (0: stress runs)
+        const long long batchPassMinTiles = tune.batchPassMinTiles; // (16,384; 0: stress runs)
         const bool smallPipelined = a.tagged && (long long)a.tilesX * a.tilesY < batchPassMinTiles;
         const bool useBatchPass = !spp1 && a.drainCompaction == 0 && !noBatchPass && !smallPipelined;
         // the continuation queues take what a 5-per-CU workgroup has left next to the scene and the rings (<= 128 entries per wavefront)
@@ -1465,17 +1483,17 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
             // (31 KB per workgroup: measured, a 32.3 KB workgroup no longer fits five times into the CU's 160 KB)
             const long long left = 31ll * 1024 - (long long)lds - (long long)waves * 64 * (long long)sizeof(PathEntryM);
             park = (int)(left / (long long)(waves * sizeof(ContEntry))) & ~7;
-            if (const char *pc = std::getenv("PT_PARK_CAPACITY")) park = std::atoi(pc) & ~7; // A/B runs
+            if (tune.parkCapacity >= 0) park = tune.parkCapacity & ~7; // A/B runs
             if (park > 128) park = 128;
             if (park < 64) park = 64; // (then the scene's materials leave LDS below)
         }
         a.contCapacity = park;
-        a.contBatchMin = std::getenv("PT_PARK_MIN") ? std::atoi(std::getenv("PT_PARK_MIN")) : 40;
+        a.contBatchMin = tune.parkMin;
         const size_t queues = useBatchPass ? (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry))
                               : (spp1 ? frame_weight_bytes(a.batchFrames) : 0) + (size_t)waves * 64 * (spp1 ? sizeof(PathEntry) + kLaneLastBytes : sizeof(RingEntry)) + (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0) // no pool without drain compaction
                                 + (spp1 && a.tagged && a.drainCompaction == 0 ? (size_t)waves * a.parkedMax * sizeof(ParkedResolve) : 0); // parked resolves of tagged launches
         // Large scenes: the generic bounce walks the sphere grid (ray_trace_t<GRID>); the grid rides in LDS next to the scene
-        static const bool noGrid = std::getenv("PT_NO_SPHERE_GRID") != nullptr; // A/B runs
+        const bool noGrid = tune.noSphereGrid != 0; // A/B runs
         const bool useGrid = a.grid != nullptr && a.gridBytes > 0 && !noGrid && !a.timeline;
         a.gridLdsBytes = useGrid ? (a.gridBytes + 15) & ~15 : 0;
         lds += (size_t)a.gridLdsBytes;
@@ -1486,7 +1504,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         size_t wgFull = ldsPerCU / (ldsTotal + fixedLds), wgLean = ldsPerCU / (ldsLean + fixedLds);
         if (wgFull > (size_t)blocksPerCU) wgFull = (size_t)blocksPerCU;
         if (wgLean > (size_t)blocksPerCU) wgLean = (size_t)blocksPerCU;
-        static const bool forceLean = std::getenv("PT_FORCE_LEAN_LDS") != nullptr; // A/B runs: materials always from the UBO copy
+        const bool forceLean = tune.forceLeanLds != 0; // A/B runs: materials always from the UBO copy
         if (wgLean > wgFull || forceLean || useGrid) { // (the grid kernel is only instantiated for materials in device memory)
             a.materialsInLds = 0;
             ldsTotal = ldsLean;
@@ -1494,8 +1512,11 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
 #ifndef PT_GRID_MIN_WAVES
 #define PT_GRID_MIN_WAVES 6
 #endif
+#ifndef PT_SPP1_WAVES
+#define PT_SPP1_WAVES 6
+#endif
 #define PT_LAUNCH_PERSISTENT(TL, S1, ML) \
-    hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, (S1 ? 6 : 5), TL, S1, ML>), dim3(nwg), dim3(256), ldsTotal, stream, a)
+    hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, (S1 ? PT_SPP1_WAVES : 5), TL, S1, ML>), dim3(nwg), dim3(256), ldsTotal, stream, a)
         const bool matLds = a.materialsInLds != 0;
         if (a.timeline && spp1 && matLds) PT_LAUNCH_PERSISTENT(true, true, true); // per-wavefront timestamps (tools/timeline.py)
         else if (spp1 && matLds) PT_LAUNCH_PERSISTENT(false, true, true);

@@ -63,6 +63,10 @@ struct FrameArgs {
     float gridLo[3], gridHi[3], gridCell[3], gridInvCell[3]; // box, cell size and its reciprocal per axis
     float gridCenter[3];    // a ray uses the grid when its origin lies within sqrt(gridReach2) of the box centre (see ray_trace_t)
     float gridReach2;
+    // Sphere runs (in-order sphere loop, ray_trace_t): bit i is set when sphere i does NOT have the same centre x AND z bits as sphere
+    // i - 1 (bit 0 is always set).  Inside a run the loop reuses o.x - c.x, o.z - c.z and the two products that start the dot-product
+    // chains — the same binary32 values the per-sphere evaluation would produce (pt_sphere_grid.hpp: sphere_runs).
+    unsigned long long sphereRunStart[4];
     // Present snapshot (non-blocking present, mi355pt.cpp pt_present_rgba8_async): when set, the resolve of the launch's LAST frame
     // also stores the pixel's new value here (same indexing as accum) — a consistent image of that frame that later frames never
     // touch, so the tone map can read it while the next launch (chained, ordered per pixel by the tags) already overwrites accum.

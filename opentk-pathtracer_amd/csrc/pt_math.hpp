@@ -109,11 +109,18 @@ PT_DEV void pt_sincos(float a, float &sn, float &cs)
 }
 
 // e^x: n = rint(x*log2 e), two-step fused reduction, degree-6 polynomial, 2^n as two exact power-of-two factors.
+template <bool SELECTED = false>
 PT_DEV float pt_exp(float x)
 {
-    if (x != x) return x;
-    if (x > 88.72283935546875f) return __builtin_inff();
-    if (x < -104.0f) return 0.0f;
+    // SELECTED: the three special cases are selected at the end instead of branched around (same value for every input).  A divergent
+    // early return costs four scalar instructions and a branch (tools/ubench3.hip: a scalar instruction takes 0.8 of a vector
+    // instruction's issue time), and the polynomial runs for some lane of the wavefront anyway; but the selected form keeps three
+    // polynomial chains in flight at once and costs registers, so only the kernel that has them to spare asks for it.
+    if (!SELECTED) {
+        if (x != x) return x;
+        if (x > 88.72283935546875f) return __builtin_inff();
+        if (x < -104.0f) return 0.0f;
+    }
     float n = __builtin_rintf(x * 1.44269504088896341f);
     float r = f_fma(n, -0.693145751953125f, x);
     r = f_fma(n, -1.428606765330187045e-06f, r);
@@ -123,10 +130,16 @@ PT_DEV float pt_exp(float x)
     p = f_fma(p, r, 1.6666665459e-1f);
     p = f_fma(p, r, 5.0000001201e-1f);
     float y = f_fma(p, r * r, r) + 1.0f;
-    int ni = (int)n;
+    int ni = SELECTED ? (int)__builtin_fminf(__builtin_fmaxf(n, -200.0f), 200.0f) : (int)n; // (in range wherever the special cases do not take over)
     int n1 = ni >> 1, n2 = ni - n1;
     y = y * __uint_as_float((uint32_t)(n1 + 127) << 23);
-    return y * __uint_as_float((uint32_t)(n2 + 127) << 23);
+    y = y * __uint_as_float((uint32_t)(n2 + 127) << 23);
+    if (SELECTED) {
+        y = x < -104.0f ? 0.0f : y;
+        y = x > 88.72283935546875f ? __builtin_inff() : y;
+        y = x != x ? x : y;
+    }
+    return y;
 }
 
 PT_DEV float pt_pow5(float x)

@@ -58,6 +58,7 @@ struct pt_renderer {
     unsigned char objectsShadow[PT_GAME_OBJECTS_UBO_SIZE] = {0};
     bool gridDirty = true;
     ptgrid::SphereGrid grid;
+    unsigned long long sphereRunStart[4] = {~0ull, ~0ull, ~0ull, ~0ull}; // FrameArgs::sphereRunStart, rebuilt with the grid
     unsigned char *dGrid = nullptr; // (kMaxCells + 1) * 2 + kMaxRefs bytes
     float *dLut = nullptr;          // 256-entry sRGB table
     unsigned int *dQueue = nullptr; // global chunk-ticket counter of the persistent kernel (never reset: epoch scheme)

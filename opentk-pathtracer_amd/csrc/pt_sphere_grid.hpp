@@ -14,6 +14,8 @@
 #include <cstring>
 #include <vector>
 
+#include "pt_tuning.hpp"
+
 namespace ptgrid {
 
 constexpr int kMinSpheres = 64;   // below this the in-order loop is as fast (default scene: 48 spheres)
@@ -29,11 +31,25 @@ struct SphereGrid {
     int numRefs = 0;
 };
 
+// Sphere runs of the in-order loop (FrameArgs::sphereRunStart): bit i = sphere i starts a new run, i.e. its centre's x or z differs
+// BITWISE from sphere i - 1's (a scene laid out on a lattice, like the reference's LoadScene, MainWindow.cs:208-244, repeats
+// coordinates in consecutive spheres).  Equal bits give equal differences and products, so sharing them changes no result.
+inline void sphere_runs(const float *objects, int ns, unsigned long long out[4])
+{
+    for (int w = 0; w < 4; w++) out[w] = ~0ull; // (spheres beyond ns are never visited)
+    for (int i = 1; i < ns && i < 256; i++) {
+        uint32_t a[3], b[3];
+        std::memcpy(a, objects + 20 * (i - 1), 12);
+        std::memcpy(b, objects + 20 * i, 12);
+        if (a[0] == b[0] && a[2] == b[2]) out[i >> 6] &= ~(1ull << (i & 63));
+    }
+}
+
 // objects: the 26,624-byte std140 block (sphere i: centre.xyz, radius at float 20 * i).
 inline SphereGrid build(const float *objects, int ns)
 {
     SphereGrid g;
-    static const int minSpheres = std::getenv("PT_GRID_MIN_SPHERES") ? std::atoi(std::getenv("PT_GRID_MIN_SPHERES")) : kMinSpheres; // tuning runs
+    const int minSpheres = pt::tuning().gridMinSpheres; // (kMinSpheres unless a tuning run changed it)
     if (ns < minSpheres || ns < 2 || ns > 256) return g;
     double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300}, maxAbs = 0.0;
     std::vector<double> rad(ns);
@@ -91,7 +107,7 @@ inline SphereGrid build(const float *objects, int ns)
     }
     const double reachIn = std::max(0.0, reach - maxMargin) * 0.99; // (compared against an fp32 distance^2: stay inside the analysed range)
     g.reach2 = (float)(reachIn * reachIn);
-    static const int cellTarget = std::getenv("PT_GRID_CELLS") ? std::atoi(std::getenv("PT_GRID_CELLS")) : kMaxCells; // tuning runs
+    const int cellTarget = pt::tuning().gridCells; // (kMaxCells unless a tuning run changed it)
     const int maxCells = std::max(1, std::min(cellTarget, kMaxCells));
     // about 5 cells per 8 spheres (measured on the 256-sphere scene: 8 x 5 x 4 cells beat both coarser and finer grids), cells as
     // cubic as the box allows
@@ -103,11 +119,8 @@ inline SphereGrid build(const float *objects, int ns)
             if (g.dims[k] > g.dims[big]) big = k;
         g.dims[big]--;
     }
-    if (const char *dimsEnv = std::getenv("PT_GRID_DIMS")) { // tuning runs: "x,y,z"
-        int x = 0, y = 0, z = 0;
-        if (std::sscanf(dimsEnv, "%d,%d,%d", &x, &y, &z) == 3 && x > 0 && y > 0 && z > 0 && x * y * z <= kMaxCells) {
-            g.dims[0] = x; g.dims[1] = y; g.dims[2] = z;
-        }
+    if (const int *td = pt::tuning().gridDims; td[0] > 0 && td[1] > 0 && td[2] > 0 && td[0] * td[1] * td[2] <= kMaxCells) { // tuning runs
+        g.dims[0] = td[0]; g.dims[1] = td[1]; g.dims[2] = td[2];
     }
     for (int k = 0; k < 3; k++) {
         g.cell[k] = (float)(ext[k] / g.dims[k]);

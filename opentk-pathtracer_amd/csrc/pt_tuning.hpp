@@ -1,0 +1,78 @@
+// pt_tuning.hpp — the library's tuning knobs (A/B runs, stress tools, tests).
+//
+// The product library reads NO environment variables: a knob only ever changes through pt_debug_set(key, value), an entry point that
+// is exported but NOT declared in include/mi355pt.h (like the other pt_debug_* test aids).  One set of knobs per process, read where
+// they apply (plain loads of this struct — nothing is parsed per launch); a knob affects renderers / launches created after it is set.
+//   Python: native.debug_set("no_sphere_grid", 1); bench.py --tune key=value; tools/handover_stress.bin --tune key=value
+#pragma once
+#include <cstring>
+
+namespace pt {
+
+struct Tuning {
+    // renderer creation (mi355pt.cpp: pt_create)
+    int drainCompaction = -2;      // >= -1: overrides pt_renderer::drainCompaction (-1 = automatic)
+    int batchWorkgroupsPerCU = 0;  // 1..8: workgroups per CU of pipelined launches (default 6)
+    int frameBatch = 0;            // 1..64: initial pt_set_frame_batch
+    int queueChunk = 0;            // 1..1024: tiles per global ticket (0 = automatic)
+    int groupBand = -1;            // group handles: band height (0 = contiguous row blocks; else a multiple of 8)
+    // launches (mi355pt.cpp: launch_frames)
+    int auditSabotage = 0;         // -DPT_AUDIT builds only: every n-th (pixel, frame) folds into a perturbed colour
+    int noSingleTagged = 0;        // 1: single frames never chain
+    int shortWorkgroupsPerCU = 5;  // workgroups per CU of launches of fewer than 8 frames
+    long chainWaitUs = 60000;      // back-pressure: how long a launch waits for its predecessor to become resident
+    // kernel selection (pt_kernels.hip: launch_integrate)
+    int parkedMax = -1;            // >= 0: parked resolves per wavefront
+    int noBatchPass = 0;           // 1: spp > 1 keeps the in-lane sample chain
+    long long batchPassMinTiles = 16384; // pipelined spp > 1 launches over fewer tiles per frame keep the in-lane sample chain
+    int parkCapacity = -1;         // >= 0: parked continuations per wavefront of the batch-pass kernel
+    int parkMin = 40;              // parked continuations that make a batch pass worth running
+    int noSphereGrid = 0;          // 1: large scenes keep the reference's in-order sphere loop
+    int forceLeanLds = 0;          // 1: materials are always read from the UBO copy
+    // sphere grid build (pt_sphere_grid.hpp)
+    int gridMinSpheres = 64;       // scenes with fewer spheres get no grid
+    int gridCells = 256;           // cell budget (<= ptgrid::kMaxCells)
+    int gridDims[3] = {0, 0, 0};   // all > 0: the grid's resolution
+};
+
+inline Tuning &tuning()
+{
+    static Tuning t;
+    return t;
+}
+
+// -> false for an unknown key
+inline bool tuning_set(const char *key, long long v)
+{
+    Tuning &t = tuning();
+#define PT_KNOB(name, field)                 \
+    if (std::strcmp(key, name) == 0) {       \
+        t.field = (decltype(t.field))v;      \
+        return true;                         \
+    }
+    PT_KNOB("drain_compaction", drainCompaction)
+    PT_KNOB("batch_wg", batchWorkgroupsPerCU)
+    PT_KNOB("frame_batch", frameBatch)
+    PT_KNOB("queue_chunk", queueChunk)
+    PT_KNOB("group_band", groupBand)
+    PT_KNOB("audit_sabotage", auditSabotage)
+    PT_KNOB("no_single_tagged", noSingleTagged)
+    PT_KNOB("short_wg", shortWorkgroupsPerCU)
+    PT_KNOB("chain_wait_us", chainWaitUs)
+    PT_KNOB("parked_max", parkedMax)
+    PT_KNOB("no_batch_pass", noBatchPass)
+    PT_KNOB("batch_pass_min_tiles", batchPassMinTiles)
+    PT_KNOB("park_capacity", parkCapacity)
+    PT_KNOB("park_min", parkMin)
+    PT_KNOB("no_sphere_grid", noSphereGrid)
+    PT_KNOB("force_lean_lds", forceLeanLds)
+    PT_KNOB("grid_min_spheres", gridMinSpheres)
+    PT_KNOB("grid_cells", gridCells)
+    PT_KNOB("grid_dim_x", gridDims[0])
+    PT_KNOB("grid_dim_y", gridDims[1])
+    PT_KNOB("grid_dim_z", gridDims[2])
+#undef PT_KNOB
+    return false;
+}
+
+} // namespace pt

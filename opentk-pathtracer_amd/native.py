@@ -222,3 +222,15 @@ def check(rc: int, handle=None) -> int:
         msg = load().pt_last_error(handle)
         raise NativeError(rc, msg.decode() if msg else "")
     return rc
+
+
+def debug_set(key: str, value: int) -> None:
+    """Tuning knob of the library (csrc/pt_tuning.hpp) through pt_debug_set — an exported entry point that include/mi355pt.h does NOT
+    declare.  The product library reads no environment variables; A/B runs, stress tools and a few tests use this instead."""
+    L = load()
+    L.pt_debug_set.argtypes = [C.c_char_p, C.c_longlong]
+    L.pt_debug_set.restype = C.c_int
+    rc = L.pt_debug_set(key.encode(), int(value))
+    if rc != PT_OK:
+        raise NativeError(rc, f"pt_debug_set({key!r}): unknown knob")
+

@@ -613,57 +613,115 @@ static void make_ctx(Ctx *c, const PtoParams *p, const float *basic, const float
     fill_lut(c->srgbLut);
 }
 
-typedef struct {
-    const Ctx *c; float *image; int y0, rows, frame, tid, nthreads; Stats st; int wantStats;
-} Job;
+/* ---- host threading of one frame (bench.py's cpu_baseline leg and the tests).  A persistent pool of worker threads (created on
+ * first use, grown on demand, never more than PTO_MAX_THREADS) renders the frame's rows in DYNAMIC chunks of PTO_CHUNK_ROWS rows
+ * taken from one atomic counter: rows near the floor cost ~2x sky rows, so a static split leaves most threads idle behind the
+ * slowest one, and creating 256 threads per frame costs milliseconds of a sub-second frame.  Which thread renders which row never
+ * changes a pixel (every pixel owns its RNG stream, compute.glsl:106): the image is the same for any thread count (tested). */
+#define PTO_MAX_THREADS 256
+#define PTO_CHUNK_ROWS 4
 
-static void *row_worker(void *arg)
+typedef struct {
+    const Ctx *c; float *image; int y0, rows, frame, wantStats;
+    int nextChunk;               /* atomic: next chunk of PTO_CHUNK_ROWS rows to hand out */
+    Stats st[PTO_MAX_THREADS];   /* per participant (slot 0 = the calling thread) */
+} FrameJob;
+
+static void render_chunks(FrameJob *j, int slot)
 {
-    Job *j = (Job *)arg;
     const Ctx *c = j->c;
-    for (int r = j->tid; r < j->rows; r += j->nthreads) {
-        int y = j->y0 + r;
-        float *row = j->image + (size_t)r * c->width * 4;
-        for (int x = 0; x < c->width; x++) {
-            float out[4];
-            shade_pixel(c, x, y, j->frame, row + 4 * x, out, j->wantStats ? &j->st : NULL);
-            memcpy(row + 4 * x, out, 16);
+    const int chunks = (j->rows + PTO_CHUNK_ROWS - 1) / PTO_CHUNK_ROWS;
+    for (;;) {
+        const int k = __atomic_fetch_add(&j->nextChunk, 1, __ATOMIC_RELAXED);
+        if (k >= chunks) break;
+        const int r1 = (k + 1) * PTO_CHUNK_ROWS < j->rows ? (k + 1) * PTO_CHUNK_ROWS : j->rows;
+        for (int r = k * PTO_CHUNK_ROWS; r < r1; r++) {
+            const int y = j->y0 + r;
+            float *row = j->image + (size_t)r * c->width * 4;
+            for (int x = 0; x < c->width; x++) {
+                float out[4];
+                shade_pixel(c, x, y, j->frame, row + 4 * x, out, j->wantStats ? &j->st[slot] : NULL);
+                memcpy(row + 4 * x, out, 16);
+            }
         }
+    }
+}
+
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t wake, done;
+    pthread_t th[PTO_MAX_THREADS];
+    int created;        /* workers that exist (worker w has slot w + 1) */
+    unsigned long gen;  /* job generation: a worker runs each generation at most once */
+    int wanted;         /* workers with slot <= wanted take part in the current generation */
+    int running;        /* participants of the current generation that have not finished yet */
+    FrameJob *job;
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, { 0 }, 0, 0, 0, 0, NULL };
+
+static void *pool_worker(void *arg)
+{
+    const int slot = (int)(intptr_t)arg;
+    unsigned long seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (g_pool.gen == seen || slot > g_pool.wanted) {
+            if (g_pool.gen != seen && slot > g_pool.wanted) seen = g_pool.gen; /* not invited to this one */
+            pthread_cond_wait(&g_pool.wake, &g_pool.mu);
+        }
+        seen = g_pool.gen;
+        FrameJob *j = g_pool.job;
+        pthread_mutex_unlock(&g_pool.mu);
+        render_chunks(j, slot);
+        pthread_mutex_lock(&g_pool.mu);
+        if (--g_pool.running == 0) pthread_cond_signal(&g_pool.done);
     }
     return NULL;
 }
 
 /* Render one frame into `image` (rows [y0, y0+rows) of the full image, tightly packed RGBA32F, row 0 = y0),
  * accumulating onto its current contents exactly like one PathTracer.Render() call (PathTracer.cs:114-123).
- * stats (optional, 6 x uint64): samples, bounces, sphereTests, cuboidTests, envLookups, reserved. */
+ * stats (optional, 6 x uint64): samples, bounces, sphereTests, cuboidTests, envLookups, reserved.
+ * Not re-entrant (one frame at a time per process: the pool is shared); the callers are single-threaded test / bench code. */
 PTO_API int pto_render_frame(const PtoParams *p, const float *basic144, const float *objects26624, const void *env,
                              float *image, int y0, int rows, int frame, int nthreads, uint64_t *stats)
 {
+    static pthread_mutex_t serial = PTHREAD_MUTEX_INITIALIZER;
     Ctx c;
     make_ctx(&c, p, basic144, objects26624, env);
     if (nthreads < 1) nthreads = 1;
-    if (nthreads > 256) nthreads = 256;
-    if (nthreads > rows) nthreads = rows > 0 ? rows : 1; /* thread t renders rows t, t + nthreads, ...: more threads than rows would idle */
-    pthread_t th[256];
-    int started[256];
-    Job jobs[256];
-    for (int t = 0; t < nthreads; t++) {
-        Job j = { &c, image, y0, rows, frame, t, nthreads, { 0, 0, 0, 0, 0, 0 }, stats != NULL };
-        jobs[t] = j;
-        /* a thread that cannot be created (EAGAIN under a process limit) must not leave its rows unrendered: run them here */
-        started[t] = nthreads > 1 && pthread_create(&th[t], NULL, row_worker, &jobs[t]) == 0;
+    if (nthreads > PTO_MAX_THREADS) nthreads = PTO_MAX_THREADS;
+    const int chunks = (rows + PTO_CHUNK_ROWS - 1) / PTO_CHUNK_ROWS;
+    if (nthreads > chunks) nthreads = chunks > 0 ? chunks : 1; /* more threads than chunks would idle */
+    static FrameJob job; /* (16 KB of per-thread statistics: not on the stack) */
+    pthread_mutex_lock(&serial);
+    memset(&job, 0, sizeof job);
+    job.c = &c; job.image = image; job.y0 = y0; job.rows = rows; job.frame = frame; job.wantStats = stats != NULL;
+    int helpers = nthreads - 1;
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.created < helpers) { /* grow the pool; a thread that cannot be created (EAGAIN) just means fewer helpers */
+        if (pthread_create(&g_pool.th[g_pool.created], NULL, pool_worker, (void *)(intptr_t)(g_pool.created + 1)) != 0) break;
+        pthread_detach(g_pool.th[g_pool.created]);
+        g_pool.created++;
     }
-    for (int t = 0; t < nthreads; t++) {
-        if (started[t]) pthread_join(th[t], NULL);
-        else row_worker(&jobs[t]);
-    }
+    if (helpers > g_pool.created) helpers = g_pool.created;
+    g_pool.job = &job;
+    g_pool.wanted = helpers;
+    g_pool.running = helpers;
+    g_pool.gen++;
+    if (helpers > 0) pthread_cond_broadcast(&g_pool.wake);
+    pthread_mutex_unlock(&g_pool.mu);
+    render_chunks(&job, 0); /* the calling thread takes chunks too (and all of them when it has no helpers) */
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.running > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
     if (stats) {
         memset(stats, 0, 6 * sizeof(uint64_t));
-        for (int t = 0; t < nthreads; t++) {
-            stats[0] += jobs[t].st.samples; stats[1] += jobs[t].st.bounces; stats[2] += jobs[t].st.sphereTests;
-            stats[3] += jobs[t].st.cuboidTests; stats[4] += jobs[t].st.envLookups;
+        for (int t = 0; t <= helpers; t++) {
+            stats[0] += job.st[t].samples; stats[1] += job.st[t].bounces; stats[2] += job.st[t].sphereTests;
+            stats[3] += job.st[t].cuboidTests; stats[4] += job.st[t].envLookups;
         }
     }
+    pthread_mutex_unlock(&serial);
     return 0;
 }
 

@@ -267,6 +267,35 @@ def gen_convergence():
              env_key=np.array(w.env), iparams=ip, fparams=fp, mean=mean.astype(np.float32), stderr=se.astype(np.float32))
 
 
+def gen_edge_nanenv():
+    """The quirk scene's per-SAMPLE record: for 64 frames of the `edge` scene (total internal reflection ->
+    normalize(vec3(0)) = NaN direction -> texture(SamplerEnvironment, NaN), undefined in GL) the reference's running means after
+    every frame, and — from the oracle's diagnostic build (oracle/Makefile: nanmark) — which (frame, pixel) samples END in such a
+    NaN-direction environment lookup.  tests/test_live_reference.py makes the same comparison against the live llvmpipe run; this
+    fixture lets the GPU box make it (the HIP path equals the oracle bit for bit, so the oracle's flags are the HIP path's)."""
+    print("edge scene: per-frame reference accumulation + NaN-direction lookup flags:")
+    import __graft_entry__ as graft
+    O = graft.load_oracle()
+    plain, marked = O.Oracle(), O.Oracle(mark_nan_env=True)
+    w = configs.Workload("edge_64x36_d16", "edge", 64, 36, 16, "sky_f32_32", frames=64)
+    sc, basic, objs, env, kw = configs.inputs(w)
+    acc_ref = ref.run_pathtracer(w.width, w.height, basic, objs, env, num_frames=w.frames, dump_each=True, **kw)[..., :3]
+    acc = [x.render(w.width, w.height, basic, objs, env, num_frames=w.frames, dump_each=True, **kw)[..., :3].astype(np.float64)
+           for x in (plain, marked)]
+
+    def samples(a):
+        s_ = np.empty_like(a)
+        s_[0] = a[0]
+        for k in range(1, len(a)):
+            s_[k] = (k + 1) * a[k] - k * a[k - 1]
+        return s_
+    nan_env = np.abs(samples(acc[1]) - samples(acc[0])).max(-1) > 10.0
+    ip, fp = params_array(w, kw)
+    print(f"   {int(nan_env.sum())} of {nan_env.size} samples end in a NaN-direction lookup")
+    save("edge_nanenv_" + w.name, basic=np.frombuffer(basic, np.uint8), objects=np.frombuffer(objs, np.uint8), env_key=np.array(w.env),
+         iparams=ip, fparams=fp, expected_each=acc_ref.astype(np.float32), nan_env=np.packbits(nan_env.reshape(-1)))
+
+
 def gen_bench_fixture():
     """Only what round 2 added (keeps every older fixture byte-identical): the atmosphere_64 cube + the sparse fixture of
     the exact workload bench.py times."""
@@ -279,7 +308,7 @@ def gen_bench_fixture():
     gen_sparse(only={configs.C2_ATMO.name})
 
 
-GROUPS = {"bench": gen_bench_fixture, "converged": gen_converged, "convergence": gen_convergence, "post": gen_post, "envs": gen_envs, "micro": gen_micro, "frames": gen_frames, "envonly": gen_envonly, "sparse": gen_sparse,
+GROUPS = {"edge": gen_edge_nanenv, "bench": gen_bench_fixture, "converged": gen_converged, "convergence": gen_convergence, "post": gen_post, "envs": gen_envs, "micro": gen_micro, "frames": gen_frames, "envonly": gen_envonly, "sparse": gen_sparse,
           "atmo": gen_atmo}
 
 if __name__ == "__main__":

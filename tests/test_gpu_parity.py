@@ -174,9 +174,12 @@ def test_frame_pipelining_survives_oversubscription(pkg, native_lib, oracle, spp
     """More workgroups than the GPU can keep resident (8 per CU requested; registers allow 6 resp. 5): a workgroup that
     starts late must not own early (frame, tile) work that running workgroups wait for — every chunk of a pipelined
     launch is drawn from the global counter.  (With static first chunks this configuration deadlocks.)"""
-    monkeypatch.setenv("PT_BATCH_WG", "8")
-    w = configs.Workload("oversub", "default", 640, 360, 5, "sky_f32_32", frames=24, spp=spp)
-    got = hip_render(pkg, w)
+    pkg.native.debug_set("batch_wg", 8)  # (a tuning knob of the library: csrc/pt_tuning.hpp)
+    try:
+        w = configs.Workload("oversub", "default", 640, 360, 5, "sky_f32_32", frames=24, spp=spp)
+        got = hip_render(pkg, w)
+    finally:
+        pkg.native.debug_set("batch_wg", 0)
     xy = np.stack([np.arange(0, 640 * 360, 97) % 640, np.arange(0, 640 * 360, 97) // 640], 1)
     sc, basic, objs, env, kw = configs.inputs(w)
     want = None
@@ -701,6 +704,22 @@ def test_converged_accumulation_vs_reference(pkg, native_lib):
     assert psnr > 50.0
     rel = np.abs(got - ref) / np.maximum(np.abs(ref), 0.05)
     assert (rel.max(-1) < 0.02).mean() > 0.99 and abs(got.mean() - ref.mean()) < 1e-3 * ref.mean()
+
+
+def test_edge_scene_differences_are_nan_direction_lookups(pkg, native_lib):
+    """The quirk scene on the GPU (fixture from tests/golden/make_golden.py `edge`): 64 frames, read back after every
+    frame; per sample, every gross difference from the reference GLSL ends in a NaN-direction environment lookup (flags from the
+    oracle's diagnostic build, which the HIP path equals bit for bit) or belongs to the branch-flip budget."""
+    fx = fixtures.load("edge_nanenv_edge_64x36_d16")
+    pt = fixtures.hip_tracer(pkg, fx)
+    acc = []
+    for _ in range(fx["frames"]):
+        pt.Render()
+        acc.append(pt.Result[..., :3].copy())
+    pt.Dispose()
+    st = fixtures.edge_nanenv_check(fx, np.stack(acc))
+    assert st["nan_env"] > 100, "the scene no longer exercises the quirk"
+    assert st["gross_unflagged"] <= 3e-4 * st["samples"] and st["masked_mean_rel_err"] <= 4e-4, st
 
 
 def test_external_stream_and_interleaved_uploads(pkg, native_lib, oracle):

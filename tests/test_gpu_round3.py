@@ -4,7 +4,7 @@
     C ABI, every observed image compared bit for bit with the same sequence rendered by the simplest kernel) against the
     product library and against the -DPT_AUDIT -DPT_CHAOS build, whose kernels mirror every pixel read-modify-write with a
     device-scope atomic side word and inject random delays at the protocol's decision points (csrc/pt_kernels.hip);
-  * the spp > 1 batch-pass kernel forced onto tiny pipelined images (PT_BATCH_PASS_MIN_TILES=0), where round 2 saw its
+  * the spp > 1 batch-pass kernel forced onto tiny pipelined images (tuning knob batch_pass_min_tiles = 0), where round 2 saw its
     hand-over stall, and a pipelined spp > 1 launch at >= 16,384 tiles per frame (advisor finding, round 2);
   * REAL peers: everything the group-handle / RCCL tests do with device 0 named several times, on distinct devices — skipped
     on a one-GPU box, parametrised on pt_device_count() otherwise (the reference is single-GPU,
@@ -30,10 +30,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _stress(pkg, lib, cases, seed, *extra, env=None, timeout=600):
+def _stress(pkg, lib, cases, seed, *extra, timeout=600):
     tool = pkg.native.build_stress_tool()
-    e = dict(os.environ, **(env or {}))
-    p = subprocess.run([tool, lib, str(cases), str(seed), *extra], capture_output=True, text=True, timeout=timeout, env=e)
+    p = subprocess.run([tool, lib, str(cases), str(seed), *extra], capture_output=True, text=True, timeout=timeout)
     tail = "\n".join(p.stdout.strip().splitlines()[-25:])
     assert p.returncode == 0, f"handover_stress failed (rc {p.returncode}):\n{tail}\n{p.stderr[-2000:]}"
     assert "0 failures, 0 audit violations" in p.stdout, tail
@@ -57,14 +56,13 @@ def test_handover_stress_audit_chaos_build(pkg, native_lib):
 
 
 def test_audit_build_detects_a_broken_handover(pkg, native_lib):
-    """The audit is not vacuous: PT_AUDIT_SABOTAGE makes the audit build fold every 97th tagged (pixel, frame) into a perturbed
+    """The audit is not vacuous: the `audit_sabotage` knob makes the audit build fold every 97th tagged (pixel, frame) into a perturbed
     colour, as a stale or torn 16-byte read would — the stress tool must then report audit violations and wrong images."""
     lib = pkg.native.variant_path("audit")
     if not os.path.exists(lib):
         pkg.native.build_variant("audit")
     tool = pkg.native.build_stress_tool()
-    p = subprocess.run([tool, lib, "200", "303", "--no-ops"], capture_output=True, text=True, timeout=120,
-                       env=dict(os.environ, PT_AUDIT_SABOTAGE="97"))
+    p = subprocess.run([tool, lib, "200", "303", "--no-ops", "--tune", "audit_sabotage=97"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 1 and "AUDIT violation" in p.stdout, p.stdout[-2000:]
 
 
@@ -72,9 +70,9 @@ def test_multisample_batch_pass_forced_onto_tiny_images(pkg, native_lib):
     """Round 2's stall: pipelined spp > 1 launches over a few tiles through the batch-pass kernel (lanes and queue fill up with
     results that wait for work parked in the same wavefront).  The forced batch pass must keep that work moving: no error
     code, no slow case, every image right — product library and audit + chaos build."""
-    env = {"PT_BATCH_PASS_MIN_TILES": "0"}
-    print(_stress(pkg, pkg.native.LIB_PATH, 1200, 304, "--multisample", env=env))
-    print(_stress(pkg, pkg.native.variant_path("audit_chaos"), 600, 305, "--multisample", env=env))
+    tune = ("--tune", "batch_pass_min_tiles=0")  # (a tuning knob of the library: csrc/pt_tuning.hpp)
+    print(_stress(pkg, pkg.native.LIB_PATH, 1200, 304, "--multisample", *tune))
+    print(_stress(pkg, pkg.native.variant_path("audit_chaos"), 600, 305, "--multisample", *tune))
 
 
 def test_round2_stall_reproducer_through_the_batch_pass_kernel(pkg, native_lib, oracle):
@@ -86,6 +84,7 @@ import numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
 import __graft_entry__ as g
 pkg = g.load_package(); oracle = g.load_oracle().Oracle(); S = pkg.scene
+pkg.native.debug_set('batch_pass_min_tiles', 0)  # every pipelined spp > 1 launch through the batch-pass kernel
 rng = np.random.RandomState(5); sc = S.Scene()
 for i in range(200):
     sc.spheres.append(S.Sphere(rng.uniform([-18, -11, -20], [18, 11, 0]).astype(np.float32), np.float32(0.6 * rng.uniform(0.2, 1.5)), i, S.Material(albedo=rng.rand(3))))
@@ -102,8 +101,7 @@ for rep in range(40):
     assert (got.view(np.uint32) == want.view(np.uint32)).all(), rep
 print('OK worst %%.3f s' %% worst); assert worst < 2.0
 """ % (ROOT, ROOT)
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, PT_BATCH_PASS_MIN_TILES="0"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "OK worst" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
 
 

@@ -308,3 +308,15 @@ def test_per_pixel_convergence_against_the_reference(oracle):
     print(st)
     assert st["nan_mismatch"] == 0 and st["pixels"] == fx["width"] * fx["height"]
     assert st["max_abs_z"] <= tol.CONV_MAX_ABS_Z and st["rms_z"] <= tol.CONV_RMS_Z and st["mean_rel_err"] <= tol.CONV_MEAN_REL_TOL, st
+
+
+def test_edge_scene_differences_are_nan_direction_lookups_fixture(oracle):
+    """The committed form of tests/test_live_reference.py's edge-scene test: per sample, the only gross differences
+    between this arithmetic and the reference on the quirk scene end in texture(SamplerEnvironment, NaN) — undefined in GL."""
+    fx = fixtures.load("edge_nanenv_edge_64x36_d16")
+    acc = oracle.render(fx["width"], fx["height"], fx["basic"], fx["objects"], fx["env"], num_frames=fx["frames"], dump_each=True,
+                        **fixtures.kwargs(fx))[..., :3]
+    st = fixtures.edge_nanenv_check(fx, acc)
+    print(st)
+    assert st["nan_env"] > 100, "the scene no longer exercises the quirk"
+    assert st["gross_unflagged"] <= 3e-4 * st["samples"] and st["masked_mean_rel_err"] <= 4e-4, st

@@ -51,6 +51,7 @@ struct Api {
     int (*device_count)(void);
     const char *(*last_error)(H);
     int (*audit_read)(H, unsigned int *, int);
+    int (*debug_set)(const char *, long long);
 };
 
 static bool load_api(const char *path, Api &a)
@@ -72,7 +73,7 @@ static bool load_api(const char *path, Api &a)
     SYM(render, "pt_render") SYM(set_batch, "pt_set_frame_batch") SYM(read, "pt_read_result") SYM(present, "pt_present_rgba8")
     SYM(present_async, "pt_present_rgba8_async") SYM(present_wait, "pt_present_wait") SYM(sync, "pt_synchronize")
     SYM(devptr, "pt_result_device_ptr") SYM(set_variant, "pt_set_variant") SYM(device_count, "pt_device_count")
-    SYM(last_error, "pt_last_error") SYM(audit_read, "pt_debug_audit_read")
+    SYM(last_error, "pt_last_error") SYM(audit_read, "pt_debug_audit_read") SYM(debug_set, "pt_debug_set")
 #undef SYM
     return true;
 }
@@ -313,7 +314,7 @@ static const char *kOpNames[] = {"render", "read", "present", "present_async", "
 int main(int argc, char **argv)
 {
     if (argc < 4) {
-        std::fprintf(stderr, "usage: %s <lib.so> <cases> <seed> [--only N] [--repeat N] [--verbose] [--devices a,b,..] [--max-parts N] [--no-ops] [--fresh] [--multisample] [--ref-lib lib.so]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <lib.so> <cases> <seed> [--only N] [--repeat N] [--verbose] [--devices a,b,..] [--max-parts N] [--no-ops] [--fresh] [--multisample] [--ref-lib lib.so] [--tune key=value ...]\n", argv[0]);
         return 2;
     }
     const char *libPath = argv[1], *refPath = argv[1];
@@ -323,6 +324,7 @@ int main(int argc, char **argv)
     int repeat = 1, maxParts = 5;
     bool verbose = false, withOps = true, freshHandles = false, multisample = false;
     std::vector<int> devices = {0};
+    std::vector<std::pair<std::string, long long>> tune; // the library's tuning knobs (csrc/pt_tuning.hpp), set through pt_debug_set
     for (int i = 4; i < argc; i++) {
         std::string s = argv[i];
         if (s == "--only" && i + 1 < argc) only = std::atol(argv[++i]);
@@ -333,6 +335,12 @@ int main(int argc, char **argv)
         else if (s == "--multisample") multisample = true;
         else if (s == "--max-parts" && i + 1 < argc) maxParts = std::atoi(argv[++i]);
         else if (s == "--ref-lib" && i + 1 < argc) refPath = argv[++i];
+        else if (s == "--tune" && i + 1 < argc) {
+            std::string kv = argv[++i];
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos) { std::fprintf(stderr, "--tune wants key=value\n"); return 2; }
+            tune.push_back({kv.substr(0, eq), std::atoll(kv.c_str() + eq + 1)});
+        }
         else if (s == "--devices" && i + 1 < argc) {
             devices.clear();
             for (char *tok = std::strtok(argv[++i], ","); tok; tok = std::strtok(nullptr, ",")) devices.push_back(std::atoi(tok));
@@ -342,6 +350,11 @@ int main(int argc, char **argv)
     if (!load_api(libPath, a)) return 2;
     if (std::string(refPath) == libPath) ref = a;
     else if (!load_api(refPath, ref)) return 2;
+    for (const auto &kv : tune)
+        if (a.debug_set(kv.first.c_str(), kv.second) != 0 || (std::string(refPath) != libPath && ref.debug_set(kv.first.c_str(), kv.second) != 0)) {
+            std::fprintf(stderr, "unknown tuning knob %s\n", kv.first.c_str());
+            return 2;
+        }
     if (a.device_count() < 1) {
         std::fprintf(stderr, "no HIP device\n");
         return 2;

@@ -11,7 +11,7 @@ prof ${RND}_d13 default_1920x1080_d13_spp1_atmosphere256_g1 --depth 13
 prof ${RND}_C3spp4 stress256_1920x1080_d8_spp4_atmosphere256_g1 --config C3 --spp 4
 prof ${RND}_4k default_3840x2160_d8_spp1_atmosphere256_g1_strong4k --strong-4k
 prof ${RND}_variant14 default_1920x1080_d8_spp1_atmosphere256_g1_variant14 --variant 14
-PT_NO_SPHERE_GRID=1 prof ${RND}_C3nogrid stress256_1920x1080_d8_spp1_atmosphere256_g1_nogrid --config C3
+prof ${RND}_C3nogrid stress256_1920x1080_d8_spp1_atmosphere256_g1_nogrid --config C3 --tune no_sphere_grid=1
 unset PROFILE_NO_CAL PROFILE_PASSES PROFILE_BENCH_EXTRA PROFILE_STEPS PROFILE_WARMUP
 bash tools/bench_configs.sh > gpurun_out/$RND/bench_configs.log 2>&1; cp gpurun_out/bench_configs.jsonl gpurun_out/$RND/
 tail -13 gpurun_out/$RND/bench_configs.log
