@@ -209,7 +209,7 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
         const pt::Tuning &t = pt::tuning();
         if (t.drainCompaction >= -1) h->drainCompaction = t.drainCompaction;
         if (t.batchWorkgroupsPerCU >= 1 && t.batchWorkgroupsPerCU <= 8) h->batchWorkgroupsPerCU = t.batchWorkgroupsPerCU;
-        if (t.frameBatch >= 1 && t.frameBatch <= 64) h->maxBatch = t.frameBatch;
+        if (t.frameBatch >= 1 && t.frameBatch <= 64) { h->maxBatch = t.frameBatch; h->maxBatchExplicit = true; }
         if (t.queueChunk >= 1 && t.queueChunk <= 1024) h->queueChunk = t.queueChunk;
     }
     h->width = width;
@@ -931,7 +931,7 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     // per launch when the batch size was left at its default: every launch boundary costs ~0.1 ms of drain + ramp, 7 % of a 64-frame
     // launch there; spp > 1 keeps 64, its kernels carry the frame index in 7 bits)
     int maxBatch = h->maxBatch;
-    if (maxBatch == 64 && h->spp == 1 && (long long)((h->width + 7) / 8) * ((h->rows + 7) / 8) < 12000) maxBatch = 256;
+    if (!h->maxBatchExplicit && h->spp == 1 && (long long)((h->width + 7) / 8) * ((h->rows + 7) / 8) < 12000) maxBatch = 256;
     if (!batchable || h->pendingFrames >= maxBatch || !gpu_busy(h)) return flush_frames(h);
     return PT_OK;
 }
@@ -1035,8 +1035,12 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
             // wave priority, the next launch is already resident on the other stream).  Only the NEXT-BUT-ONE launch queues behind it.
             // Not on the copy stream: tone map + 150 us copy in one queue would bound the display rate; not on a stream of its own: a
             // fourth busy stream shares a hardware queue with a launch stream and would run behind the next launch.
+            // (a slot the host reuses before its previous copy has landed: wait for that copy HERE, on the host — queued on the launch's
+            // stream instead, the next-but-one integrator launch would stall behind a PCIe copy.  A host that calls pt_present_wait
+            // on a slot before it presents into it again, as the header recommends, never waits here)
+            if (s.inFlight && hipEventQuery(s.copied) != hipSuccess) PT_HIP(h, hipEventSynchronize(s.copied));
+            (void)hipGetLastError(); // (hipErrorNotReady of the query is not an error)
             for (const pt_renderer::SnapLaunch &l : h->snapLaunches) {
-                if (s.inFlight) PT_HIP(h, hipStreamWaitEvent(l.stream, s.copied, 0)); // the slot's previous copy still reads its device image
                 PT_HIP(h, pt::launch_postprocess(h->dSnap[k] + l.firstPixel, (char *)image + l.firstPixel * 4, l.pixels, l.stream));
                 PT_HIP(h, hipEventRecord(l.done, l.stream)); // "launch done" now includes its tone map
                 PT_HIP(h, hipStreamWaitEvent(h->copyStream, l.done, 0));
@@ -1388,6 +1392,7 @@ PT_API int pt_set_frame_batch(pt_handle h, int max_frames)
     PT_FAN_OUT(h, pt_set_frame_batch(part, max_frames));
     if (int rc = flush_frames(h)) return rc;
     h->maxBatch = max_frames;
+    h->maxBatchExplicit = true; // (a limit the host asked for bounds latency and deferral: never raised behind its back)
     return PT_OK;
 }
 

@@ -403,11 +403,11 @@ PT_DEV int queue_pop_tile(BlockQueue *q)
                 CHAOS(2);
                 if (leader) ticket = atomicAdd(ca->queue, 1u) - ca->queueBase;
                 ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
-                long long first = ((ca->tagged ? 0ll : (long long)gridDim.x) + ticket) * chunk; // tagged launches have no static chunks
+                const long long first = ((ca->tagged ? 0ll : (long long)gridDim.x) + ticket) * chunk; // tagged launches have no static chunks
+                const long long last = first + chunk < numTiles ? first + chunk : numTiles;
                 if (first >= numTiles) {
                     if (leader) lds_store(&q->done, 1u);
                 } else {
-                    long long last = first + chunk < numTiles ? first + chunk : numTiles;
                     if (leader) atomicExch(&q->pair, ((unsigned long long)last << 32) | (unsigned long long)first);
                 }
             }
@@ -1447,6 +1447,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         if (a.spp != 1 && blocksPerCU > 5) blocksPerCU = 5; // the kernels without tile pass need 88 VGPRs: 5 wavefronts per SIMD
         int nwg = a.numCUs * blocksPerCU;
         if (a.batchFrames < 1 || a.batchFrames > MAX_BATCH_FRAMES) return hipErrorInvalidValue;
+        if (a.batchFrames > 64) a.drainCompaction = 0; // (the drain pool's records keep the frame of the batch in 6 bits)
         int numChunks = (int)(((long long)tiles * a.batchFrames + a.queueChunk - 1) / a.queueChunk); // (frame, tile) pairs
         if (nwg > numChunks) nwg = numChunks;
         if (nwg < 1) nwg = 1;

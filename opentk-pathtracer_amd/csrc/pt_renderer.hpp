@@ -65,13 +65,14 @@ struct pt_renderer {
     // error word of the frame pipelining: ONE page-locked host word the kernels can reach (mapped): it is only ever
     // written when a hand-over fails, and the host reads it without a copy once the stream is drained
     unsigned int *hostErrWord = nullptr, *devErrWord = nullptr;
-    int queueChunk = 0;             // tiles per global ticket; 0 = automatic (PT_QUEUE_CHUNK overrides, for tuning runs)
+    int queueChunk = 0;             // tiles per global ticket; 0 = automatic (tuning knob queue_chunk)
     unsigned long long *dTimeline = nullptr; // tuning only (pt_debug_timeline)
     // Frame pipelining: consecutive pt_render calls are collected and launched as ONE batch kernel (see pt_kernels.hip)
     // when nothing observable happens in between; every other entry point launches what is pending first.
     int pendingFrames = 0;        // frames accepted by pt_render, not launched yet
-    int maxBatch = 64;            // PT_FRAME_BATCH=1 turns batching off (every pt_render launches at once)
-    int batchWorkgroupsPerCU = 6; // grid of the batch kernel (PT_BATCH_WG, tuning)
+    int maxBatch = 64;            // pt_set_frame_batch: 1 turns batching off (every pt_render launches at once)
+    bool maxBatchExplicit = false; // the host called pt_set_frame_batch: its limit is kept as given (no automatic 256-frame launches)
+    int batchWorkgroupsPerCU = 6; // grid of the batch kernel (tuning knob batch_wg)
     bool batchLaunched = false;   // a batch kernel ran since the last error-word check
     int rendersSincePresent = 0;  // pt_render calls since the last pt_present_rgba8_async ...
     int presentCadence = 0;       // ... and how many there were before that present (1 = the host presents every frame)
@@ -99,7 +100,7 @@ struct pt_renderer {
     bool flushFinal = false;           // the flush comes from an entry point that joins the streams: its launch stores alpha = 1 last
     bool sawBatch = false;             // the host has pipelined frames before: single frames launch tagged too, so that they overlap
     bool stripeInFlight[ptimpl::kMaxStripes] = {false, false, false, false}; // same for the stripe streams
-    int drainCompaction = -1;      // donate threshold in live paths (<= 32), 0 = off, -1 = auto; env PT_DRAIN_COMPACTION
+    int drainCompaction = -1;      // donate threshold in live paths (<= 32), 0 = off, -1 = auto; tuning knob drain_compaction
     int numCUs = 256;
     void *dEnv = nullptr; // current environment cube
     size_t envBytes = 0;

@@ -47,7 +47,7 @@ def _worker(rank, world, port, height, out_path, band=0):
         off = 0
         for b0 in range(rank * band, height, world * band):  # one oracle call per owned band
             n = min(band, height - b0)
-            img = oracle.render(wl.width, wl.height, basic, objs, env, num_frames=2, y0=b0, rows=n, threads=2, **kw)
+            img = oracle.render(wl.width, wl.height, basic, objs, env, num_frames=2, y0=b0, rows=n, threads=1 if world > 3 else 2, **kw)
             tile[off:off + n] = t.from_numpy(img)
             off += n
         assert off == len(mine)
@@ -69,7 +69,9 @@ def _worker(rank, world, port, height, out_path, band=0):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height,band", [(2, 36, 0), (3, 37, 0), (2, 43, 8)])
+# (8, 2160, 16): the row partition of BASELINE configs[3] — 3840x2160 over 8 GPUs in 16-row bands (135 bands: seven ranks own 17, one
+# owns 16) — at the full height and a narrow width (the partition only concerns rows), RGBA32F and RGBA8 gathers included
+@pytest.mark.parametrize("world,height,band", [(2, 36, 0), (3, 37, 0), (2, 43, 8), (8, 2160, 16), (8, 1080, 16)])
 def test_tiled_present_over_gloo(tmp_path, oracle, world, height, band):
     out = str(tmp_path / "full.npy")
     port = _free_port()
