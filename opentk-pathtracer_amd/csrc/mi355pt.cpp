@@ -572,7 +572,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     // stripes); a host that lets the GPU run dry between its frames (blocking reads / presents) keeps the stripes, which are the
     // faster way to render ONE frame on an idle machine.
     const bool noSingleTagged = pt::tuning().noSingleTagged != 0; // A/B runs
-    const bool chainable = h->variant == 0 && !h->externalStream() && h->dTimeline == nullptr;
+    const bool chainable = h->variant == 0 && !h->externalStream() && !ptimpl::timeline_blocks_pipelining(h);
     // (also the first frame of a burst on an idle GPU once the host has pipelined frames before: the batch that follows then chains
     // on it instead of waiting behind two joined stripes — the driver's `--steps 20` command: 15.4 instead of 14.8 Gsamples/s)
     const bool tagged = h->variant == 0 && (n > 1 || (chainable && !noSingleTagged && (gpu_busy(h) || (h->sawBatch && h->presentCadence != 1))));
@@ -914,7 +914,7 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     // (only the first pt_render after a present is treated that way: a host that goes on rendering without presenting gets
     // its frames pipelined again)
     const bool presentsEveryFrame = h->presentCadence == 1 && h->rendersSincePresent == 0;
-    const bool batchable = h->variant == 0 && h->maxBatch > 1 && h->dTimeline == nullptr && !h->externalStream() && !presentsEveryFrame;
+    const bool batchable = h->variant == 0 && h->maxBatch > 1 && !ptimpl::timeline_blocks_pipelining(h) && !h->externalStream() && !presentsEveryFrame;
     h->rendersSincePresent++;
     h->pendingFrames++;
     h->frame++; // PathTracer.cs:117 post-increment
@@ -923,7 +923,7 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     // attached: the launch stores the frame's pixels a second time while it resolves them (FrameArgs::snapshot), the present that
     // follows tone-maps that copy, and the tone map never stands between two frames.  (Launched NOW, not by the present: a host
     // that first waits for a present slot and then presents must find the GPU busy.  If no present follows, the copy is ignored.)
-    if (presentsEveryFrame && (h->variant == 0 || h->variant >= 10) && !h->externalStream() && h->dTimeline == nullptr)
+    if (presentsEveryFrame && (h->variant == 0 || h->variant >= 10) && !h->externalStream() && !ptimpl::timeline_blocks_pipelining(h))
         return ptimpl::flush_with_snapshot(h);
     // Frames are only held back while the GPU still has integrator work of this handle in flight: deferring can then
     // never idle the device, and a host that leaves time between its frames gets every frame launched at once.
@@ -1024,7 +1024,7 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
     // ---- snapshot path: the launch of the frames shown writes its last frame into a snapshot buffer while it resolves the pixels;
     // the tone map follows that launch on its stream, the copy on the copy stream, and nothing waits for them: the next pt_render
     // chains its launch beside this one.
-    const bool snapshotCapable = (h->variant == 0 || h->variant >= 10) && !h->externalStream() && h->dTimeline == nullptr;
+    const bool snapshotCapable = (h->variant == 0 || h->variant >= 10) && !h->externalStream() && !ptimpl::timeline_blocks_pipelining(h);
     if (snapshotCapable && h->pendingFrames > 0)
         if (int rc = ptimpl::flush_with_snapshot(h)) return rc;
     if (snapshotCapable && h->pendingFrames == 0 && h->snapFrame == h->frame && !h->snapLaunches.empty()) {

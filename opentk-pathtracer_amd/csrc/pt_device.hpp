@@ -4,24 +4,9 @@
 //   /root/reference/OpenTK-PathTracer/res/shaders/PathTracing/compute.glsl
 // it implements; the arithmetic is the "pt-f32" contract of pt_math.hpp (bit-identical to oracle/pt_oracle.c).
 #pragma once
+#include "pt_debug_hooks.hpp"
 #include "pt_kernels.hpp"
 #include "pt_math.hpp"
-
-// Section profiling (tuning builds only: hipcc -DPT_PROFILE): per-wavefront s_memtime deltas accumulated per section of
-// the bounce iteration and added to FrameArgs::timeline[0..7] at the end.  Compiled out of the product build.
-#ifdef PT_PROFILE
-#define PROF_PARAM , unsigned long long *prof
-#define PROF_PASS , prof
-#define PROF_DUMMY , prof_dummy
-#define PROF_BEGIN unsigned long long prof_t = __builtin_readcyclecounter();
-#define PROF_MARK(slot) { unsigned long long n_ = __builtin_readcyclecounter(); prof[slot] += n_ - prof_t; prof_t = n_; }
-#else
-#define PROF_PARAM
-#define PROF_PASS
-#define PROF_DUMMY
-#define PROF_BEGIN
-#define PROF_MARK(slot)
-#endif
 
 namespace pt {
 

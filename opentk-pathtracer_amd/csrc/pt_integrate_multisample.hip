@@ -1,0 +1,372 @@
+// pt_integrate_multisample.hip — the spp > 1 integrator of gfx950: the BATCH PASS kernel (every sample's first bounce coherent and
+// culled).  Same arithmetic contract, same per-pixel sample order as every other kernel: bit-identical images.
+// Build flags (see __graft_entry__.build): -O3 -ffp-contract=off -fno-fast-math --offload-arch=gfx950
+#include "pt_kernel_common.hpp"
+
+namespace pt {
+
+// ---- spp > 1: the BATCH PASS kernel.
+// With several samples per pixel per frame the samples of a pixel form a chain: sample s+1 starts from the RNG state sample s
+// ended with (compute.glsl:106-124, one stream per pixel per frame), so a pixel's next primary ray can only be generated
+// when its previous path has ended — after a different number of bounces for every pixel.  Generating it right there
+// (the persistent kernel's spp > 1 path) runs the camera code and a full, unculled first bounce on a few lanes at a time.
+// Here a lane that finishes a sample instead parks the pixel's continuation (pixel, RNG state, radiance so far, sample
+// counter: 28 bytes) in its wavefront's LDS queue and takes other work; when the wavefront next runs out of ring
+// entries it turns up to 64 parked continuations — or a fresh 8x8 tile for sample 0 — into a BATCH PASS: 64 primary rays
+// and their whole first bounce with all lanes together, exactly like the spp = 1 tile pass.  The sphere culling needs no
+// tile structure: cull_spheres() bounds whatever 64 rays the wavefront holds (a wavefront's tiles are neighbours, and all
+// primary rays leave the lens), so every sample's first bounce — 1 / 2.7 of all rays cast — visits a handful of spheres
+// instead of all of them.  A continuation that finds the queue full falls back to the divergent in-lane primary ray.
+// Per pixel nothing changes: same samples in the same order on one RNG stream, irradiance summed in sample order -> the
+// image is bit-identical to every other variant.  Frames are pipelined exactly as in the spp = 1 kernel (alpha tags).
+template <bool MATLDS, bool GRID = false>
+__global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const FrameArgs a)
+{
+    __shared__ __attribute__((aligned(16))) BlockQueue queue;
+    constexpr int NWAVES = 4;
+    const int numTilesFrame = a.tilesX * a.tilesY;
+    const int numTiles = numTilesFrame * a.batchFrames; // (frame, tile) pairs, frame-major
+    if (threadIdx.x == 0) {
+        long long first = (long long)blockIdx.x * a.queueChunk;
+        long long last = first + a.queueChunk < numTiles ? first + a.queueChunk : numTiles;
+        if (first >= numTiles || a.tagged) { first = 0; last = 0; } // tagged launches draw every chunk from the global counter
+        queue.pair = ((unsigned long long)last << 32) | (unsigned long long)first;
+        queue.lock = 0u;
+        queue.done = 0u;
+        if (a.startedFlags) // "this workgroup is resident" (launch chaining): a system-scope store, the host polls the word
+            __hip_atomic_store(a.startedFlags + blockIdx.x, a.launchSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    CHAOS(1);
+    SceneLds sc = stage_scene(a); // ends with __syncthreads()
+    EnvRef env{nullptr, (LdsFloats)sc.lut, 0, 0};
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    char *ringBase = (char *)g_lds + scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, a.materialsInLds != 0, a.gridLdsBytes);
+    PathEntryM *ring = (PathEntryM *)ringBase + wave * 64;
+    const int CONT_BATCH_MIN = a.contBatchMin; // parked continuations that make a batch pass worth its ~950 instructions
+    const int parkCapacity = a.contCapacity; // per wavefront (whatever LDS is left next to scene and rings, see the launch)
+    ContEntry *cq = (ContEntry *)(ringBase + NWAVES * 64 * (int)sizeof(PathEntryM)) + wave * parkCapacity;
+    // image coordinates of accumulation pixel `p` of this launch: x | global row << 16
+    auto pixel_xy = [&](int p) -> int { // p = x | local row << 16 (no division anywhere)
+        ColdArgs ca = cold_args();
+        const int ly = p >> 16, x = p & 0xffff;
+        return x | (global_row_v(ca->bandRows, ca->bandWorld, ca->bandRank, ca->localRow0, ca->y0, ly) << 16);
+    };
+
+    int avail = 0, parked = 0, qhead = 0; // wave-uniform: ring entries [0, avail); `parked` continuations from slot qhead on (FIFO, circular)
+    int stalled = 0;                      // wave-uniform: consecutive iterations in which no lane traced anything
+    auto qslot = [&](int i) -> int { // slot of the i-th parked continuation
+        int sl = qhead + i;
+        return sl >= parkCapacity ? sl - parkCapacity : sl;
+    };
+    bool exhausted = false;
+    int pix = -1, sample = 0, bounce = 0, fj = 0;
+    bool needRay = false, pending = false;
+    float walkFrom = -1.0f, walkFresh = -1.0f; // (WALK SLICES, as in the persistent kernel)
+#ifdef PT_PROFILE
+    unsigned long long prof_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // (this kernel has no section counters of its own)
+#endif
+    uint32_t seed = 0;
+    v3 ro = V(0, 0, 0), rd = V(0, 0, 1), throughput = V(1, 1, 1), rad = V(0, 0, 0), irr = V(0, 0, 0);
+
+    auto fold = [&](float4 last, v3 rirr, int rfj) -> float4 { // compute.glsl:125-129
+        ColdArgs ca = cold_args();
+        rirr = v_scale(rirr, f_div_ieee(1.0f, (float)ca->spp));
+        const float w = f_div_ieee(1.0f, (float)(ca->frame + rfj + 1));
+        const float alpha = (rfj == ca->batchFrames - 1 && !ca->keepTags) ? 1.0f : frame_tag(ca->frame + rfj);
+        return make_float4(f_mix(last.x, rirr.x, w), f_mix(last.y, rirr.y, w), f_mix(last.z, rirr.z, w), alpha);
+    };
+    auto try_resolve = [&](int rpix, int rfj, v3 rirr, bool force) -> bool {
+        const size_t pidx = (size_t)((rpix >> 16) * cold_args()->width + (rpix & 0xffff));
+        float4 *ptr = a.accum + pidx;
+        if (!a.tagged) {
+            const float4 last = *ptr, next = fold(last, rirr, 0);
+            AUDIT_RESOLVE(a, pidx, a.frame, last, next, 5);
+            *ptr = next;
+            if (float4 *snap = cold_args()->snapshot) snap[pidx] = next;
+            return true;
+        }
+        CHAOS(20);
+        float4 last = load_pixel_sc1(ptr);
+        const float expected = rfj > 0 ? frame_tag(a.frame + rfj - 1) : a.chainTag;
+        if (expected != 0.0f && !force && last.w != expected) return false;
+        if (AUDIT_SABOTAGED(a, rpix, rfj)) last.x += 1.0f; // (audit build + PT_AUDIT_SABOTAGE only: a simulated stale / torn read)
+        CHAOS(21);
+        const float4 next = fold(last, rirr, rfj);
+        AUDIT_RESOLVE(a, pidx, a.frame + rfj, last, next, 6);
+        store_pixel_sc1(ptr, next);
+        if (rfj == cold_args()->batchFrames - 1)
+            if (float4 *snap = cold_args()->snapshot) snap[pidx] = make_float4(next.x, next.y, next.z, 1.0f);
+        CHAOS(22);
+        return true;
+    };
+
+    // ---- rescue.  Inside a pipelined batch a pixel's last sample may have to wait for the pixel's previous frame.  If ALL
+    // lanes of a wavefront wait like that, nothing pops its ring or runs a batch pass any more — and the work those lanes
+    // wait for may be exactly what sits in this wavefront's ring or queue (small images: consecutive frames of one tile meet
+    // in one wavefront).  So a wavefront whose lanes all wait moves the waiting results out of the lanes into free slots of
+    // the continuation queue (a waiting result — pixel, frame, irradiance — is a continuation with sample == spp; batch passes
+    // retry it, oldest first) and the freed lanes pop the ring as usual: no queued work depends on a lane that only waits,
+    // and every pixel still runs the same samples in the same order on its own RNG stream.  Should the queue itself be full
+    // of waiting results (more than 150 finished pixels of one wavefront all waiting for other frames), the per-wavefront
+    // stall bound below ends the wait with the error word instead of hanging.  (Swapping waiting results with queued paths
+    // was tried first: it needs the path state to be assignable at a second place, which costs 20 spilled VGPRs.)
+    auto rescue = [&]() -> void {
+        const int room = parkCapacity - parked;
+        if (room > 0) {
+            if (lane < room) { // (every lane waits, so lane l parks into the l-th free slot)
+                ContEntry e;
+                e.pix = pix; e.seed = seed; e.sfj = sample | (fj << 16); // sample == spp marks "last sample done, waiting"
+                e.irr[0] = irr.x; e.irr[1] = irr.y; e.irr[2] = irr.z;
+                cq[qslot(parked + lane)] = e;
+                pix = -1;
+                pending = false;
+            }
+            parked += room < 64 ? room : 64;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (;;) {
+        bool idle = pix < 0;
+        unsigned long long m = __ballot(idle);
+        // ---- forced batch pass (the progress guarantee of the pipelining).  When EVERY lane holds a finished pixel that waits for its
+        // previous frame, nothing pops the ring or runs a batch pass any more — and the work those lanes wait for may be parked in this
+        // wavefront's own queue.  A batch pass needs no idle lane (it computes in its own registers and only needs ring slots), so
+        // such a wavefront runs one over the oldest parked records anyway, appending the survivors to the ring.  Every record keeps
+        // exactly one place (lane, ring slot or queue slot), a pass that finds real work advances it by a bounce or a sample and
+        // leaves at least as much room in the queue as it put paths into the ring — so rescue() below can then free lanes for them.
+        // Waiting records it meets are retried and rotate to the back of the FIFO.  With the tickets handed out frame-major, all
+        // work of the oldest unfinished frame is therefore always executed by whichever wavefront holds it: no cycle of waits.
+        bool forcePass = parked > 0 && avail < 64 && __ballot(!(pix >= 0 && pending && !needRay)) == 0ull;
+        for (int pass = 0; pass < 16 && (m != 0ull || forcePass); pass++) {
+            if (avail == 0 || forcePass) {
+                // ---- batch pass: 64 parked continuations, or the next tile's 64 pixels (sample 0)
+                const bool fromQueue = forcePass || parked >= CONT_BATCH_MIN || (exhausted && parked > 0);
+                forcePass = false;
+                const int base = avail; // ring entries already there (only a forced pass finds any)
+                int tile = -1;
+                if (!fromQueue) {
+                    if (exhausted) break;
+                    tile = queue_pop_tile(&queue);
+                    if (tile < 0) {
+                        exhausted = true;
+                        continue; // (parked continuations, if any, are next)
+                    }
+                }
+                ColdArgs ca = cold_args();
+                ColdFloats cam = (ColdFloats)ca;
+                const int width = ca->width;
+                const float invW = f_div_ieee(1.0f, (float)width), invH = f_div_ieee(1.0f, (float)ca->height);
+                bool valid = false;
+                int tpix = 0, tpxy = 0, tsample = 0, tfj = 0;
+                uint32_t tseed = 0;
+                v3 tirr = V(0.0f, 0.0f, 0.0f);
+                if (fromQueue) {
+                    const int n = parked < 64 - base ? parked : 64 - base;
+                    valid = lane < n;
+                    if (valid) {
+                        const ContEntry e = cq[qslot(lane)]; // oldest first: a parked pixel never waits behind younger ones
+                        tpix = e.pix; tpxy = pixel_xy(e.pix); tseed = e.seed;
+                        tsample = e.sfj & 0xffff; tfj = e.sfj >> 16;
+                        tirr = V(e.irr[0], e.irr[1], e.irr[2]);
+                    }
+                    qhead = qslot(n);
+                    parked -= n;
+                    __builtin_amdgcn_wave_barrier(); // the entries are read before this pass parks new ones in their place
+                } else {
+                    const int tilesX = ca->tilesX;
+                    tfj = tile / numTilesFrame;
+                    tile -= tfj * numTilesFrame;
+                    const int tx = tile % tilesX, ty = tile / tilesX;
+                    const int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+                    valid = x < width && ly < ca->rows;
+                    if (valid) {
+                        const int gy = global_row_v(ca->bandRows, ca->bandWorld, ca->bandRank, ca->localRow0, ca->y0, ly);
+                        tpix = x | (ly << 16);
+                        tpxy = x | (gy << 16);
+                        tseed = pixel_seed(x, gy, ca->frame + tfj);
+                    }
+                }
+                // (a parked record with sample == spp is a finished pixel that waited for its previous frame: retried below)
+                const bool twaiting = valid && tsample >= a.spp;
+                valid = valid && !twaiting;
+                v3 to = V(0.0f, 0.0f, 0.0f), td = V(0.0f, 0.0f, 1.0f), tthr = V(1.0f, 1.0f, 1.0f), trad = V(0.0f, 0.0f, 0.0f);
+                if (valid) primary_ray_cam(cam, invW, invH, tpxy & 0xffff, tpxy >> 16, tseed, to, td);
+                unsigned long long masks[4];
+                cull_spheres(sc, a.numSpheres, valid, to, td, masks);
+                bool tcont = false;
+                if (valid) {
+                    if (0 < a.rayDepth) tcont = bounce_step_t<true, MATLDS>(sc, a.numSpheres, a.numCuboids, env, to, td, tthr, trad, tseed, masks, walkFresh PROF_DUMMY);
+                    if (1 >= a.rayDepth) tcont = false;
+                }
+                // 1. paths that continue go to the ring
+                const unsigned long long cm = __ballot(tcont);
+                if (tcont) {
+                    const int slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+                    PathEntryM e;
+                    e.pix = tpix; e.counters = 1 | (tsample << 12) | (tfj << 24); e.seed = tseed;
+                    e.ro[0] = to.x; e.ro[1] = to.y; e.ro[2] = to.z;
+                    e.rd[0] = td.x; e.rd[1] = td.y; e.rd[2] = td.z;
+                    e.thr[0] = tthr.x; e.thr[1] = tthr.y; e.thr[2] = tthr.z;
+                    e.rad[0] = trad.x; e.rad[1] = trad.y; e.rad[2] = trad.z;
+                    e.irr[0] = tirr.x; e.irr[1] = tirr.y; e.irr[2] = tirr.z;
+                    ring[slot] = e;
+                }
+                avail = base + __builtin_popcountll(cm);
+                // 2. samples that ended at their first bounce: irradiance += Radiance (compute.glsl:122); more samples to go ->
+                // park the continuation; the pixel's last sample -> compute.glsl:125-129
+                const bool tfin = valid && !tcont;
+                if (tfin) {
+                    tirr = v_add(tirr, trad);
+                    tsample++;
+                }
+                bool tmore = tfin && tsample < a.spp;
+                if (twaiting) { // still waiting: back into the queue, as it was
+                    const bool force = stalled > FRAME_RETRY_LIMIT;
+                    if (!try_resolve(tpix, tfj, tirr, force)) tmore = true;
+                    else if (force) atomicOr(cold_args()->errorWord, 1u);
+                }
+                const unsigned long long pm = __ballot(tmore);
+                bool toRing = false; // overflow of the queue / a resolve that has to wait: through the ring, handled in the lane
+                int ringCounters = 0;
+                if (pm != 0ull) {
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
+                    const int room = parkCapacity - parked;
+                    if (tmore && rank < room) {
+                        ContEntry e;
+                        e.pix = tpix; e.seed = tseed; e.sfj = tsample | (tfj << 16);
+                        e.irr[0] = tirr.x; e.irr[1] = tirr.y; e.irr[2] = tirr.z;
+                        cq[qslot(parked + rank)] = e;
+                    } else if (tmore) {
+                        toRing = true;
+                        ringCounters = (tsample << 12) | (tfj << 24) | (int)0x80000000; // no ray yet
+                    }
+                    const int n = __builtin_popcountll(pm);
+                    parked += n < room ? n : room;
+                }
+                if (tfin && tsample >= a.spp && !try_resolve(tpix, tfj, tirr, false)) {
+                    toRing = true;
+                    ringCounters = a.rayDepth | (tsample << 12) | (tfj << 24); // "at full depth": resolved in the bounce loop
+                }
+                const unsigned long long wm = __ballot(toRing);
+                if (wm != 0ull) {
+                    if (toRing) {
+                        const int slot = avail + __builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u));
+                        PathEntryM e;
+                        e.pix = tpix; e.counters = ringCounters; e.seed = tseed;
+                        e.ro[0] = e.ro[1] = e.ro[2] = 0.0f; e.rd[0] = e.rd[1] = 0.0f; e.rd[2] = 1.0f;
+                        e.thr[0] = e.thr[1] = e.thr[2] = 1.0f;
+                        e.rad[0] = e.rad[1] = e.rad[2] = 0.0f;
+                        e.irr[0] = tirr.x; e.irr[1] = tirr.y; e.irr[2] = tirr.z;
+                        ring[slot] = e;
+                    }
+                    avail += __builtin_popcountll(wm);
+                }
+                __builtin_amdgcn_wave_barrier(); // ring / queue entries are read by other lanes of this wave below
+                if (avail == 0) continue;
+            }
+            // ---- idle lanes pop paths (top down)
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (idle && rank < avail) {
+                const PathEntryM e = ring[avail - 1 - rank];
+                pix = e.pix;
+                bounce = e.counters & 0xfff;
+                sample = (e.counters >> 12) & 0xfff;
+                fj = (e.counters >> 24) & 0x7f;
+                needRay = e.counters < 0;
+                pending = false;
+                walkFrom = -1.0f; // (a fresh path: no unfinished grid walk)
+                seed = e.seed;
+                ro = V(e.ro[0], e.ro[1], e.ro[2]);
+                rd = V(e.rd[0], e.rd[1], e.rd[2]);
+                throughput = V(e.thr[0], e.thr[1], e.thr[2]);
+                rad = V(e.rad[0], e.rad[1], e.rad[2]);
+                irr = V(e.irr[0], e.irr[1], e.irr[2]);
+                if (!needRay && bounce >= a.rayDepth && sample >= a.spp) pending = true; // a resolve that had to wait
+            }
+            const int n = __builtin_popcountll(m);
+            avail = n < avail ? avail - n : 0;
+            idle = pix < 0;
+            m = __ballot(idle);
+        }
+        bool active = pix >= 0;
+        if (__ballot(active) == 0ull) {
+            if (exhausted && avail == 0 && parked == 0) break;
+            stalled++; // (only waiting records left in the queue: they are retried by the batch passes above)
+            if (parked > 0 && avail == 0) __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        if (__ballot(!(active && pending && !needRay)) == 0ull && (avail > 0 || parked > 0)) {
+            rescue(); // every lane waits: see above
+            // (round 4: the lanes rescue() has just emptied are NOT active any more.  They used to run one bounce of their dead path below —
+            // harmless while a bounce left nothing behind in the lane, but a grid walk cut short (WALK SLICES) leaves walkFrom, and the
+            // path the lane pops next would have resumed someone else's walk: found by tools/handover_stress --multisample)
+            active = pix >= 0;
+        }
+        // (a wavefront that has done nothing but wait for FRAME_RETRY_LIMIT iterations in a row gives up the hand-over: waiting
+        // records move between lanes, ring and queue, so the bound is kept per wavefront, not per lane)
+        stalled = __ballot(pix >= 0 && !pending) == 0ull ? stalled + 1 : 0;
+        if (active && needRay) { // fallback (queue was full): the next sample's primary ray, generated in the lane
+            const int pxy = pixel_xy(pix);
+            primary_ray(a, pxy & 0xffff, pxy >> 16, seed, ro, rd);
+            throughput = V(1.0f, 1.0f, 1.0f);
+            rad = V(0.0f, 0.0f, 0.0f);
+            bounce = 0;
+            needRay = false;
+        }
+        bool wantPark = false;
+        if (active && !pending) {
+            bool cont = false;
+            if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr, walkFrom PROF_DUMMY);
+            const bool sliced = GRID && walkFrom >= 0.0f; // (the grid walk of this bounce continues in the next iteration: pt_device.hpp, WALK SLICES)
+            if (!sliced) bounce++;
+            if (!sliced && (!cont || bounce >= a.rayDepth)) {
+                irr = v_add(irr, rad); // compute.glsl:122
+                sample++;
+                if (sample < a.spp) wantPark = true;
+                else pending = true; // the pixel's last sample: fold into the accumulation image
+            }
+        }
+        // ---- park the pixels whose sample ended; the lane is free for other work
+        const unsigned long long pm = __ballot(wantPark);
+        if (pm != 0ull) {
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
+            const int room = parkCapacity - parked;
+            if (wantPark && rank < room) {
+                ContEntry e;
+                e.pix = pix; e.seed = seed; e.sfj = sample | (fj << 16);
+                e.irr[0] = irr.x; e.irr[1] = irr.y; e.irr[2] = irr.z;
+                cq[qslot(parked + rank)] = e;
+                pix = -1;
+            } else if (wantPark) {
+                needRay = true;
+            }
+            const int n = __builtin_popcountll(pm);
+            parked += n < room ? n : room;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (pix >= 0 && pending) {
+            const bool force = stalled > FRAME_RETRY_LIMIT; // (bounded per wavefront: waiting records move between lanes, ring and queue)
+            if (try_resolve(pix, fj, irr, force)) {
+                if (force) atomicOr(cold_args()->errorWord, 1u);
+                pix = -1;
+                pending = false;
+            }
+        }
+        { // nothing but waiting paths left in this wavefront: do not hammer the pixel
+            const bool act = pix >= 0;
+            if (__ballot(act && pending) != 0ull && __ballot(act && !pending) == 0ull && parked < CONT_BATCH_MIN && avail == 0)
+                __builtin_amdgcn_s_sleep(8);
+        }
+    }
+}
+
+hipError_t launch_multisample(const FrameArgs &a, int workgroups, size_t ldsBytes, hipStream_t stream, bool materialsInLds, bool sphereGrid)
+{
+    if (materialsInLds) hipLaunchKernelGGL(pt_integrate_multisample_kernel<true>, dim3(workgroups), dim3(256), ldsBytes, stream, a);
+    else if (sphereGrid) hipLaunchKernelGGL((pt_integrate_multisample_kernel<false, true>), dim3(workgroups), dim3(256), ldsBytes, stream, a);
+    else hipLaunchKernelGGL(pt_integrate_multisample_kernel<false>, dim3(workgroups), dim3(256), ldsBytes, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace pt

@@ -1,0 +1,226 @@
+// pt_kernel_common.hpp — what the integrator kernels share (included by pt_integrate_persistent.hip and pt_integrate_multisample.hip
+// only): scene staging into LDS, the frame-pipelining hand-over primitives (alpha tags, device-coherent 16-byte pixel accesses), the
+// path / continuation record layouts and the two-level tile queue.
+#pragma once
+#include <type_traits>
+
+#include "pt_debug_hooks.hpp"
+#include "pt_device.hpp"
+#include "pt_kernels.hpp"
+#include "pt_math.hpp"
+
+namespace pt {
+
+extern __shared__ float4 g_lds[];
+
+// Stage + re-pack the scene into LDS (all 256 threads): std140 Sphere = 5 x float4 (geometry, 4 x material),
+// Cuboid = 6 x float4.  Ends with a workgroup barrier.
+PT_DEV SceneLds stage_scene(const FrameArgs &a)
+{
+    const int ns = a.numSpheres, nc = a.numCuboids;
+    float4 *sph = g_lds;
+    float4 *cmin = sph + ns;
+    float4 *cmax = cmin + nc;
+    float4 *mat = cmax + nc;
+    const bool matInLds = a.materialsInLds != 0;
+    float *invr = (float *)(mat + (matInLds ? 4 * (ns + nc) : 0));
+    float *lut = invr + ((ns + 3) & ~3);
+    const int tid = threadIdx.x;
+    const float4 *obj = (const float4 *)a.objects;
+    const int nthreads = blockDim.x;
+    if (matInLds) {
+        for (int i = tid; i < ns * 5; i += nthreads) {
+            int s = i / 5, part = i - s * 5;
+            float4 v = obj[i];
+            if (part == 0) {
+                sph[s] = v;
+                invr[s] = f_div_ieee(1.0f, v.w);
+            } else {
+                mat[4 * s + part - 1] = v;
+            }
+        }
+        for (int i = tid; i < nc * 6; i += nthreads) {
+            int c = i / 6, part = i - c * 6;
+            float4 v = obj[1280 + i]; // Cuboids[] start at byte 20480 = float4 index 1280
+            if (part == 0) cmin[c] = v;
+            else if (part == 1) cmax[c] = v;
+            else mat[4 * (ns + c) + part - 2] = v;
+        }
+    } else { // geometry only
+        for (int i = tid; i < ns; i += nthreads) {
+            float4 v = obj[5 * i];
+            sph[i] = v;
+            invr[i] = f_div_ieee(1.0f, v.w);
+        }
+        for (int i = tid; i < nc * 2; i += nthreads) {
+            int c = i >> 1;
+            float4 v = obj[1280 + 6 * c + (i & 1)];
+            if (i & 1) cmax[c] = v;
+            else cmin[c] = v;
+        }
+    }
+    if (a.envFormat == 1 && tid < 256) lut[tid] = a.srgbLut[tid];
+    // sphere grid of large scenes (only when this launch traverses it): packed uint16 starts + uint8 refs, copied word by word
+    unsigned int *grid = (unsigned int *)(lut + (a.envFormat == 1 ? 256 : 0));
+    const unsigned short *gridStarts = nullptr;
+    const unsigned char *gridRefs = nullptr;
+    if (a.gridLdsBytes > 0) {
+        const unsigned int *src = (const unsigned int *)a.grid;
+        for (int i = tid; i < (a.gridBytes + 3) / 4; i += nthreads) grid[i] = src[i];
+        gridStarts = (const unsigned short *)grid;
+        gridRefs = (const unsigned char *)(gridStarts + a.gridDims[0] * a.gridDims[1] * a.gridDims[2] + 1);
+    }
+    __syncthreads();
+    return SceneLds{sph, cmin, cmax, mat, invr, lut, obj, gridStarts, gridRefs};
+}
+
+// XCD-aware workgroup id: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, so id b is
+// remapped to a contiguous band of work per XCD (the tail nwg & 7 keeps its identity mapping).
+PT_DEV int xcd_band_id(int b, int nwg)
+{
+    int per = nwg >> 3;
+    return b < per * 8 ? (b & 7) * per + (b >> 3) : b;
+}
+
+// ---- frame pipelining (persistent spp = 1 kernels).  One launch can render a BATCH of consecutive frames: its tile queue
+// runs over (frame, tile) pairs, frame-major, so wavefronts only drain once per batch instead of once per frame (the
+// drain tail is ~75 us of a ~215 us frame at 1080p).  The only dependency between frames is per pixel: the running
+// mean of frame f+1 needs the pixel's value after frame f (compute.glsl:126-129).  It is carried IN the pixel: inside a
+// batch, frame j of the batch stores alpha = FRAME_TAG + j instead of 1 (the last frame of the batch stores the 1 the
+// reference stores), and the resolve of frame j only proceeds when it reads the tag of frame j-1.  Pixels are written
+// with ONE 16-byte device-scope (sc1) store and read with ONE 16-byte sc1 load — single-copy atomic and coherent
+// across the 8 XCD L2s — so colour and tag always belong together.  A resolve that finds its predecessor missing is
+// simply retried in the wavefront's next iteration (never a spin loop: the predecessor may live in another lane of
+// the same wavefront); after FRAME_RETRY_LIMIT attempts it proceeds anyway and raises the launch's error word.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr float FRAME_TAG = 2.0f;
+// the tag of (absolute) frame f: distinct for any two frames that can be in flight together, exact in binary32.  Launches
+// may CHAIN: the first frame of a tagged launch waits for the tag of the previous launch's last frame (FrameArgs::chainTag), so
+// two launches on different streams overlap like the frames inside one launch do (the second fills the wavefront slots the
+// first one's drain frees) — the host restores alpha = 1 before anything can observe the image (pt_set_alpha_kernel).
+PT_DEV float frame_tag(int absFrame) { return FRAME_TAG + (float)(absFrame & 1023); }
+constexpr int FRAME_RETRY_LIMIT = 1 << 22;
+constexpr int MAX_BATCH_FRAMES = 256; // (one workgroup fills the weight table: <= its 256 threads; tags cover 1,024 frames)
+
+PT_DEV float4 load_pixel_sc1(const float4 *p)
+{
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+PT_DEV void store_pixel_sc1(float4 *p, float4 c)
+{
+    f32x4 v = {c.x, c.y, c.z, c.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+
+struct RingEntry { // 40 bytes (spp > 1)
+    int pix;       // linear index into accum, -1 = pixel outside the image (ragged tile)
+    int pxy;       // px | py << 16 (global coordinates)
+    uint32_t seed; // RNG state after the primary-ray draws
+    float ox, oy, oz, dx, dy, dz;
+    int pad;       // frame of the batch (frame pipelining)
+};
+
+// spp == 1 kernels: the ring holds paths AFTER their first bounce (see the tile pass in the kernel), 60 bytes each
+struct PathEntry {
+    int pix;       // linear index into accum
+    int bounce;    // bounces done so far | frame of the batch << 16 | bit 30: `last` holds the pixel's current value
+    uint32_t seed; // RNG state
+    float ro[3], rd[3], thr[3], rad[3];
+};
+// CARRY kernels (the default kernel on full-size images): the pixel's accumulation value, read by the TILE PASS with all 64 lanes
+// (8 rows x 128 B: full lines) right after the first bounce, travels with the path: its resolve then needs no load (and no memory
+// round trip) — nobody else writes the pixel between frame f-1's resolve and frame f's.  Only valid when the tile pass already saw
+// the previous frame's tag (PATH_HAS_LAST).  Memory-side reads 84 -> 46 MB per 1080p frame (profiles/r04/xcd_affine_traffic.json).
+struct PathEntryCarry : PathEntry {
+    float last[3];
+};
+constexpr int PATH_HAS_LAST = 1 << 30;
+// per lane: the pixel value read by the tile pass (LDS slot while the path is in a lane, see the kernel)
+__host__ __device__ constexpr size_t lane_last_bytes(bool carry) { return carry ? 12 : 0; }
+
+// spp = 1, frame pipelining: a finished path whose pixel still holds an older frame used to keep its lane until the
+// previous frame's resolve arrived.  It now PARKS the result (pixel, frame of the batch, radiance: 20 bytes) in its
+// wavefront's LDS list and frees the lane; the list is retried by the wavefront's first lanes once per iteration.  It
+// matters when a GPU owns few tiles per frame (a 1/8 share of a 1080p image has 4,050 tiles for 6,144 wavefronts, so
+// consecutive frames of one tile are in flight together all the time).
+struct ParkedResolve {
+    int pix, fj;
+    float irr[3];
+};
+constexpr int PARKED_MAX = 64; // upper bound; FrameArgs::parkedMax is what a launch uses
+// LDS bytes of the per-launch table of running-mean weights (spp = 1 persistent kernels), 16-byte aligned
+__host__ __device__ constexpr size_t frame_weight_bytes(int batchFrames) { return (size_t)((batchFrames + 63) & ~63) * 4; }
+
+struct BlockQueue {            // one per workgroup, in static LDS
+    unsigned long long pair;   // (end << 32) | cursor : absolute tile indices of the current chunk
+    unsigned int lock;         // refill lock
+    unsigned int done;         // global queue exhausted
+};
+
+
+// relaxed workgroup-scope loads/stores of LDS control words (compile to ds_read / ds_write, never cached in registers)
+PT_DEV unsigned int lds_load(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+PT_DEV unsigned long long lds_load64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+PT_DEV void lds_store(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// Next tile for this wavefront, or -1 when the frame's tiles are all handed out.  Wave-uniform result.
+PT_DEV int queue_pop_tile(BlockQueue *q)
+{
+    const bool leader = (threadIdx.x & 63) == 0;
+    for (;;) {
+        unsigned long long old = 0;
+        if (leader) old = atomicAdd(&q->pair, 1ull);
+        unsigned int cursor = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)old);
+        unsigned int end = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(old >> 32));
+        if (cursor < end) return (int)cursor;
+        if (__builtin_amdgcn_readfirstlane((int)lds_load(&q->done))) return -1;
+        unsigned int got = 1;
+        if (leader) got = atomicCAS(&q->lock, 0u, 1u);
+        if (__builtin_amdgcn_readfirstlane((int)got) == 0) { // this wavefront refills
+            // re-check under the lock: another wavefront may have refilled or hit the end meanwhile (a workgroup
+            // must draw exactly ONE failing ticket per launch — the host's queueBase accounting relies on it)
+            unsigned long long cur = lds_load64(&q->pair);
+            unsigned int isDone = lds_load(&q->done);
+            if (!isDone && (unsigned int)cur >= (unsigned int)(cur >> 32)) {
+                unsigned int ticket = 0;
+                ColdArgs ca = cold_args();
+                const int numTiles = ca->tilesX * ca->tilesY * ca->batchFrames, chunk = ca->queueChunk; // (frame, tile) pairs, frame-major
+                CHAOS(2);
+                if (leader) ticket = atomicAdd(ca->queue, 1u) - ca->queueBase;
+                ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+                const long long first = ((ca->tagged ? 0ll : (long long)gridDim.x) + ticket) * chunk; // tagged launches have no static chunks
+                const long long last = first + chunk < numTiles ? first + chunk : numTiles;
+                if (first >= numTiles) {
+                    if (leader) lds_store(&q->done, 1u);
+                } else {
+                    if (leader) atomicExch(&q->pair, ((unsigned long long)last << 32) | (unsigned long long)first);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (leader) atomicExch(&q->lock, 0u);
+        } else {
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+}
+
+struct PathEntryM { // 72 bytes: a path after its first bounce, plus what its pixel needs for the samples that follow
+    int pix;        // x | local row << 16 of the pixel in this launch's accumulation rows (both < 32768: no division to unpack)
+    int counters;   // bounces done | sample << 12 | frame of the batch << 24 ; bit 31: no ray yet (generate it in the lane)
+    uint32_t seed;
+    float ro[3], rd[3], thr[3], rad[3], irr[3];
+};
+struct ContEntry {  // 24 bytes: a pixel between two of its samples
+    int pix;
+    uint32_t seed;
+    int sfj;        // sample | frame of the batch << 16
+    float irr[3];
+};
+
+
+// the spp > 1 batch-pass kernel (pt_integrate_multisample.hip), launched by launch_integrate (pt_integrate_persistent.hip)
+hipError_t launch_multisample(const FrameArgs &a, int workgroups, size_t ldsBytes, hipStream_t stream, bool materialsInLds, bool sphereGrid);
+
+} // namespace pt

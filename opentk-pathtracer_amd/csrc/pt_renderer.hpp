@@ -20,6 +20,14 @@ constexpr uint32_t kAlive = 0x4d335054u; // "M3PT"
 constexpr int kMaxStripes = 4;
 // global ticket counters of the persistent kernel: stripe j draws from word 16 * j, the chain stream from its own 128-byte line
 constexpr int kQueueWords = 128, kChainQueueWord = 64;
+// The per-wavefront timestamps of tools/timeline.py need one plain launch per frame (no batching, chaining or snapshots).  In a
+// -DPT_PROFILE build the same buffer only receives the section counters (tools/profile_sections.py), which every kernel and every
+// launch mode can write: the library keeps pipelining, so that the profile is taken in the mode bench.py measures.
+#ifdef PT_PROFILE
+#define PT_TIMELINE_BLOCKS(h) false
+#else
+#define PT_TIMELINE_BLOCKS(h) ((h)->dTimeline != nullptr)
+#endif
 constexpr int kStartedWords = pt::kStartedWords; // >= workgroups of any persistent launch (8 per CU)
 
 // One image of the non-blocking present path (pt_present_rgba8_async / pt_present_wait).
@@ -172,6 +180,7 @@ struct pt_renderer {
 
 namespace ptimpl {
 
+inline bool timeline_blocks_pipelining(const pt_renderer *h) { return PT_TIMELINE_BLOCKS(h); }
 int fail(pt_handle h, int code, const std::string &msg);
 int hip_fail(pt_handle h, hipError_t e, const char *what);
 

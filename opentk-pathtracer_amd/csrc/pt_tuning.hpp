@@ -29,6 +29,7 @@ struct Tuning {
     int parkMin = 40;              // parked continuations that make a batch pass worth running
     int noSphereGrid = 0;          // 1: large scenes keep the reference's in-order sphere loop
     int forceLeanLds = 0;          // 1: materials are always read from the UBO copy
+    int carryLast = 1;             // 0: the pixel never travels with its path (every resolve loads it; the kernel of rounds 1-3)
     // sphere grid build (pt_sphere_grid.hpp)
     int gridMinSpheres = 64;       // scenes with fewer spheres get no grid
     int gridCells = 256;           // cell budget (<= ptgrid::kMaxCells)
@@ -66,6 +67,7 @@ inline bool tuning_set(const char *key, long long v)
     PT_KNOB("park_min", parkMin)
     PT_KNOB("no_sphere_grid", noSphereGrid)
     PT_KNOB("force_lean_lds", forceLeanLds)
+    PT_KNOB("carry_last", carryLast)
     PT_KNOB("grid_min_spheres", gridMinSpheres)
     PT_KNOB("grid_cells", gridCells)
     PT_KNOB("grid_dim_x", gridDims[0])

@@ -18,7 +18,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("MI355PT_LIB") or os.path.join(HERE, "libmi355pt.so")  # MI355PT_LIB: A/B tuning builds
 HEADER = os.path.join(REPO, "include", "mi355pt.h")
-SOURCES = ["pt_kernels.hip", "mi355pt.cpp", "mi355pt_multi.cpp"]
+SOURCES = ["pt_integrate_persistent.hip", "pt_integrate_multisample.hip", "pt_helper_kernels.hip", "mi355pt.cpp", "mi355pt_multi.cpp"]
 # -ffp-contract=off / -fno-fast-math are part of the pt-f32 arithmetic contract (csrc/pt_math.hpp)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared",
                "-fvisibility=hidden"]

@@ -1,8 +1,8 @@
-"""Per-section cycle breakdown of the persistent kernel's bounce iteration (needs the -DPT_PROFILE build:
-    hipcc ... -DPT_PROFILE csrc/pt_kernels.hip csrc/mi355pt.cpp -o tools/ab/libP.so ;  MI355PT_LIB=tools/ab/libP.so python tools/profile_sections.py)
-python tools/profile_sections.py [scene] [variant frames]   default: variant 14 (one un-pipelined frame per launch), 10 frames.  Variant 0
-(pipelined batches) only makes sense on a profile build whose host code keeps pipelining on while the counter buffer exists
-(profiles/r03/profile_sections.log lists the three-line patch)."""
+"""Per-section cycle breakdown of the integrator's bounce iteration on PIPELINED launches (the mode bench.py measures).  Needs the
+-DPT_PROFILE build of the tree (tools/ab/build_ab.sh P -DPT_PROFILE): every kernel builds with it, and the library keeps batching /
+chaining while the counter buffer exists (csrc/pt_renderer.hpp, PT_TIMELINE_BLOCKS).
+    MI355PT_LIB=tools/ab/libP.so python tools/profile_sections.py [default|stress|glass] [variant frames]
+default: variant 0, 640 frames.  Variant 14 = one un-pipelined frame per launch."""
 import os, sys, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,13 +14,13 @@ W, H = 1920, 1080
 sc = {"default": pkg.scene.default_scene, "stress": pkg.scene.stress_scene, "glass": pkg.scene.glass_scene}[scene_name]()
 cam = pkg.camera.Camera()
 pt = pkg.PathTracer(pkg.envmap.synthetic_sky_rgba32f(64), W, H, 8 if scene_name != "glass" else 32, 1, 20.0, 0.14)
-variant = int(sys.argv[2]) if len(sys.argv) > 2 else 14
+variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 pt.SetVariant(variant); pt.UploadScene(sc); pt.UploadBasicData(pkg.camera.basic_data_ubo(cam, W, H))
 for _ in range(5 if variant else 128): pt.Render()
 pt.Synchronize()
 lib.pt_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 lib.pt_debug_timeline(pt._h, None, 0)          # allocate + zero
-frames = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else 640
 for _ in range(frames): pt.Render()
 pt.Synchronize()
 buf = np.zeros((65536, 4), np.uint64)
