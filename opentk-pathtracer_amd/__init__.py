@@ -4,7 +4,7 @@ BoyBaykiller/OpenTK-PathTracer, behind the C ABI of include/mi355pt.h.
 The directory name contains a hyphen (repo contract), so import it through __graft_entry__.load_package(),
 which registers it as the module `opentk_pathtracer_amd`.
 
-  csrc/            hand-written HIP kernels (pt_kernels.hip + device functions pt_device.hpp / pt_atmosphere.hpp), device math
+  csrc/            hand-written HIP kernels (pt_integrate_persistent.hip, pt_integrate_multisample.hip, pt_helper_kernels.hip + device functions pt_device.hpp / pt_atmosphere.hpp), device math
                    contract (pt_math.hpp), C ABI (mi355pt.cpp)
   native.py        hipcc build recipe + ctypes binding of libmi355pt.so (fails loudly; no CPU fallback)
   path_tracer.py   host-side mirror of the reference's PathTracer / AtmosphericScatterer classes over the C ABI

@@ -2,7 +2,7 @@
 //
 // Host-side state of one renderer (what the reference keeps in the C# class PathTracer,
 // /root/reference/OpenTK-PathTracer/src/Render/PathTracer.cs:9-141, plus the two UBOs MainWindow owns,
-// src/MainWindow.cs:195-201) and the HIP plumbing around the kernels of pt_kernels.hip.
+// src/MainWindow.cs:195-201) and the HIP plumbing around the kernels of the pt_*.hip files.
 // There is deliberately NO CPU fallback: without a HIP device every entry point fails with PT_E_NO_DEVICE.
 #include "pt_renderer.hpp"
 
@@ -307,6 +307,7 @@ PT_API int pt_destroy(pt_handle h)
     if (h->dGrid) (void)hipFree(h->dGrid);
     if (h->dLut) (void)hipFree(h->dLut);
     if (h->dQueue) (void)hipFree(h->dQueue);
+    if (h->dTileMasks) (void)hipFree(h->dTileMasks);
     if (h->hostErrWord) (void)hipHostFree(h->hostErrWord);
     if (h->hostStarted) (void)hipHostFree(h->hostStarted);
     if (h->hostAuditLog) (void)hipHostFree(h->hostAuditLog);
@@ -338,6 +339,7 @@ PT_API int pt_set_size(pt_handle h, int width, int height)
     h->rows = height;
     h->bandRows = 0;
     h->frame = 0; // PathTracer.cs:133
+    h->tileMasksValid = false;
     if (int rc = ensure_accum(h)) return rc;
     return clear_accum(h);
 }
@@ -353,6 +355,7 @@ PT_API int pt_set_tile(pt_handle h, int y0, int rows)
     h->rows = rows;
     h->bandRows = 0;
     h->frame = 0;
+    h->tileMasksValid = false;
     if (int rc = ensure_accum(h)) return rc;
     return clear_accum(h);
 }
@@ -378,6 +381,7 @@ PT_API int pt_set_interleaved_tile(pt_handle h, int rank, int world, int band_ro
     h->bandWorld = world;
     h->bandRank = rank;
     h->frame = 0;
+    h->tileMasksValid = false;
     if (int rc = ensure_accum(h)) return rc;
     return clear_accum(h);
 }
@@ -419,6 +423,7 @@ PT_API int pt_set_params(pt_handle h, int num_spheres, int num_cuboids, int ray_
     if (ray_depth > PT_MAX_RAY_DEPTH || spp > PT_MAX_SPP)
         return fail(h, PT_E_OUT_OF_RANGE, "ray_depth / spp exceed PT_MAX_RAY_DEPTH / PT_MAX_SPP (4095)");
     if (num_spheres != h->numSpheres) h->gridDirty = true;
+    if (num_spheres != h->numSpheres || focal_length != h->focalLength || aperture_diameter != h->apertureDiameter) { h->tileMasksValid = false; h->launchesSinceInputChange = 0; }
     h->numSpheres = num_spheres;
     h->numCuboids = num_cuboids;
     h->rayDepth = ray_depth;
@@ -437,6 +442,7 @@ PT_API int pt_upload_basic_data(pt_handle h, int byte_offset, int size, const vo
     if (byte_offset < 0 || size < 0 || (long long)byte_offset + size > PT_BASIC_DATA_UBO_SIZE)
         return fail(h, PT_E_OUT_OF_RANGE, "BasicDataUBO range outside [0,144)");
     std::memcpy(h->basic + byte_offset, src, (size_t)size);
+    h->tileMasksValid = false; h->launchesSinceInputChange = 0;
     return PT_OK;
 }
 
@@ -454,6 +460,7 @@ PT_API int pt_upload_game_objects(pt_handle h, int byte_offset, int size, const 
     PT_HIP(h, hipMemcpyAsync((char *)h->dObjects + byte_offset, src, (size_t)size, hipMemcpyHostToDevice, h->stream));
     std::memcpy(h->objectsShadow + byte_offset, src, (size_t)size);
     if (byte_offset < PT_MAX_SPHERES * 80) h->gridDirty = true; // (the Spheres[] array ends at byte 20,480)
+    if (byte_offset < PT_MAX_SPHERES * 80) { h->tileMasksValid = false; h->launchesSinceInputChange = 0; }
     return PT_OK;
 }
 
@@ -492,7 +499,7 @@ namespace {
 bool gpu_busy(pt_handle h);
 
 // Launch frames [firstFrame, firstFrame + n) with the handle's current inputs.  n == 1: the striped frame; n > 1: one
-// batch kernel on the main stream (pt_kernels.hip, frame pipelining).
+// batch kernel on the main stream (pt_integrate_persistent.hip, frame pipelining).
 int launch_frames(pt_handle h, int firstFrame, int n)
 {
     if (int rc = bind_device(h)) return rc;
@@ -560,6 +567,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     }
     a.gridReach2 = h->grid.reach2;
     std::memcpy(a.sphereRunStart, h->sphereRunStart, sizeof(a.sphereRunStart));
+    a.tileMasks = nullptr; // (set below, next to a.tilesY, for the launch modes that run the tile pass over the handle's whole tile)
 
     // variant -> (kernel variant, stripes): 0 = default (2 stripes x 5 workgroups/CU); 20+k / 30+k / 40+k = 2 / 3 / 4
     // stripes of the persistent kernel with k+1 workgroups per CU; everything else = one kernel on the main stream
@@ -604,6 +612,27 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         a.snapshot = h->snapshotTarget;
         a.tilesY = (h->rows + 7) / 8;
         a.keepTags = h->flushFinal ? 0 : 1;
+        // Cached tile masks (the tile pass of the spp = 1 kernels, the fresh-tile batch passes of the spp > 1 kernel): valid masks are simply used; stale ones are rebuilt once the camera / lens / spheres /
+        // tiling have been left alone for two launches — the launches still in flight read the old buffer, so the rebuild joins the two
+        // launch streams first (chainBroken: this launch starts on the main stream, behind the mask kernel)
+        if (pt::tuning().tileMasks != 0) {
+            h->launchesSinceInputChange++;
+            if (!h->tileMasksValid && h->launchesSinceInputChange > 2) {
+                if (int rc = join_stripes(h)) return rc;
+                const size_t tiles = (size_t)a.tilesX * a.tilesY;
+                if (tiles > h->tileMaskTiles) {
+                    PT_HIP(h, hipStreamSynchronize(h->stream)); // (a launch may still read the old buffer)
+                    if (h->dTileMasks) PT_HIP(h, hipFree(h->dTileMasks));
+                    h->dTileMasks = nullptr;
+                    h->tileMaskTiles = 0;
+                    PT_HIP(h, hipMalloc((void **)&h->dTileMasks, tiles * pt::kTileMaskWords * sizeof(unsigned long long)));
+                    h->tileMaskTiles = tiles;
+                }
+                PT_HIP(h, pt::launch_tile_masks(a, h->dTileMasks, h->stream));
+                h->tileMasksValid = true;
+            }
+            if (h->tileMasksValid) a.tileMasks = h->dTileMasks;
+        }
         // Beside its predecessor (other stream) only if that launch is fully resident — then this launch can only ever get the slots
         // the predecessor's workgroups give up when they are done; otherwise behind it on the same stream (no overlap, always safe).
         const bool mayChain = !h->chainBroken && h->lastWorkgroups > 0 && h->lastWorkgroups <= ptimpl::kStartedWords;

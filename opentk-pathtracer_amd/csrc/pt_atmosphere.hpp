@@ -1,4 +1,4 @@
-// pt_atmosphere.hpp — device functions of the atmosphere environment precompute (included by pt_kernels.hip only).
+// pt_atmosphere.hpp — device functions of the atmosphere environment precompute (included by pt_helper_kernels.hip only).
 #pragma once
 #include "pt_device.hpp"
 

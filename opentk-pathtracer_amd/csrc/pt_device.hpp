@@ -1,4 +1,4 @@
-// pt_device.hpp — device functions of the path-tracing integrator (included by pt_kernels.hip only): environment
+// pt_device.hpp — device functions of the path-tracing integrator (included by the integrator kernels through pt_kernel_common.hpp, and by pt_helper_kernels.hip): environment
 // sampling, scene traversal (+ the per-tile sphere culling of the tile pass), sampling / BSDF, one bounce, camera
 // rays, pixel resolve.  Each function cites the lines of
 //   /root/reference/OpenTK-PathTracer/res/shaders/PathTracing/compute.glsl
@@ -465,7 +465,9 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
         if (wf >= 0.0f) return false; // (unfinished walk: the caller re-traces this bounce from walkFrom; nothing else of the bounce has happened)
     }
     v3 invd = V(f_rcp(d.x), f_rcp(d.y), f_rcp(d.z)); // slab test by reciprocal (pt-f32 contract)
-    for (int i = 0; i < nc; i++) {
+    // MASKED: masks[4] = the cuboids some ray of the wavefront's bundle can reach (cone_cuboid_mask; all ones = not culled: the plain
+    // loop); a cuboid outside it fails `t1 <= t2 && t2 > 0` for every lane and never changes T
+    auto cuboid = [&](int i) {
         float4 mn = sc.cmin[i], mx = sc.cmax[i];
         v3 t0s = V((mn.x - o.x) * invd.x, (mn.y - o.y) * invd.y, (mn.z - o.z) * invd.z);
         v3 t1s = V((mx.x - o.x) * invd.x, (mx.y - o.y) * invd.y, (mx.z - o.z) * invd.z);
@@ -478,6 +480,15 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
             wt2 = t2;
             winner = 256 + i;
         }
+    };
+    if (MASKED && masks[4] != ~0ull) {
+        for (unsigned long long cm = masks[4]; cm != 0ull; cm &= cm - 1ull) {
+            const int i = (int)__builtin_ctzll(cm);
+            if (i >= nc) break;
+            cuboid(i);
+        }
+    } else {
+        for (int i = 0; i < nc; i++) cuboid(i);
     }
     PROF_MARK(2) // cuboid pass
     if (winner < 0 || !(T != FLOAT_MAX)) return false; // compute.glsl:257
@@ -533,10 +544,12 @@ PT_DEV float wave_max_nonneg(float x)
 // above float rounding), and the test only ever REMOVES spheres that no ray of the wavefront can hit — those would fail
 // `discriminant >= 0 && t2 > 0` (compute.glsl:261-277) for every lane and leave T untouched — so the traced result is
 // bit-identical to visiting all spheres.  Hardware sqrt/rcp approximations are fine here: they only move the padding.
-PT_DEV void cull_spheres(const SceneLds &sc, int ns, bool valid, v3 o, v3 d, unsigned long long masks[4])
+PT_DEV void cone_sphere_masks(const SceneLds &sc, int ns, v3 O, v3 A, float rho, float ct, unsigned long long masks[4]);
+PT_DEV void cull_spheres(const SceneLds &sc, int ns, bool valid, v3 o, v3 d, unsigned long long masks[5])
 {
     const int lane = threadIdx.x & 63;
     masks[0] = masks[1] = masks[2] = masks[3] = 0ull;
+    masks[4] = ~0ull;
     const unsigned long long vm = __ballot(valid);
     if (vm == 0ull) return;
     const int ref = ((vm >> 36) & 1ull) ? 36 : (int)__builtin_ctzll(vm); // pixel (4,4) of the tile, else the first valid lane
@@ -552,7 +565,16 @@ PT_DEV void cull_spheres(const SceneLds &sc, int ns, bool valid, v3 o, v3 d, uns
     float spread = wave_max_nonneg(__builtin_fmaxf(valid ? 1.0f - v_dot(A, d) : 0.0f, 0.0f)); // 1 - cos(angle to A)
     const float rho = __builtin_amdgcn_sqrtf(dev2) * 1.001f;
     const float ct = 1.0f - spread * 1.01f - 1e-5f;          // padded cos(theta)
-    const bool coneUsable = ct > 0.05f;                       // a bundle wider than ~87 degrees is not culled at all
+    cone_sphere_masks(sc, ns, O, A, rho, ct, masks);
+    masks[4] = ~0ull; // (cuboids are only culled by the cached tile masks)
+}
+
+// Lane j tests sphere j (+64, +128, +192) against the cone (apex ball of radius rho around O, axis A, cos of the half-angle ct).
+PT_DEV void cone_sphere_masks(const SceneLds &sc, int ns, v3 O, v3 A, float rho, float ct, unsigned long long masks[4])
+{
+    const int lane = threadIdx.x & 63;
+    masks[0] = masks[1] = masks[2] = masks[3] = 0ull;
+    const bool coneUsable = ct > 0.05f;                       // a bundle wider than ~87 degrees is not culled at all (NaN: neither)
     const float st = __builtin_amdgcn_sqrtf(__builtin_fmaxf(f_fma(-ct, ct, 1.0f), 0.0f));
 #pragma unroll
     for (int w = 0; w < 4; w++) {
@@ -572,6 +594,99 @@ PT_DEV void cull_spheres(const SceneLds &sc, int ns, bool valid, v3 o, v3 d, uns
         }
         masks[w] = __ballot(in && !outside);
     }
+}
+
+// The same cone for EVERY primary ray an 8x8 tile can ever cast (any sub-pixel jitter, any lens sample; compute.glsl:113-121), so that
+// the masks can be computed once per camera / scene and reused by every frame (pt_tile_masks_kernel).  The un-normalised pinhole
+// direction wd = InvView * (InvProj * (ndc, -1, 0)).xy(-1)(0) is an AFFINE function of ndc, so over the tile's rectangle of pixel
+// coordinates [x0, x0 + 8] x [gy0, gy0 + 8] it stays inside the convex hull of its four corner values: every pinhole direction lies
+// within the largest corner angle of the axis (a circular cone of less than 90 degrees is convex).  The thin lens (origin = InvView *
+// (ox, oy, 0, 1) with |(ox, oy)| <= aperture / 2, direction towards ViewPos + dir * focalLength) moves the origin by at most
+// rho = aperture / 2 * ||InvView[:, 0:2]||_F from InvView's translation O, and turns the direction by at most asin(e / (f - e)),
+// e = rho + |ViewPos - O|, f = focalLength.  Anything degenerate (NaN, f <= 2 e, a corner behind the axis) makes the cone unusable:
+// ct = 0 keeps every sphere.
+template <typename FP>
+PT_DEV void mat_vec(FP m, float x, float y, float z, float w, float *out);
+template <typename FP>
+PT_DEV void tile_cone(FP cam, float invW, float invH, int x0, int gy0, v3 &O, v3 &A, float &rho, float &ct, v3 dirs[4], float &lensSin)
+{
+    FP invProj = cam, invView = cam + 16;
+    v3 sum = V(0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float ndcx = f_fma((float)(x0 + ((c & 1) ? 8 : 0)) * invW, 2.0f, -1.0f);
+        const float ndcy = f_fma((float)(gy0 + ((c & 2) ? 8 : 0)) * invH, 2.0f, -1.0f);
+        float eye[4], wd[4];
+        mat_vec(invProj, ndcx, ndcy, -1.0f, 0.0f, eye);
+        mat_vec(invView, eye[0], eye[1], -1.0f, 0.0f, wd);
+        const float l2 = f_fma(wd[2], wd[2], f_fma(wd[1], wd[1], wd[0] * wd[0]));
+        const float il = __builtin_amdgcn_rsqf(l2);
+        dirs[c] = V(wd[0] * il, wd[1] * il, wd[2] * il);
+        sum = V(sum.x + dirs[c].x, sum.y + dirs[c].y, sum.z + dirs[c].z);
+    }
+    const float sl = __builtin_amdgcn_rsqf(f_fma(sum.z, sum.z, f_fma(sum.y, sum.y, sum.x * sum.x)));
+    A = V(sum.x * sl, sum.y * sl, sum.z * sl);
+    float cp = 1.0f; // cos of the largest corner angle
+#pragma unroll
+    for (int c = 0; c < 4; c++) cp = __builtin_fminf(cp, f_fma(A.z, dirs[c].z, f_fma(A.y, dirs[c].y, A.x * dirs[c].x)));
+    O = V(invView[12], invView[13], invView[14]);
+    const float half_ap = __builtin_fabsf(cam[36]) * 0.5f;
+    const float frob = __builtin_amdgcn_sqrtf(invView[0] * invView[0] + invView[1] * invView[1] + invView[2] * invView[2] +
+                                              invView[4] * invView[4] + invView[5] * invView[5] + invView[6] * invView[6]);
+    rho = f_fma(half_ap * frob, 1.002f, 1e-6f);
+    const v3 c0 = V(cam[32] - O.x, cam[33] - O.y, cam[34] - O.z);
+    const float e = rho + __builtin_amdgcn_sqrtf(f_fma(c0.z, c0.z, f_fma(c0.y, c0.y, c0.x * c0.x))) * 1.002f;
+    const float f = cam[35];
+    const bool ok = f > 2.0f * e && cp > 0.0f; // (NaN anywhere: false)
+    const float q = e * __builtin_amdgcn_rcpf(f - e) * 1.002f;                          // sin of the lens' turn, padded
+    const float cq = __builtin_amdgcn_sqrtf(__builtin_fmaxf(f_fma(-q, q, 1.0f), 0.0f));
+    const float sp = __builtin_amdgcn_sqrtf(__builtin_fmaxf(f_fma(-cp, cp, 1.0f), 0.0f)) * 1.002f + 1e-4f; // sin of the corner angle, padded
+    const float ctot = f_fma(cp, cq, -(sp * q));                                         // cos(corner angle + lens turn)
+    const float spread = 1.0f - ctot;
+    ct = ok ? 1.0f - spread * 1.02f - 2e-4f : 0.0f;
+    rho = ok ? rho : 0.0f;
+    lensSin = q;
+}
+
+// The cuboids a tile's rays can reach (bit i = cuboid i; all of them when the cone is unusable).  The rays leave the ball (O, rho) in
+// directions within asin(lensSin) of the pinhole directions, which lie in the pyramid spanned by the four corner directions.  For a
+// side plane of that pyramid with inward unit normal n, every point p of such a ray satisfies
+//     n . (p - O) >= -rho - (|p - O| + rho) * lensSin,
+// and g(p) = n . (p - O) + (|p - O| + rho) * lensSin + rho is convex in p, so a box whose eight corners all have g < 0 for ONE plane is
+// reached by no ray of the tile: its slab test fails `t1 <= t2 && t2 > 0` (compute.glsl:279-294) for every lane.  Padded by 0.2 % of
+// the coordinates' magnitude, far above the rounding of the slab test.  Lane j tests cuboid j.
+PT_DEV unsigned long long cone_cuboid_mask(const SceneLds &sc, int nc, v3 O, float rho, float ct, const v3 dirs[4], float lensSin)
+{
+    const int lane = threadIdx.x & 63;
+    const bool usable = ct > 0.05f;
+    const bool in = lane < nc;
+    const float4 mn = sc.cmin[in ? lane : 0], mx = sc.cmax[in ? lane : 0];
+    const float scale = 1.0f + f_max(f_max(f_abs(O.x), f_max(f_abs(O.y), f_abs(O.z))),
+                                     f_max(f_max(f_abs(mn.x), f_max(f_abs(mn.y), f_abs(mn.z))), f_max(f_abs(mx.x), f_max(f_abs(mx.y), f_abs(mx.z)))));
+    const float pad = f_fma(scale, 2e-3f, rho * 1.01f);
+    const float q = f_fma(lensSin, 1.01f, 1e-3f);
+    bool outside = false;
+    const int order[5] = {0, 1, 3, 2, 0}; // the tile's corners in cyclic order
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const v3 a = dirs[order[e]], b = dirs[order[e + 1]];
+        v3 n = V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+        const v3 mid = V(dirs[0].x + dirs[1].x + dirs[2].x + dirs[3].x, dirs[0].y + dirs[1].y + dirs[2].y + dirs[3].y, dirs[0].z + dirs[1].z + dirs[2].z + dirs[3].z);
+        const float il = __builtin_amdgcn_rsqf(f_fma(n.z, n.z, f_fma(n.y, n.y, n.x * n.x)));
+        const float sgn = (n.x * mid.x + n.y * mid.y + n.z * mid.z) < 0.0f ? -il : il; // inward: the pyramid's axis is on the positive side
+        n = V(n.x * sgn, n.y * sgn, n.z * sgn);
+        bool allOut = true;
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            const v3 p = V(((v & 1) ? mx.x : mn.x) - O.x, ((v & 2) ? mx.y : mn.y) - O.y, ((v & 4) ? mx.z : mn.z) - O.z);
+            const float len = __builtin_amdgcn_sqrtf(f_fma(p.z, p.z, f_fma(p.y, p.y, p.x * p.x)));
+            const float g = f_fma(n.x, p.x, f_fma(n.y, p.y, n.z * p.z)) + f_fma(len + rho, q, pad);
+            allOut = allOut && (g < 0.0f); // (NaN: false -> the cuboid is kept)
+        }
+        outside = outside || allOut;
+    }
+    const unsigned long long keep = __ballot(in && !(usable && outside));
+    return keep;
 }
 
 // ---------------------------------------------------------------------------------------------- sampling / BSDF

@@ -192,8 +192,14 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                 valid = valid && !twaiting;
                 v3 to = V(0.0f, 0.0f, 0.0f), td = V(0.0f, 0.0f, 1.0f), tthr = V(1.0f, 1.0f, 1.0f), trad = V(0.0f, 0.0f, 0.0f);
                 if (valid) primary_ray_cam(cam, invW, invH, tpxy & 0xffff, tpxy >> 16, tseed, to, td);
-                unsigned long long masks[4];
-                cull_spheres(sc, a.numSpheres, valid, to, td, masks);
+                unsigned long long masks[5];
+                if (!fromQueue && ca->tileMasks != nullptr) { // a fresh tile (sample 0): the tile's cached masks, as in the spp = 1 tile pass
+                    const __attribute__((address_space(4))) unsigned long long *tm =
+                        (const __attribute__((address_space(4))) unsigned long long *)ca->tileMasks + (size_t)tile * kTileMaskWords;
+                    masks[0] = tm[0]; masks[1] = tm[1]; masks[2] = tm[2]; masks[3] = tm[3]; masks[4] = tm[4];
+                } else {
+                    cull_spheres(sc, a.numSpheres, valid, to, td, masks); // (continuations of several tiles: bounded from the rays themselves)
+                }
                 bool tcont = false;
                 if (valid) {
                     if (0 < a.rayDepth) tcont = bounce_step_t<true, MATLDS>(sc, a.numSpheres, a.numCuboids, env, to, td, tthr, trad, tseed, masks, walkFresh PROF_DUMMY);

@@ -398,8 +398,14 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                             primary_ray_cam(cam, invW, invH, x, gy, tseed, to, td);
                             tpix = ly * width + x;
                         }
-                        unsigned long long masks[4];
-                        cull_spheres(sc, a.numSpheres, valid, to, td, masks);
+                        unsigned long long masks[5];
+                        if (const unsigned long long *cached = ca->tileMasks) { // (wave-uniform tile: four scalar loads, no arithmetic)
+                            const __attribute__((address_space(4))) unsigned long long *tm =
+                                (const __attribute__((address_space(4))) unsigned long long *)cached + (size_t)tile * kTileMaskWords;
+                            masks[0] = tm[0]; masks[1] = tm[1]; masks[2] = tm[2]; masks[3] = tm[3]; masks[4] = tm[4];
+                        } else {
+                            cull_spheres(sc, a.numSpheres, valid, to, td, masks);
+                        }
                         bool tcont = false, tkeep = false; // tkeep: the path goes to the ring (it continues, or its resolve must wait)
                         [[maybe_unused]] bool plastOk = false; // (CARRY)
                         [[maybe_unused]] float4 plast = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -757,6 +763,41 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     }
 }
 
+// ---- cached tile masks (FrameArgs::tileMasks): one wavefront per 8x8 tile, lane j tests sphere j (+64, +128, +192) against the cone that
+// bounds every primary ray the tile can cast (tile_cone).  Runs once per camera / scene change, never per frame.
+__global__ __launch_bounds__(256) void pt_tile_masks_kernel(const FrameArgs a, unsigned long long *out)
+{
+    SceneLds sc = stage_scene(a); // (geometry only: the launch clears materialsInLds / envFormat / gridLdsBytes)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.tilesX * a.tilesY) return;
+    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const int gy0 = global_row(a, ty * 8); // (band heights are multiples of 8: a tile's eight rows are consecutive image rows)
+    v3 O, A, dirs[4];
+    float rho, ct, lensSin;
+    tile_cone<const float *>(a.invProj, f_div_ieee(1.0f, (float)a.width), f_div_ieee(1.0f, (float)a.height), tx * 8, gy0, O, A, rho, ct, dirs, lensSin);
+    unsigned long long masks[5];
+    cone_sphere_masks(sc, a.numSpheres, O, A, rho, ct, masks);
+    masks[4] = cone_cuboid_mask(sc, a.numCuboids, O, rho, ct, dirs, lensSin);
+    if (lane == 0) {
+        unsigned long long *o = out + (size_t)tile * kTileMaskWords;
+        o[0] = masks[0]; o[1] = masks[1]; o[2] = masks[2]; o[3] = masks[3]; o[4] = masks[4]; o[5] = o[6] = o[7] = 0ull;
+    }
+}
+
+hipError_t launch_tile_masks(const FrameArgs &args, unsigned long long *masks, hipStream_t stream)
+{
+    FrameArgs a = args;
+    a.materialsInLds = 0;
+    a.envFormat = 0;
+    a.gridLdsBytes = 0;
+    const int tiles = a.tilesX * a.tilesY;
+    if (tiles <= 0) return hipSuccess;
+    const size_t lds = scene_lds_bytes(a.numSpheres, a.numCuboids, 0, false);
+    hipLaunchKernelGGL(pt_tile_masks_kernel, dim3((tiles + 3) / 4), dim3(256), lds, stream, a, masks);
+    return hipGetLastError();
+}
+
 // Kernel variants (pt_set_variant; every variant produces the same bits):
 //   0        default = persistent queue kernel (5 workgroups per CU per stripe; 6 for a pipelined batch)
 //   1        one wavefront per 8x8 tile, one pixel per lane (the reference's own mapping; simplest kernel)
@@ -815,7 +856,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         // whole queue, can fill up with results that wait for exactly that parked work.  Round 2 saw that end in the stall bound's
         // error code (225 tiles per frame, 32 frames: 2-4 % of launches).  Round 3: the kernel's FORCED BATCH PASS (a wavefront
         // whose lanes all wait runs a pass over its oldest parked records anyway) makes the parked work progress whatever the lanes
-        // hold, so the cycle cannot form any more (tools/handover_stress --multisample with PT_BATCH_PASS_MIN_TILES=0 sends every
+        // hold, so the cycle cannot form any more (tools/handover_stress --multisample --tune batch_pass_min_tiles=0 sends every
         // such launch through this kernel).  Small images still take the in-lane sample chain — for speed: when consecutive frames
         // of a tile meet in one wavefront all the time, the queue mostly rotates waiting records.  16,384 tiles per frame
         // (1024 x 1024) leave a wavefront 3-4 tiles per frame.

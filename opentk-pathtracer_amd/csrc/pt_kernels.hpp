@@ -1,4 +1,5 @@
-// pt_kernels.hpp — host-visible launch interface of the HIP kernels (implemented in pt_kernels.hip).
+// pt_kernels.hpp — host-visible launch interface of the HIP kernels (implemented in pt_integrate_persistent.hip, pt_integrate_multisample.hip
+// and pt_helper_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -67,6 +68,10 @@ struct FrameArgs {
     // i - 1 (bit 0 is always set).  Inside a run the loop reuses o.x - c.x, o.z - c.z and the two products that start the dot-product
     // chains — the same binary32 values the per-sphere evaluation would produce (pt_sphere_grid.hpp: sphere_runs).
     unsigned long long sphereRunStart[4];
+    // Cached tile masks (nullptr = the tile pass culls against its own 64 rays): per 8x8 tile of this launch's rows 4 x 64 bits, the
+    // spheres that ANY primary ray of the tile can reach, whatever the jitter and the lens sample — computed once per camera / scene by
+    // pt_tile_masks_kernel (tile_cone in pt_device.hpp) and read with scalar loads by every frame's tile pass
+    const unsigned long long *tileMasks; // kTileMaskWords words per tile: [0..3] spheres, [4] cuboids
     // Present snapshot (non-blocking present, mi355pt.cpp pt_present_rgba8_async): when set, the resolve of the launch's LAST frame
     // also stores the pixel's new value here (same indexing as accum) — a consistent image of that frame that later frames never
     // touch, so the tone map can read it while the next launch (chained, ordered per pixel by the tags) already overwrites accum.
@@ -77,9 +82,10 @@ struct FrameArgs {
     // "one ordered read-modify-write per pixel per frame".  Violations go to auditLog (host-mapped): [0] = count, 12 words each.
     unsigned long long *audit;
     unsigned int *auditLog;
-    int auditSabotage;      // audit build, PT_AUDIT_SABOTAGE=n: every n-th (pixel, frame) folds into a perturbed colour, as a stale or torn read would — proves that the audit sees it
+    int auditSabotage;      // audit build, tuning knob audit_sabotage = n: every n-th (pixel, frame) folds into a perturbed colour, as a stale or torn read would — proves that the audit sees it
 };
 constexpr int kAuditLogRecords = 1024, kAuditRecordWords = 12;
+constexpr int kTileMaskWords = 8; // 64 bytes per tile (FrameArgs::tileMasks)
 constexpr int kStartedWords = 4096; // capacity of FrameArgs::startedFlags (a launch with more workgroups does not report in)
 
 // the persistent kernel reads the camera block straight from its kernarg segment (see primary_ray_cam)
@@ -100,6 +106,8 @@ struct AtmoArgs {
 // workgroups: the grid size of the launch (persistent kernels)
 hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int *ticketsConsumed, int *workgroups = nullptr);
 hipError_t launch_atmosphere(const AtmoArgs &a, hipStream_t stream);
+// masks[kTileMaskWords * tile + w] for every 8x8 tile of the launch described by `a` (tilesX x tilesY tiles; see FrameArgs::tileMasks)
+hipError_t launch_tile_masks(const FrameArgs &a, unsigned long long *masks, hipStream_t stream);
 hipError_t launch_clear(float4 *p, size_t n, hipStream_t stream);
 // alpha := 1 over n pixels (pt_write_result / pt_bind_result_buffer: alpha is the frame tag inside pipelined launches)
 hipError_t launch_set_alpha(float4 *p, size_t n, hipStream_t stream);

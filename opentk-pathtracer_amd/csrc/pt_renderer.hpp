@@ -3,7 +3,7 @@
 //
 // What the reference keeps in the C# class PathTracer (/root/reference/OpenTK-PathTracer/src/Render/PathTracer.cs:9-141)
 // plus the two UBOs MainWindow owns (src/MainWindow.cs:195-201), and the HIP plumbing around the kernels of
-// pt_kernels.hip.  There is deliberately NO CPU fallback anywhere behind this struct.
+// the pt_*.hip files.  There is deliberately NO CPU fallback anywhere behind this struct.
 #pragma once
 #include "../../include/mi355pt.h"
 
@@ -67,6 +67,13 @@ struct pt_renderer {
     bool gridDirty = true;
     ptgrid::SphereGrid grid;
     unsigned long long sphereRunStart[4] = {~0ull, ~0ull, ~0ull, ~0ull}; // FrameArgs::sphereRunStart, rebuilt with the grid
+    // Cached tile masks (FrameArgs::tileMasks): rebuilt by pt_tile_masks_kernel when the camera, the lens, the spheres or the tiling
+    // changed AND the camera has then been left alone for two launches (a host that moves the camera every frame keeps the per-tile
+    // culling of the tile pass: rebuilding needs the two launch streams joined, which would break its chaining)
+    unsigned long long *dTileMasks = nullptr;
+    size_t tileMaskTiles = 0;        // capacity in tiles
+    bool tileMasksValid = false;
+    int launchesSinceInputChange = 0;
     unsigned char *dGrid = nullptr; // (kMaxCells + 1) * 2 + kMaxRefs bytes
     float *dLut = nullptr;          // 256-entry sRGB table
     unsigned int *dQueue = nullptr; // global chunk-ticket counter of the persistent kernel (never reset: epoch scheme)
@@ -75,7 +82,7 @@ struct pt_renderer {
     unsigned int *hostErrWord = nullptr, *devErrWord = nullptr;
     int queueChunk = 0;             // tiles per global ticket; 0 = automatic (tuning knob queue_chunk)
     unsigned long long *dTimeline = nullptr; // tuning only (pt_debug_timeline)
-    // Frame pipelining: consecutive pt_render calls are collected and launched as ONE batch kernel (see pt_kernels.hip)
+    // Frame pipelining: consecutive pt_render calls are collected and launched as ONE batch kernel (see pt_integrate_persistent.hip)
     // when nothing observable happens in between; every other entry point launches what is pending first.
     int pendingFrames = 0;        // frames accepted by pt_render, not launched yet
     int maxBatch = 64;            // pt_set_frame_batch: 1 turns batching off (every pt_render launches at once)
@@ -121,7 +128,7 @@ struct pt_renderer {
     size_t rgba8Capacity = 0;     // in pixels
     size_t boundBytes = 0;
 
-    // hand-over audit (only allocated by the -DPT_AUDIT build, see pt_kernels.hip): side word per accumulation pixel + violation log
+    // hand-over audit (only allocated by the -DPT_AUDIT build, see pt_debug_hooks.hpp): side word per accumulation pixel + violation log
     unsigned long long *dAudit = nullptr;
     size_t auditCapacity = 0; // in pixels
     unsigned int *hostAuditLog = nullptr, *devAuditLog = nullptr;

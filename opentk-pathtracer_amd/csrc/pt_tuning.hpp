@@ -21,7 +21,7 @@ struct Tuning {
     int noSingleTagged = 0;        // 1: single frames never chain
     int shortWorkgroupsPerCU = 5;  // workgroups per CU of launches of fewer than 8 frames
     long chainWaitUs = 60000;      // back-pressure: how long a launch waits for its predecessor to become resident
-    // kernel selection (pt_kernels.hip: launch_integrate)
+    // kernel selection (pt_integrate_persistent.hip: launch_integrate)
     int parkedMax = -1;            // >= 0: parked resolves per wavefront
     int noBatchPass = 0;           // 1: spp > 1 keeps the in-lane sample chain
     long long batchPassMinTiles = 16384; // pipelined spp > 1 launches over fewer tiles per frame keep the in-lane sample chain
@@ -29,6 +29,7 @@ struct Tuning {
     int parkMin = 40;              // parked continuations that make a batch pass worth running
     int noSphereGrid = 0;          // 1: large scenes keep the reference's in-order sphere loop
     int forceLeanLds = 0;          // 1: materials are always read from the UBO copy
+    int tileMasks = 1;             // 0: the tile pass always culls the spheres against its own 64 rays (no cached per-tile masks)
     int carryLast = 1;             // 0: the pixel never travels with its path (every resolve loads it; the kernel of rounds 1-3)
     // sphere grid build (pt_sphere_grid.hpp)
     int gridMinSpheres = 64;       // scenes with fewer spheres get no grid
@@ -68,6 +69,7 @@ inline bool tuning_set(const char *key, long long v)
     PT_KNOB("no_sphere_grid", noSphereGrid)
     PT_KNOB("force_lean_lds", forceLeanLds)
     PT_KNOB("carry_last", carryLast)
+    PT_KNOB("tile_masks", tileMasks)
     PT_KNOB("grid_min_spheres", gridMinSpheres)
     PT_KNOB("grid_cells", gridCells)
     PT_KNOB("grid_dim_x", gridDims[0])

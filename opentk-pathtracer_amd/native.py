@@ -78,7 +78,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 # Diagnostic builds of the same sources (never loaded by the product path; tools/handover_stress.cpp and the GPU test that runs it):
-#   audit       -DPT_AUDIT            every pixel read-modify-write mirrored by a device-scope atomic side word (pt_kernels.hip)
+#   audit       -DPT_AUDIT            every pixel read-modify-write mirrored by a device-scope atomic side word (csrc/pt_debug_hooks.hpp)
 #   chaos       -DPT_CHAOS            pseudo-random s_sleep delays at the hand-over protocol's decision points
 #   audit_chaos both
 VARIANTS = {"audit": ["-DPT_AUDIT"], "chaos": ["-DPT_CHAOS"], "audit_chaos": ["-DPT_AUDIT", "-DPT_CHAOS"]}

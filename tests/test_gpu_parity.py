@@ -135,6 +135,69 @@ def test_tile_pass_culling_is_conservative(pkg, native_lib, oracle, scene, size,
         assert_bit_exact(hip_render(pkg, w), oracle_render(oracle, w), f"{w.name} pos={pos} look={look}")
 
 
+@pytest.mark.parametrize("scene,size,aperture,focal", [
+    ("stress256", (128, 72), 0.14, 20.0), ("stress256", (24, 16), 0.14, 20.0), ("default", (8, 8), 0.14, 20.0),
+    ("default", (96, 54), 8.0, 2.0), ("default", (96, 54), 0.5, 0.3), ("edge", (96, 54), 1.0, 6.0), ("randmat", (96, 54), 0.0, 20.0),
+], ids=lambda v: str(v))
+def test_cached_tile_masks_are_conservative(pkg, native_lib, oracle, scene, size, aperture, focal):
+    """Round 4: once the camera has been left alone for two launches, the tile pass takes its sphere masks from a per-tile cache that
+    pt_tile_masks_kernel fills from an ANALYTIC bound of every ray the tile can cast (any jitter, any lens sample: tile_cone,
+    pt_device.hpp).  Random cameras all over (and inside) the scenes, lenses from pinhole to larger than the focal length: five launches
+    of four frames (the last three with cached masks), the camera then moved (masks stale, per-tile culling again, rebuilt two launches
+    later) — bit for bit the brute-force oracle."""
+    cams = _random_cameras(5, 7 * sum(map(ord, scene)) + size[0])
+    for k, (pos, look) in enumerate(cams):
+        w = configs.Workload(f"masks_{scene}_{k}", scene, size[0], size[1], 6, "sky_f32_32", aperture=aperture, focal_length=focal,
+                             look=look, position=pos)
+        sc, basic, objs, env, kw = configs.inputs(w)
+        pt = pkg.PathTracer(env, w.width, w.height, w.ray_depth, 1, w.focal_length, w.aperture)
+        pt.UploadScene(sc)
+        pt.UploadBasicData(basic)
+        for _ in range(5):
+            for _ in range(4):
+                pt.Render()
+            pt.Synchronize()
+        want = oracle.render(w.width, w.height, basic, objs, env, num_frames=20, **kw)
+        assert_bit_exact(pt.Result, want, f"{w.name} pos={pos} look={look} (cached masks)")
+        # move the camera: the accumulation restarts, the masks are stale until two launches later
+        pos2, look2 = cams[(k + 1) % len(cams)]
+        w2 = configs.Workload(f"masks_{scene}_{k}b", scene, size[0], size[1], 6, "sky_f32_32", aperture=aperture, focal_length=focal,
+                              look=look2, position=pos2)
+        _, basic2, _, _, _ = configs.inputs(w2)
+        pt.UploadBasicData(basic2)
+        pt.ResetRenderer()
+        for _ in range(4):
+            for _ in range(3):
+                pt.Render()
+            pt.Synchronize()
+        want2 = oracle.render(w.width, w.height, basic2, objs, env, num_frames=12, **kw)
+        assert_bit_exact(pt.Result, want2, f"{w2.name} pos={pos2} look={look2} (after a camera move)")
+        pt.Dispose()
+
+
+def test_cached_tile_masks_in_the_multisample_kernel(pkg, native_lib, oracle):
+    """The spp > 1 batch-pass kernel takes the cached masks for its fresh-tile passes (sample 0); continuations keep the per-bundle
+    culling.  Small images only reach that kernel with the tuning knob batch_pass_min_tiles = 0."""
+    pkg.native.debug_set("batch_pass_min_tiles", 0)
+    try:
+        for k, (pos, look) in enumerate(_random_cameras(4, 4242)):
+            for scene in ("default", "stress256"):
+                w = configs.Workload(f"masks_ms_{scene}_{k}", scene, 96, 54, 6, "sky_f32_32", spp=3, look=look, position=pos)
+                sc, basic, objs, env, kw = configs.inputs(w)
+                pt = pkg.PathTracer(env, w.width, w.height, w.ray_depth, w.spp, w.focal_length, w.aperture)
+                pt.UploadScene(sc)
+                pt.UploadBasicData(basic)
+                for _ in range(5):
+                    for _ in range(3):
+                        pt.Render()
+                    pt.Synchronize()
+                want = oracle.render(w.width, w.height, basic, objs, env, num_frames=15, **kw)
+                assert_bit_exact(pt.Result, want, f"{w.name} pos={pos} look={look}")
+                pt.Dispose()
+    finally:
+        pkg.native.debug_set("batch_pass_min_tiles", 16384)
+
+
 @pytest.mark.parametrize("size,frames,batch", [((8, 8), 64, 16), ((8, 8), 70, 32), ((16, 8), 150, 64), ((24, 16), 40, 16), ((128, 72), 23, 16), ((128, 72), 23, 5),
                                                ((128, 72), 23, 1), ((96, 54), 37, 2)], ids=lambda v: str(v))
 def test_frame_pipelining_is_bit_exact(pkg, native_lib, oracle, size, frames, batch):

@@ -3,7 +3,7 @@
   * the hand-over machinery under its own audit: tools/handover_stress (native, thousands of random call sequences through the
     C ABI, every observed image compared bit for bit with the same sequence rendered by the simplest kernel) against the
     product library and against the -DPT_AUDIT -DPT_CHAOS build, whose kernels mirror every pixel read-modify-write with a
-    device-scope atomic side word and inject random delays at the protocol's decision points (csrc/pt_kernels.hip);
+    device-scope atomic side word and inject random delays at the protocol's decision points (csrc/pt_debug_hooks.hpp);
   * the spp > 1 batch-pass kernel forced onto tiny pipelined images (tuning knob batch_pass_min_tiles = 0), where round 2 saw its
     hand-over stall, and a pipelined spp > 1 launch at >= 16,384 tiles per frame (advisor finding, round 2);
   * REAL peers: everything the group-handle / RCCL tests do with device 0 named several times, on distinct devices — skipped

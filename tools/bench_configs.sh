@@ -11,6 +11,7 @@ python $R/bench.py --no-cpu-baseline --steady-ms 0 --depth 13 >> $O             
 python $R/bench.py --no-cpu-baseline --steady-ms 0 --spp 4 --steps 240 --warmup 80 >> $O                   # 4 samples per pixel per frame
 python $R/bench.py --no-cpu-baseline --steady-ms 0 --config C3 --spp 4 --steps 240 --warmup 80 >> $O       # C3 at 4 samples per pixel
 python $R/bench.py --no-cpu-baseline --steady-ms 0 --config C3 --tune no_sphere_grid=1 >> $O                   # C3 with the reference's in-order sphere loop (no grid)
+python $R/bench.py --no-cpu-baseline --steady-ms 0 --tune carry_last=0 >> $O                    # default scene, every resolve loads its pixel (the kernel of rounds 1-3)
 python $R/bench.py --no-cpu-baseline --steady-ms 0 --frame-batch 1 >> $O                       # one launch per frame (2 overlapping row stripes)
 python $R/bench.py --no-cpu-baseline --steady-ms 0 --strong-4k >> $O                          # 3840x2160 on one GPU
 python $R/bench.py --no-cpu-baseline --steady-ms 0 --variant 1 >> $O                           # tile-per-wave kernel (reference mapping)

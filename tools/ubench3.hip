@@ -142,6 +142,32 @@ template <int MODE> __global__ __launch_bounds__(256, 8) void k(float *out, unsi
         } else if (MODE == 32) { // 32 per iteration: v_mul / v_fma alternating
             asm volatile(R8("v_mul_f32 %0, %0, %4\n v_fma_f32 %1, %1, %4, %5\n v_mul_f32 %2, %2, %4\n v_fma_f32 %3, %3, %4, %5\n")
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m), "v"(c));
+        } else if (MODE >= 33 && MODE <= 39) {
+            // LDS read cost against VALU work: R broadcast reads of width B (all lanes one address), then V v_mul.
+            //   33: 4 x b32 + 8   34: 4 x b64 + 8   35: 2 x b128 + 8   36: 1 x b128 + 8   37: 4 x b128 + 40   38: 2 x b128 + 40   39: 0 reads + 40
+            float4 q0 = make_float4(m, m, m, m), q1 = q0, q2 = q0, q3 = q0;
+            if (MODE == 33)
+                asm volatile("ds_read_b32 %0, %4\n ds_read_b32 %1, %4 offset:16\n ds_read_b32 %2, %4 offset:32\n ds_read_b32 %3, %4 offset:48\n s_waitcnt lgkmcnt(0)"
+                             : "=v"(q0.x), "=v"(q1.y), "=v"(q2.z), "=v"(q3.w) : "v"(sacc & 1023) : "memory");
+            if (MODE == 34) {
+                float2 p0, p1, p2, p3;
+                asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:16\n ds_read_b64 %2, %4 offset:32\n ds_read_b64 %3, %4 offset:48\n s_waitcnt lgkmcnt(0)"
+                             : "=v"(p0), "=v"(p1), "=v"(p2), "=v"(p3) : "v"(sacc & 1023) : "memory");
+                q0.x = p0.x; q1.y = p1.y; q2.z = p2.x; q3.w = p3.y;
+            }
+            if (MODE == 35 || MODE == 38)
+                asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:16\n s_waitcnt lgkmcnt(0)" : "=v"(q0), "=v"(q1) : "v"(sacc & 1023) : "memory");
+            if (MODE == 36) asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(q0) : "v"(sacc & 1023) : "memory");
+            if (MODE == 37)
+                asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:16\n ds_read_b128 %2, %4 offset:32\n ds_read_b128 %3, %4 offset:48\n s_waitcnt lgkmcnt(0)"
+                             : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3) : "v"(sacc & 1023) : "memory");
+#define MUL8 "v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %9\n v_mul_f32 %2, %2, %10\n v_mul_f32 %3, %3, %11\n v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %9\n v_mul_f32 %6, %6, %10\n v_mul_f32 %7, %7, %11\n"
+            if (MODE >= 37)
+                asm volatile(MUL8 MUL8 MUL8 MUL8 MUL8
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(q0.x), "v"(q1.y), "v"(q2.z), "v"(q3.w));
+            else
+                asm volatile(MUL8 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(q0.x), "v"(q1.y), "v"(q2.z), "v"(q3.w));
+#undef MUL8
         }
     }
     unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
@@ -179,11 +205,21 @@ template <int MODE> void run(const char *name, int valuPerIter, int blocksPerCU)
     run<25>("(v_cmp -> vcc, v_cndmask) x4 [8 VALU]", 8, W);                    \
     run<26>("(v_cmp -> SGPR pair, v_cndmask) x4 [8 VALU]", 8, W);              \
     run<27>("4 v_cmp -> SGPR pairs, then 4 v_cndmask [8 VALU]", 8, W);
-int main()
+#define LDS(W)                                                                 \
+    run<22>("4 broadcast ds_read_b128 + wait + 8 v_mul", 8, W);                \
+    run<33>("4 broadcast ds_read_b32 + wait + 8 v_mul", 8, W);                 \
+    run<34>("4 broadcast ds_read_b64 + wait + 8 v_mul", 8, W);                 \
+    run<35>("2 broadcast ds_read_b128 + wait + 8 v_mul", 8, W);                \
+    run<36>("1 broadcast ds_read_b128 + wait + 8 v_mul", 8, W);                \
+    run<39>("40 v_mul", 40, W);                                                \
+    run<37>("4 broadcast ds_read_b128 + wait + 40 v_mul", 40, W);              \
+    run<38>("2 broadcast ds_read_b128 + wait + 40 v_mul", 40, W);
+int main(int argc, char **argv)
 {
+    const bool lds = argc > 1 && argv[1][0] == 'l'; // "lds": what a broadcast LDS read costs beside VALU work
     for (int w : {1, 6}) {
         printf("--- %d wavefront(s) per SIMD\n", w);
-        ALL(w)
+        if (lds) { LDS(w) } else { ALL(w) }
     }
     return 0;
 }
