@@ -93,6 +93,15 @@ def load_profile_number(file_name: str, workload_key: str, csrc_hash: str):
     return e["value"], None
 
 
+def load_profile_entry(file_name: str, workload_key: str, csrc_hash: str) -> dict:
+    """The whole entry behind load_profile_number (same staleness rule), or {}."""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", file_name))).get(workload_key)
+    except Exception:
+        return {}
+    return e if isinstance(e, dict) and e.get("csrc_hash") == csrc_hash else {}
+
+
 # VALU issue roof: the 157.3 TFLOP/s FP32 vector peak = 1024 SIMDs x 32 lanes x 2 flops x 2.4 GHz, i.e. at best one
 # wave64 instruction per 2 clocks per SIMD.  (A dependence-free v_fma_f32 stream sustains one per 2.63 clocks with
 # 4 wavefronts per SIMD, tools/ubench2.hip; the integrator's mix — with instructions that retire early under an empty
@@ -595,7 +604,16 @@ def main():
                                               "note": "the binding roof: SQ_INSTS_VALU per step (rocprofv3 PMC pass committed under "
                                                       "profiles/, same kernel sources: csrc_hash) / kernel time, against one wave64 VALU "
                                                       "instruction per 2 clocks per SIMD (the rate behind the 157.3 TFLOP/s FP32 vector "
-                                                      "peak); a pure v_fma_f32 stream sustains 2.63 clocks (tools/ubench2.hip)"}
+                                                      "peak).  Measured on whole-machine launches (tools/ubench3.hip, profiles/r04/ubench3_*.log): "
+                                                      "a VALU stream sustains one instruction per ~2.4 clocks at 6 wavefronts per SIMD, and a "
+                                                      "scalar / branch instruction of the same wavefronts takes an issue slot of about the same "
+                                                      "length - `all_issue` counts them too"}
+            other = load_profile_entry("valu_insts.json", wl_key, csrc_hash).get("other")
+            if other:
+                tot = vi + sum(other.values())
+                out["roofline"]["valu_issue"]["all_issue"] = {"wave_insts_per_step": tot, **other,
+                                                               "achieved": round(tot / (kernel_ms * 1e-3) / 1e9, 1),
+                                                               "frac_of_valu_peak": round(tot / (kernel_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_GINST, 4)}
         elif vi_note:
             out["roofline"]["valu_issue"] = None
             out["roofline"]["valu_issue_note"] = vi_note

@@ -512,6 +512,8 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     a.apertureDiameter = h->apertureDiameter;
     a.width = h->width;
     a.height = h->height;
+    a.invW = 1.0f / (float)h->width; // (correctly rounded, like the device's f_div_ieee)
+    a.invH = 1.0f / (float)h->height;
     a.numSpheres = h->numSpheres;
     a.numCuboids = h->numCuboids;
     a.rayDepth = h->rayDepth;

@@ -405,7 +405,8 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
                 disc[k] = f_fma(b[k], b[k], -c[k]);
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) candidate(i + k, b[k], c[k], disc[k]);
+            for (int k = 0; k < 4; k++) // (`any`: see the run loop below)
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(disc[k] < 0.0f)) != 0ull, 0)) candidate(i + k, b[k], c[k], disc[k]);
         }
         for (; i < ns; i++) {
             float4 s = sc.sph[i];
@@ -415,39 +416,43 @@ PT_DEV bool ray_trace_t(const SceneLds &sc, int ns, int nc, v3 o, v3 d, Hit &h, 
             candidate(i, b, c, f_fma(b, b, -c));
         }
     } else if (i < ns) {
+        // Issue slots, not arithmetic, are what this loop costs (tools/ubench3.hip: a scalar instruction takes an issue slot like a
+        // vector one): per sphere ONE asm block (the compiler pads every asm statement with an s_nop), the run bit tested straight
+        // from the 32-bit word, and a sphere that no lane can hit costs one compare and one scalar branch (`any`, below).
         ColdArgs rca = cold_args();
-        unsigned int runs = 0u;
         float ocz = 0.0f, bx = 0.0f, cx = 0.0f;
 #define PT_RUN_SPHERE(S, K)                                                                                              \
-        if (runs & (1u << (K))) {                                                                                        \
-            float ocx;                                                                                                   \
-            asm volatile("v_sub_f32 %0, %1, %2" : "=v"(ocx) : "v"(o.x), "v"(S.x));                                       \
-            ocz = o.z - S.z;                                                                                             \
-            bx = d.x * ocx;                                                                                              \
-            cx = ocx * ocx;                                                                                              \
-        }                                                                                                                \
-        {                                                                                                                \
-            const float ocy = o.y - S.y;                                                                                 \
-            float t1, u1;                                                                                                \
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(d.y), "v"(ocy), "v"(bx));   /* fma(d.y, oc.y, d.x * oc.x) */  \
-            asm volatile("v_fma_f32 %0, %1, %1, %2" : "=v"(u1) : "v"(ocy), "v"(cx));             /* fma(oc.y, oc.y, oc.x * oc.x) */ \
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(b[K]) : "v"(d.z), "v"(ocz), "v"(t1)); /* == v_dot(d, oc) */             \
-            asm volatile("v_fma_f32 %0, %1, %1, %2" : "=v"(u1) : "v"(ocz), "v"(u1));             /* == v_dot(oc, oc) */            \
-            c[K] = f_fma(-S.w, S.w, u1);                                                          /* ... - r * r */                \
-            disc[K] = f_fma(b[K], b[K], -c[K]);                                                                          \
-        }
-        for (; i + 4 <= ns; i += 4) {
-            if ((i & 31) == 0) runs = ((const __attribute__((address_space(4))) unsigned int *)rca->sphereRunStart)[i >> 5];
-            const float4 s0 = sc.sph[i], s1 = sc.sph[i + 1], s2 = sc.sph[i + 2], s3 = sc.sph[i + 3];
-            float b[4], c[4], disc[4];
-            asm volatile("" ::"v"(s0.x), "v"(s0.z), "v"(s1.x), "v"(s1.z), "v"(s2.x), "v"(s2.z), "v"(s3.x), "v"(s3.z)); // (whole float4 reads, all four at once)
-            PT_RUN_SPHERE(s0, 0)
-            PT_RUN_SPHERE(s1, 1)
-            PT_RUN_SPHERE(s2, 2)
-            PT_RUN_SPHERE(s3, 3)
-            runs >>= 4;
+        if (runs & (1u << (K)))                                                                                          \
+            asm volatile("v_sub_f32 %0, %4, %6\n v_sub_f32 %1, %5, %7\n v_mul_f32 %2, %8, %0\n v_mul_f32 %3, %0, %0"     \
+                         : "=&v"(ocx), "=&v"(ocz), "=&v"(bx), "=&v"(cx)                                                  \
+                         : "v"(o.x), "v"(o.z), "v"(S.x), "v"(S.z), "v"(d.x)); /* oc.x, oc.z, d.x * oc.x, oc.x * oc.x */  \
+        asm volatile("v_sub_f32 %2, %3, %4\n"       /* oc.y */                                                           \
+                     "v_fma_f32 %0, %5, %2, %6\n"   /* fma(d.y, oc.y, d.x * oc.x) */                                      \
+                     "v_fma_f32 %1, %2, %2, %7\n"   /* fma(oc.y, oc.y, oc.x * oc.x) */                                    \
+                     "v_fma_f32 %0, %8, %9, %0\n"   /* == v_dot(d, oc) */                                                 \
+                     "v_fma_f32 %1, %9, %9, %1"     /* == v_dot(oc, oc) */                                                \
+                     : "=&v"(b[K]), "=&v"(c[K]), "=&v"(ocy)                                                              \
+                     : "v"(o.y), "v"(S.y), "v"(d.y), "v"(bx), "v"(cx), "v"(d.z), "v"(ocz));                              \
+        c[K] = f_fma(-S.w, S.w, c[K]);              /* ... - r * r */                                                    \
+        disc[K] = f_fma(b[K], b[K], -c[K]);
+        const int ns4 = ns & ~3;
+        while (i < ns4) { // (i is a multiple of 32 here)
+            unsigned int runs = ((const __attribute__((address_space(4))) unsigned int *)rca->sphereRunStart)[i >> 5];
+            const int end = ns4 < i + 32 ? ns4 : i + 32;
+            for (; i < end; i += 4) {
+                const float4 s0 = sc.sph[i], s1 = sc.sph[i + 1], s2 = sc.sph[i + 2], s3 = sc.sph[i + 3];
+                float b[4], c[4], disc[4], ocx, ocy;
+                asm volatile("" ::"v"(s0.x), "v"(s0.z), "v"(s1.x), "v"(s1.z), "v"(s2.x), "v"(s2.z), "v"(s3.x), "v"(s3.z)); // (whole float4 reads, all four at once)
+                PT_RUN_SPHERE(s0, 0)
+                PT_RUN_SPHERE(s1, 1)
+                PT_RUN_SPHERE(s2, 2)
+                PT_RUN_SPHERE(s3, 3)
+                runs >>= 4;
+                asm volatile("" : "+v"(disc[0]), "+v"(disc[1]), "+v"(disc[2]), "+v"(disc[3])); // (the four tests below stay below the four blocks above)
 #pragma unroll
-            for (int k = 0; k < 4; k++) candidate(i + k, b[k], c[k], disc[k]); // one wave-level branch per sphere
+                for (int k = 0; k < 4; k++) // `any`: a sphere that no lane's line meets costs one compare and one scalar branch (no exec save / restore)
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(disc[k] < 0.0f)) != 0ull, 0)) candidate(i + k, b[k], c[k], disc[k]);
+            }
         }
 #undef PT_RUN_SPHERE
         for (; i < ns; i++) { // (ns % 4 spheres: evaluated on their own)
@@ -863,7 +868,7 @@ PT_DEV void primary_ray_cam(FP cam, float invW, float invH, int px, int py, uint
 
 PT_DEV void primary_ray(const FrameArgs &a, int px, int py, uint32_t &seed, v3 &ro, v3 &rd)
 {
-    primary_ray_cam<const float *>(a.invProj, f_div_ieee(1.0f, (float)a.width), f_div_ieee(1.0f, (float)a.height), px, py, seed, ro, rd);
+    primary_ray_cam<const float *>(a.invProj, a.invW, a.invH, px, py, seed, ro, rd);
 }
 
 // image row of local row `ly` of this launch (contiguous row block, or block-cyclic bands across GPUs)

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                 ColdArgs ca = cold_args();
                 ColdFloats cam = (ColdFloats)ca;
                 const int width = ca->width;
-                const float invW = f_div_ieee(1.0f, (float)width), invH = f_div_ieee(1.0f, (float)ca->height);
+                const float invW = ca->invW, invH = ca->invH;
                 bool valid = false;
                 int tpix = 0, tpxy = 0, tsample = 0, tfj = 0;
                 uint32_t tseed = 0;
@@ -175,9 +175,9 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                     __builtin_amdgcn_wave_barrier(); // the entries are read before this pass parks new ones in their place
                 } else {
                     const int tilesX = ca->tilesX;
-                    tfj = tile / numTilesFrame;
-                    tile -= tfj * numTilesFrame;
-                    const int tx = tile % tilesX, ty = tile / tilesX;
+                    int tx, ty;
+                    fast_divmod(tile, numTilesFrame, ca->tilesFrameMagic, tfj, tile);
+                    fast_divmod(tile, tilesX, ca->tilesXMagic, ty, tx);
                     const int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
                     valid = x < width && ly < ca->rows;
                     if (valid) {
@@ -321,9 +321,10 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
             needRay = false;
         }
         bool wantPark = false;
-        if (active && !pending) {
-            bool cont = false;
-            if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr, walkFrom PROF_DUMMY);
+        const bool trace = active && !pending; // (one divergent region around the bounce, as in the persistent kernel)
+        bool cont = false;
+        if (trace && bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID, (MATLDS && !GRID)>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr, walkFrom PROF_DUMMY);
+        if (trace) {
             const bool sliced = GRID && walkFrom >= 0.0f; // (the grid walk of this bounce continues in the next iteration: pt_device.hpp, WALK SLICES)
             if (!sliced) bounce++;
             if (!sliced && (!cont || bounce >= a.rayDepth)) {

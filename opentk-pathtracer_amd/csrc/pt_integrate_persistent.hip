@@ -21,6 +21,8 @@
 //
 // Arithmetic: the "pt-f32" contract of pt_math.hpp (bit-identical to oracle/pt_oracle.c).
 // Build flags (see __graft_entry__.build): -O3 -ffp-contract=off -fno-fast-math --offload-arch=gfx950
+#include <cstdio>
+
 #include "pt_kernel_common.hpp"
 #include "pt_tuning.hpp"
 
@@ -194,13 +196,11 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     // sixth workgroup per CU (27.9 instead of 27.2 KB)
     // (the table's address is re-derived from the kernarg segment where it is read — see cold_args — instead of living in a register
     // across the bounce loop)
-    auto frame_weights = [&]() -> float * {
-        ColdArgs ca = cold_args();
-        return (float *)((char *)g_lds + scene_lds_bytes(ca->numSpheres, ca->numCuboids, ca->envFormat, ca->materialsInLds != 0, ca->gridLdsBytes));
-    };
+    auto frame_weights = [&]() -> float2 * { return (float2 *)((char *)g_lds + cold_args()->sceneLdsBytes); };
     if (SPP1) {
-        float *fw = frame_weights();
-        for (int j = (int)threadIdx.x; j < a.batchFrames; j += (int)blockDim.x) fw[j] = f_div_ieee(1.0f, (float)(a.frame + j + 1));
+        float2 *fw = frame_weights();
+        for (int j = (int)threadIdx.x; j < a.batchFrames; j += (int)blockDim.x)
+            fw[j] = make_float2(f_div_ieee(1.0f, (float)(a.frame + j + 1)), (j == a.batchFrames - 1 && !a.keepTags) ? 1.0f : frame_tag(a.frame + j));
     }
     if (threadIdx.x == 0) {
         // One frame per launch: the workgroup's first chunk is static (chunk index = workgroup index).  A pipelined batch
@@ -238,7 +238,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     constexpr int LANE_LAST_BYTES = CARRY ? NWAVES * 3 * 64 * 4 : 0;
     float *laneLast = (float *)(ringBase + NWAVES * 64 * ENTRY_BYTES) + wave * 3 * 64 + lane; // (only touched by CARRY kernels)
     PathState *pool = (PathState *)(ringBase + NWAVES * 64 * ENTRY_BYTES + LANE_LAST_BYTES);
-    const bool compaction = a.drainCompaction != 0;
+    // (CARRY kernels are only launched without drain compaction: the donate / adopt code and its copies of the path state are compiled out)
+    const bool compaction = !CARRY && a.drainCompaction != 0;
     // parked resolves of this wavefront (pipelined spp = 1 launches only; behind the rings — such launches have no drain pool)
     ParkedResolve *parkedList = (ParkedResolve *)(ringBase + NWAVES * 64 * ENTRY_BYTES + LANE_LAST_BYTES) + wave * a.parkedMax;
     const bool parking = SPP1 && a.tagged && !compaction && a.parkedMax > 0;
@@ -276,15 +277,17 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     // compute.glsl:125-129 for frame `rfj` of the batch: irradiance / SPP folded into the running mean, alpha = 1 (or the
     // frame tag inside a batch).  The uniform inputs are re-read from the kernarg segment here (see cold_args).
     auto fold = [&](float4 last, v3 rirr, int rfj) -> float4 {
-        ColdArgs ca = cold_args();
-        float w;
-        if constexpr (SPP1) { // irradiance / 1 is exact (x * 1.0f == x bit for bit): skipped; weight from the per-batch table
-            w = frame_weights()[rfj];
+        float w, alpha;
+        if constexpr (SPP1) { // irradiance / 1 is exact (x * 1.0f == x bit for bit): skipped; weight and alpha from the per-batch table
+            const float2 wa = frame_weights()[rfj];
+            w = wa.x;
+            alpha = wa.y;
         } else {
+            ColdArgs ca = cold_args();
             rirr = v_scale(rirr, f_div_ieee(1.0f, (float)ca->spp));
             w = f_div_ieee(1.0f, (float)(ca->frame + rfj + 1));
+            alpha = (rfj == ca->batchFrames - 1 && !ca->keepTags) ? 1.0f : frame_tag(ca->frame + rfj);
         }
-        const float alpha = (rfj == ca->batchFrames - 1 && !ca->keepTags) ? 1.0f : frame_tag(ca->frame + rfj);
         return make_float4(f_mix(last.x, rirr.x, w), f_mix(last.y, rirr.y, w), f_mix(last.z, rirr.z, w), alpha);
     };
     // CARRY: compute.glsl:126-129 with the pixel's value already in hand (read by the tile pass, which also checked the tag): no load
@@ -294,8 +297,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         AUDIT_RESOLVE(a, (size_t)rpix, a.frame + rfj, last, next, 7);
         if (!a.tagged) a.accum[rpix] = next;
         else store_pixel_sc1(a.accum + rpix, next);
-        if (rfj == cold_args()->batchFrames - 1)
-            if (float4 *snap = cold_args()->snapshot) snap[rpix] = make_float4(next.x, next.y, next.z, 1.0f);
+        if (float4 *snap = cold_args()->snapshot) // (wave-uniform, almost always null: the present snapshot of the launch's last frame)
+            if (rfj == cold_args()->batchFrames - 1) snap[rpix] = make_float4(next.x, next.y, next.z, 1.0f);
     };
     // False = the pixel still holds an older frame (only possible inside a batch): try again in the next iteration.
     auto try_resolve = [&](int rpix, int rfj, v3 rirr, bool force) -> bool {
@@ -317,8 +320,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         const float4 next = fold(last, rirr, rfj);
         AUDIT_RESOLVE(a, (size_t)rpix, a.frame + rfj, last, next, 4);
         store_pixel_sc1(ptr, next);
-        if (rfj == cold_args()->batchFrames - 1) // the launch's last frame: the present snapshot (plain store, read after the launch)
-            if (float4 *snap = cold_args()->snapshot) snap[rpix] = make_float4(next.x, next.y, next.z, 1.0f);
+        if (float4 *snap = cold_args()->snapshot) // the launch's last frame: the present snapshot (plain store, read after the launch)
+            if (rfj == cold_args()->batchFrames - 1) snap[rpix] = make_float4(next.x, next.y, next.z, 1.0f);
         CHAOS(12);
         return true;
     };
@@ -383,10 +386,10 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         ColdArgs ca = cold_args();
                         ColdFloats cam = (ColdFloats)ca;
                         const int width = ca->width, tilesX = ca->tilesX;
-                        const float invW = f_div_ieee(1.0f, (float)width), invH = f_div_ieee(1.0f, (float)ca->height);
-                        const int tfj = tile / numTilesFrame; // frame of the batch this (frame, tile) ticket belongs to
-                        tile -= tfj * numTilesFrame;
-                        int tx = (int)(tile % tilesX), ty = (int)(tile / tilesX);
+                        const float invW = ca->invW, invH = ca->invH;
+                        int tfj, tx, ty; // frame of the batch this (frame, tile) ticket belongs to; tile column, row
+                        fast_divmod(tile, numTilesFrame, ca->tilesFrameMagic, tfj, tile);
+                        fast_divmod(tile, tilesX, ca->tilesXMagic, ty, tx);
                         int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
                         const bool valid = x < width && ly < ca->rows;
                         v3 to = V(0.0f, 0.0f, 0.0f), td = V(0.0f, 0.0f, 1.0f), tthr = V(1.0f, 1.0f, 1.0f), trad = V(0.0f, 0.0f, 0.0f);
@@ -464,10 +467,10 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         ColdArgs ca = cold_args(); // opaque: load the camera here, do not keep it live across the loop
                         ColdFloats cam = (ColdFloats)ca;
                         const int width = ca->width, tilesX = ca->tilesX;
-                        const float invW = f_div_ieee(1.0f, (float)width), invH = f_div_ieee(1.0f, (float)ca->height);
-                        const int tfj = tile / numTilesFrame; // frame of the batch this (frame, tile) ticket belongs to
-                        tile -= tfj * numTilesFrame;
-                        int tx = (int)(tile % tilesX), ty = (int)(tile / tilesX);
+                        const float invW = ca->invW, invH = ca->invH;
+                        int tfj, tx, ty; // frame of the batch this (frame, tile) ticket belongs to; tile column, row
+                        fast_divmod(tile, numTilesFrame, ca->tilesFrameMagic, tfj, tile);
+                        fast_divmod(tile, tilesX, ca->tilesXMagic, ty, tx);
                         int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
                         RingEntry e;
                         e.pix = -1;
@@ -670,34 +673,33 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         prof_util[2] += (unsigned long long)__builtin_popcountll(__ballot(active && pending));
 #endif
         if constexpr (SPP1) {
-            if (active) {
-                if (!pending) {
-                    bool cont = false;
-                    if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID, (MATLDS && !GRID)>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr, walkFrom PROF_PASS);
-                    if (!(GRID && walkFrom >= 0.0f)) { // (else: the grid walk of this bounce continues in the next iteration, pt_device.hpp WALK SLICES)
-                        bounce++;
-                        pending = !cont || bounce >= a.rayDepth;
-                        if (pending) walkFrom = 0.0f; // (= no failed resolve attempt yet)
-                    }
-                }
+            // ONE divergent region around the bounce (not three nested ones: the compiler copies the whole path state — 16 registers — in
+            // front of every level of a nest whose inside modifies it)
+            const bool trace = active && !pending;
+            bool cont = false;
+            if (trace && bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID, (MATLDS && !GRID)>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr, walkFrom PROF_PASS);
+            if (trace && !(GRID && walkFrom >= 0.0f)) { // (else: the grid walk of this bounce continues in the next iteration, pt_device.hpp WALK SLICES)
+                bounce++;
+                pending = !cont || bounce >= a.rayDepth;
+                if (pending) walkFrom = 0.0f; // (= no failed resolve attempt yet)
+            }
 #ifdef PT_PROFILE
-                prof_t = __builtin_readcyclecounter();
+            prof_t = __builtin_readcyclecounter();
 #endif
-                if (CARRY && pending && (fj & 0x4000)) { // the tile pass read the pixel (and saw the previous frame's tag): no load, cannot fail
-                    commit_resolve(pix, fj & 0x3fff, v_add(V(0.0f, 0.0f, 0.0f), rad), V(laneLast[0], laneLast[64], laneLast[128]));
+            if (CARRY && active && pending && (fj & 0x4000)) { // the tile pass read the pixel (and saw the previous frame's tag): no load, cannot fail
+                commit_resolve(pix, fj & 0x3fff, v_add(V(0.0f, 0.0f, 0.0f), rad), V(laneLast[0], laneLast[64], laneLast[128]));
+                pix = -1;
+                pending = false;
+            }
+            if (active && pending) {
+                v3 firr = v_add(V(0.0f, 0.0f, 0.0f), rad);
+                const bool force = retries() > FRAME_RETRY_LIMIT;
+                if (try_resolve(pix, fj, firr, force)) {
+                    if (force) atomicOr(cold_args()->errorWord, 1u); // host-visible error word
                     pix = -1;
                     pending = false;
-                }
-                if (pending) {
-                    v3 firr = v_add(V(0.0f, 0.0f, 0.0f), rad);
-                    const bool force = retries() > FRAME_RETRY_LIMIT;
-                    if (try_resolve(pix, fj, firr, force)) {
-                        if (force) atomicOr(cold_args()->errorWord, 1u); // host-visible error word
-                        pix = -1;
-                        pending = false;
-                    } else {
-                        walkFrom = __int_as_float(retries() + 1);
-                    }
+                } else {
+                    walkFrom = __int_as_float(retries() + 1);
                 }
             }
             if (parking) {
@@ -775,7 +777,7 @@ __global__ __launch_bounds__(256) void pt_tile_masks_kernel(const FrameArgs a, u
     const int gy0 = global_row(a, ty * 8); // (band heights are multiples of 8: a tile's eight rows are consecutive image rows)
     v3 O, A, dirs[4];
     float rho, ct, lensSin;
-    tile_cone<const float *>(a.invProj, f_div_ieee(1.0f, (float)a.width), f_div_ieee(1.0f, (float)a.height), tx * 8, gy0, O, A, rho, ct, dirs, lensSin);
+    tile_cone<const float *>(a.invProj, a.invW, a.invH, tx * 8, gy0, O, A, rho, ct, dirs, lensSin);
     unsigned long long masks[5];
     cone_sphere_masks(sc, a.numSpheres, O, A, rho, ct, masks);
     masks[4] = cone_cuboid_mask(sc, a.numCuboids, O, rho, ct, dirs, lensSin);
@@ -822,6 +824,8 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
     a.gridLdsBytes = 0;
     *ticketsConsumed = 0;
     int tiles = a.tilesX * a.tilesY;
+    a.tilesFrameMagic = div_magic((unsigned int)tiles);
+    a.tilesXMagic = div_magic((unsigned int)a.tilesX);
     size_t lds = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, true);
     if (a.variant == 1) {
         int nwg = (tiles + 3) / 4;
@@ -888,7 +892,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         // CARRY (the pixel travels with its path, see PathEntryCarry): full-size images of scenes whose materials stay in LDS — the 12 more
         // bytes per ring entry and the 3 KB of lane slots are what the parked resolves take elsewhere, and only a GPU that owns few
         // tiles per frame needs those (+0.3 % at full 1080p); with the sphere grid, or on a small share, the plain kernel stays
-        bool carry = spp1 && !useGrid && !perWaveTimeline && tiles >= 12000 && tune.carryLast != 0;
+        bool carry = spp1 && !useGrid && !perWaveTimeline && tiles >= 12000 && tune.carryLast != 0 && a.drainCompaction == 0;
         auto queue_bytes = [&](bool c) -> size_t {
             if (useBatchPass) return (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry));
             return (spp1 ? frame_weight_bytes(a.batchFrames) : 0) +
@@ -900,22 +904,41 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         const size_t ldsPerCU = 160 * 1024, fixedLds = 64; // (static LDS of the persistent kernels: queue, drain control)
         const bool forceLean = tune.forceLeanLds != 0; // A/B runs: materials always from the UBO copy
         size_t queues = 0, ldsTotal = 0;
+        a.parkedMax = carry ? 0 : parkedMaxPlain;
         for (;;) {
-            a.parkedMax = carry ? 0 : parkedMaxPlain;
             queues = queue_bytes(carry);
             ldsTotal = lds + queues;
             const size_t ldsLean = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, false, a.gridLdsBytes) + queues;
-            size_t wgFull = ldsPerCU / (ldsTotal + fixedLds), wgLean = ldsPerCU / (ldsLean + fixedLds);
+            // The hardware hands out LDS in granules of 1,280 bytes (160 KB / 128) — measured on the 256-sphere scene: 26,880 bytes per
+            // workgroup (21 granules) run six workgroups per CU, 27,136 run five, although 6 x 27,136 < 160 KB and
+            // hipOccupancyMaxActiveBlocksPerMultiprocessor answers 6 for both.
+            auto fit = [&](size_t bytes) { return ldsPerCU / ((bytes + fixedLds + 1279) / 1280 * 1280); };
+            size_t wgFull = fit(ldsTotal), wgLean = fit(ldsLean);
             if (wgFull > (size_t)blocksPerCU) wgFull = (size_t)blocksPerCU;
             if (wgLean > (size_t)blocksPerCU) wgLean = (size_t)blocksPerCU;
             const bool lean = wgLean > wgFull || forceLean || useGrid; // (the grid kernel is only instantiated for materials in device memory)
             if (carry && (lean || wgFull < (size_t)blocksPerCU)) { // (the carrying kernel exists with materials in LDS only, and must not cost a workgroup)
                 carry = false;
+                a.parkedMax = parkedMaxPlain;
+                continue;
+            }
+            // the parked-resolve lists give way before a resident workgroup does (a list of 16 is plenty on a full-size image; the 256-sphere
+            // scene with its grid sits 100 bytes over six workgroups per CU with lists of 64)
+            if (!carry && spp1 && a.tagged && a.drainCompaction == 0 && tune.parkedMax < 0 && a.parkedMax > 16 &&
+                (wgFull > wgLean ? wgFull : wgLean) < (size_t)blocksPerCU) {
+                a.parkedMax -= 8;
                 continue;
             }
             a.materialsInLds = lean ? 0 : 1;
             if (lean) ldsTotal = ldsLean;
             break;
+        }
+        a.sceneLdsBytes = (int)scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, a.materialsInLds != 0, a.gridLdsBytes);
+        if (tuning().logLaunch > 0) {
+            tuning().logLaunch--;
+            std::fprintf(stderr, "mi355pt launch: spp1 %d grid %d carry %d matLds %d batchPass %d frames %d tiles %d wg/CU %d | LDS scene %d + queues %zu = %zu (+%zu static) -> %zu per CU fit, parkedMax %d\n",
+                         (int)spp1, (int)useGrid, (int)carry, a.materialsInLds, (int)useBatchPass, a.batchFrames, tiles, blocksPerCU, a.sceneLdsBytes, queues, ldsTotal, fixedLds,
+                         ldsPerCU / ((ldsTotal + fixedLds + 1279) / 1280 * 1280), a.parkedMax);
         }
 #ifndef PT_GRID_MIN_WAVES
 #define PT_GRID_MIN_WAVES 6

@@ -150,8 +150,10 @@ struct ParkedResolve {
     float irr[3];
 };
 constexpr int PARKED_MAX = 64; // upper bound; FrameArgs::parkedMax is what a launch uses
-// LDS bytes of the per-launch table of running-mean weights (spp = 1 persistent kernels), 16-byte aligned
-__host__ __device__ constexpr size_t frame_weight_bytes(int batchFrames) { return (size_t)((batchFrames + 63) & ~63) * 4; }
+// LDS bytes of the per-launch frame table (spp = 1 persistent kernels), 16-byte aligned: per frame of the batch its running-mean weight
+// 1 / (frame + 1) and the alpha it stores (its tag, or the reference's 1 for the launch's last frame) — everything a resolve needs to
+// know about its frame in one 8-byte LDS read, no scalar arithmetic
+__host__ __device__ constexpr size_t frame_weight_bytes(int batchFrames) { return (size_t)((batchFrames + 63) & ~63) * 8; }
 
 struct BlockQueue {            // one per workgroup, in static LDS
     unsigned long long pair;   // (end << 32) | cursor : absolute tile indices of the current chunk
@@ -164,6 +166,18 @@ struct BlockQueue {            // one per workgroup, in static LDS
 PT_DEV unsigned int lds_load(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PT_DEV unsigned long long lds_load64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PT_DEV void lds_store(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// n / d and n % d for wave-uniform n < 2^31 with the host's magic = floor(2^32 / d) (d = 1: 2^32 - 1): the estimate mul_hi(n, magic) is the
+// quotient or one less, so ONE correction step makes it exact — 6 scalar instructions where the compiler's division expands to 25.
+__host__ __device__ inline unsigned int div_magic(unsigned int d) { return d <= 1u ? 0xffffffffu : (unsigned int)(0x100000000ull / d); }
+PT_DEV void fast_divmod(int n, int d, unsigned int magic, int &q, int &r)
+{
+    unsigned int qq = __umulhi((unsigned int)n, magic);
+    unsigned int rr = (unsigned int)n - qq * (unsigned int)d;
+    if (rr >= (unsigned int)d) { qq++; rr -= (unsigned int)d; }
+    q = (int)qq;
+    r = (int)rr;
+}
 
 // Next tile for this wavefront, or -1 when the frame's tiles are all handed out.  Wave-uniform result.
 PT_DEV int queue_pop_tile(BlockQueue *q)

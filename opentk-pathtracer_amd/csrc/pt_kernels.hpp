@@ -60,6 +60,10 @@ struct FrameArgs {
     const unsigned char *grid;
     int gridBytes;          // size of the packed grid
     int gridLdsBytes;       // set by the launch: LDS bytes the staged grid takes (0 = this launch does not traverse it)
+    unsigned int tilesFrameMagic, tilesXMagic; // floor(2^32 / (tilesX * tilesY)), floor(2^32 / tilesX): split_ticket (pt_kernel_common.hpp)
+    float invW, invH;       // 1 / width, 1 / height: IEEE quotients, computed once on the host (what the tile pass used to divide out per tile)
+    int sceneLdsBytes;      // set by the launch: scene_lds_bytes(...) of this launch = where the frame table starts (one scalar load where a
+                            // pixel is resolved, instead of re-deriving it from five other fields)
     int gridDims[3];        // cells per axis (their product is the cell count)
     float gridLo[3], gridHi[3], gridCell[3], gridInvCell[3]; // box, cell size and its reciprocal per axis
     float gridCenter[3];    // a ray uses the grid when its origin lies within sqrt(gridReach2) of the box centre (see ray_trace_t)

@@ -131,6 +131,10 @@ if pmc.get("SQ_INSTS_VALU"):
     vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
     v = json.load(open(vpath)) if os.path.exists(vpath) else {}
     v[key] = {"value": round(pmc["SQ_INSTS_VALU"]), "csrc_hash": CSRC_HASH}
+    # the other instruction classes that take issue slots of the same wavefronts (round 4: a scalar instruction costs about what a vector one does)
+    other = {k.lower()[len("sq_insts_"):]: round(pmc[k]) for k in ("SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_SMEM") if pmc.get(k)}
+    if other:
+        v[key]["other"] = other
     json.dump(v, open(vpath, "w"), indent=1, sort_keys=True)
 json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "pmc_per_frame"}, indent=1))
