@@ -184,9 +184,12 @@ struct DrainControl {        // static LDS, one per workgroup
 // that handful; material / BSDF / environment code runs on coherent lanes too.  Paths that end at the first bounce are
 // resolved immediately, the survivors go to the ring as PathEntry records and are picked up by idle lanes of the
 // generic bounce loop.  Per path the arithmetic is unchanged (same tests in the same order, same RNG draws).
-template <int NWAVES, int MIN_WAVES_PER_SIMD, bool TIMELINE, bool SPP1, bool MATLDS, bool GRID = false, bool CARRY = false>
+// COMPACT = false: the donate / adopt code of the drain compaction is compiled out (pipelined launches never use it, and while it sits in
+// the main loop the compiler keeps a second copy of the path state around it: "feed" was 20 % of the 256-sphere scene's wavefront time).
+template <int NWAVES, int MIN_WAVES_PER_SIMD, bool TIMELINE, bool SPP1, bool MATLDS, bool GRID = false, bool CARRY = false, bool COMPACT = true>
 __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_persistent_kernel(const FrameArgs a)
 {
+    static_assert(!(CARRY && COMPACT), "the carrying kernels are only launched without drain compaction");
     __shared__ __attribute__((aligned(16))) BlockQueue queue; // 16 B: keeps the dynamic-LDS base 16-byte aligned
     __shared__ __attribute__((aligned(16))) DrainControl drain; // 32 B
     const int numTilesFrame = a.tilesX * a.tilesY;
@@ -238,8 +241,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     constexpr int LANE_LAST_BYTES = CARRY ? NWAVES * 3 * 64 * 4 : 0;
     float *laneLast = (float *)(ringBase + NWAVES * 64 * ENTRY_BYTES) + wave * 3 * 64 + lane; // (only touched by CARRY kernels)
     PathState *pool = (PathState *)(ringBase + NWAVES * 64 * ENTRY_BYTES + LANE_LAST_BYTES);
-    // (CARRY kernels are only launched without drain compaction: the donate / adopt code and its copies of the path state are compiled out)
-    const bool compaction = !CARRY && a.drainCompaction != 0;
+    const bool compaction = COMPACT && a.drainCompaction != 0;
     // parked resolves of this wavefront (pipelined spp = 1 launches only; behind the rings — such launches have no drain pool)
     ParkedResolve *parkedList = (ParkedResolve *)(ringBase + NWAVES * 64 * ENTRY_BYTES + LANE_LAST_BYTES) + wave * a.parkedMax;
     const bool parking = SPP1 && a.tagged && !compaction && a.parkedMax > 0;
@@ -721,10 +723,11 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             bounce = 0;
             needRay = false;
         }
-        if (active) {
-            if (!pending) {
-                bool cont = false;
-                if (bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr, walkFrom PROF_PASS);
+        {
+            const bool trace = active && !pending; // (one divergent region around the bounce, as above)
+            bool cont = false;
+            if (trace && bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr, walkFrom PROF_PASS);
+            if (trace) {
                 const bool sliced = GRID && walkFrom >= 0.0f; // (the grid walk of this bounce continues in the next iteration)
                 if (!sliced) bounce++;
                 if (!sliced && (!cont || bounce >= a.rayDepth)) {
@@ -737,7 +740,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
 #ifdef PT_PROFILE
             prof_t = __builtin_readcyclecounter();
 #endif
-            if (pending) {
+            if (active && pending) {
                 const bool force = retries() > FRAME_RETRY_LIMIT;
                 if (try_resolve(pix, fj, irr, force)) {
                     if (force) atomicOr(cold_args()->errorWord, 1u);
@@ -888,6 +891,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
 #endif
         const bool useGrid = a.grid != nullptr && a.gridBytes > 0 && !noGrid && !perWaveTimeline;
         a.gridLdsBytes = useGrid ? (a.gridBytes + 15) & ~15 : 0;
+        if (useGrid && spp1) a.drainCompaction = 0; // (the tile-pass grid kernel exists without drain compaction only)
         lds += (size_t)a.gridLdsBytes;
         // CARRY (the pixel travels with its path, see PathEntryCarry): full-size images of scenes whose materials stay in LDS — the 12 more
         // bytes per ring entry and the 3 KB of lane slots are what the parked resolves take elsewhere, and only a GPU that owns few
@@ -950,9 +954,10 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
     hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, (S1 ? PT_SPP1_WAVES : 5), TL, S1, ML>), dim3(nwg), dim3(256), ldsTotal, stream, a)
         const bool matLds = a.materialsInLds != 0;
         if (perWaveTimeline && spp1 && matLds) PT_LAUNCH_PERSISTENT(true, true, true); // per-wavefront timestamps (tools/timeline.py)
-        else if (spp1 && matLds && carry) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_SPP1_WAVES, false, true, true, false, true>), dim3(nwg), dim3(256), ldsTotal, stream, a);
+        else if (spp1 && matLds && carry) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_SPP1_WAVES, false, true, true, false, true, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
+        else if (spp1 && matLds && a.drainCompaction == 0) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_SPP1_WAVES, false, true, true, false, false, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1 && matLds) PT_LAUNCH_PERSISTENT(false, true, true);
-        else if (spp1 && useGrid) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_GRID_MIN_WAVES, false, true, false, true>), dim3(nwg), dim3(256), ldsTotal, stream, a);
+        else if (spp1 && useGrid) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_GRID_MIN_WAVES, false, true, false, true, false, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1) PT_LAUNCH_PERSISTENT(false, true, false);
         else if (useBatchPass) (void)launch_multisample(a, nwg, ldsTotal, stream, matLds, useGrid);
         else if (matLds) PT_LAUNCH_PERSISTENT(false, false, true);

@@ -9,6 +9,10 @@ pkg = g.load_package()
 out = {"csrc_hash": pkg.native.csrc_hash(), "band_rows": 16, "results": {}}
 sc, cam = pkg.scene.default_scene(), pkg.camera.Camera()
 only = os.environ.get("EMULATE_ONLY")  # e.g. "1920x1080:8" (tuning runs)
+for kv in filter(None, os.environ.get("EMULATE_TUNE", "").split(",")):  # e.g. "parked_max=16,batch_wg=5" (tuning runs)
+    k, v = kv.split("=")
+    pkg.native.debug_set(k, int(v))
+    out.setdefault("tuning", {})[k] = int(v)
 for (W, H) in ((1920, 1080), (3840, 2160)):
     for world in (1, 2, 4, 8):
         if only and only != f"{W}x{H}:{world}":

@@ -2,7 +2,7 @@
 -DPT_PROFILE build of the tree (tools/ab/build_ab.sh P -DPT_PROFILE): every kernel builds with it, and the library keeps batching /
 chaining while the counter buffer exists (csrc/pt_renderer.hpp, PT_TIMELINE_BLOCKS).
     MI355PT_LIB=tools/ab/libP.so python tools/profile_sections.py [default|stress|glass] [variant frames]
-default: variant 0, 640 frames.  Variant 14 = one un-pipelined frame per launch."""
+default: variant 0, 640 frames.  Variant 14 = one un-pipelined frame per launch.  PROFILE_SHARE=rank,world profiles one rank's share."""
 import os, sys, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,6 +16,10 @@ cam = pkg.camera.Camera()
 pt = pkg.PathTracer(pkg.envmap.synthetic_sky_rgba32f(64), W, H, 8 if scene_name != "glass" else 32, 1, 20.0, 0.14)
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 pt.SetVariant(variant); pt.UploadScene(sc); pt.UploadBasicData(pkg.camera.basic_data_ubo(cam, W, H))
+if os.environ.get("PROFILE_SHARE"):  # "rank,world": one rank's block-cyclic share of the image (16-row bands), as bench.py --gpus N renders it
+    rank, world = map(int, os.environ["PROFILE_SHARE"].split(","))
+    pt.SetInterleavedTile(rank, world, 16)
+    print(f"share: rank {rank} of {world}")
 for _ in range(5 if variant else 128): pt.Render()
 pt.Synchronize()
 lib.pt_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
