@@ -25,7 +25,11 @@ for (W, H) in ((1920, 1080), (3840, 2160)):
             if world > 1:
                 pt.SetInterleavedTile(rank, world, 16)
             t = time.perf_counter()
-            while time.perf_counter() - t < 0.08:
+            fixed = int(os.environ.get("EMULATE_FIXED_WARMUP", "0"))  # counter runs: a known number of frames (n rounds of 64) instead of 80 ms
+            for _ in range(fixed):
+                for _ in range(64): pt.Render()
+                pt.Synchronize()
+            while not fixed and time.perf_counter() - t < 0.08:
                 for _ in range(64): pt.Render()
                 pt.Synchronize()
             steps = 640
