@@ -423,7 +423,10 @@ PT_API int pt_set_params(pt_handle h, int num_spheres, int num_cuboids, int ray_
     if (ray_depth > PT_MAX_RAY_DEPTH || spp > PT_MAX_SPP)
         return fail(h, PT_E_OUT_OF_RANGE, "ray_depth / spp exceed PT_MAX_RAY_DEPTH / PT_MAX_SPP (4095)");
     if (num_spheres != h->numSpheres) h->gridDirty = true;
-    if (num_spheres != h->numSpheres || focal_length != h->focalLength || aperture_diameter != h->apertureDiameter) { h->tileMasksValid = false; h->launchesSinceInputChange = 0; }
+    if (num_spheres != h->numSpheres || num_cuboids != h->numCuboids || focal_length != h->focalLength || aperture_diameter != h->apertureDiameter) {
+        h->tileMasksValid = false; // (the cached masks cull spheres AND cuboids against the lens' cone)
+        h->launchesSinceInputChange = 0;
+    }
     h->numSpheres = num_spheres;
     h->numCuboids = num_cuboids;
     h->rayDepth = ray_depth;
@@ -460,7 +463,8 @@ PT_API int pt_upload_game_objects(pt_handle h, int byte_offset, int size, const 
     PT_HIP(h, hipMemcpyAsync((char *)h->dObjects + byte_offset, src, (size_t)size, hipMemcpyHostToDevice, h->stream));
     std::memcpy(h->objectsShadow + byte_offset, src, (size_t)size);
     if (byte_offset < PT_MAX_SPHERES * 80) h->gridDirty = true; // (the Spheres[] array ends at byte 20,480)
-    if (byte_offset < PT_MAX_SPHERES * 80) { h->tileMasksValid = false; h->launchesSinceInputChange = 0; }
+    h->tileMasksValid = false; // (any object: the cached per-tile masks hold a sphere mask and a cuboid mask)
+    h->launchesSinceInputChange = 0;
     return PT_OK;
 }
 

@@ -175,6 +175,63 @@ def test_cached_tile_masks_are_conservative(pkg, native_lib, oracle, scene, size
         pt.Dispose()
 
 
+def test_cached_tile_masks_follow_cuboid_edits(pkg, native_lib, oracle):
+    """The cached masks hold a CUBOID mask too: a cuboid that is moved, resized or added through partial uploads of the GameObjectsUBO
+    (Cuboid.cs:21 buffer offsets, all beyond the Spheres[] array) must drop them.  (Found by review at the end of round 4: only uploads
+    that touched the sphere array did; a cuboid moved into a tile's view stayed culled there.)"""
+    import copy
+    w = configs.Workload("masks_cuboid_edit", "default", 128, 72, 6, "sky_f32_32")
+    sc, basic, objs, env, kw = configs.inputs(w)
+    pt = pkg.PathTracer(env, w.width, w.height, w.ray_depth, 1, w.focal_length, w.aperture)
+    pt.UploadScene(sc)
+    pt.UploadBasicData(basic)
+    for _ in range(5):
+        for _ in range(3):
+            pt.Render()
+        pt.Synchronize()
+    before = oracle.render(w.width, w.height, basic, objs, env, num_frames=15, **kw)
+    assert_bit_exact(pt.Result, before, "before the edit (cached masks)")
+    # 1: the last cuboid becomes a slab right in front of the camera (one SubData at its own offset, like the reference's editor)
+    cam = pkg.camera.Camera(position=w.position, look_x=w.look[0], look_y=w.look[1])
+    sc2 = copy.deepcopy(sc)
+    c = sc2.cuboids[-1]
+    c.position = (np.asarray(w.position, dtype=np.float32) + np.asarray(cam.view_dir if hasattr(cam, "view_dir") else (0.0, 0.0, -1.0), dtype=np.float32) * np.float32(6.0)).astype(np.float32)
+    c.dimensions = np.asarray((3.0, 2.0, 0.5), dtype=np.float32)
+    d = c.gpu_data()
+    pt.GameObjectsUBO.SubData(c.buffer_offset, d.nbytes, d)
+    pt.ResetRenderer()
+    for _ in range(4):
+        for _ in range(3):
+            pt.Render()
+        pt.Synchronize()
+    after = oracle.render(w.width, w.height, basic, sc2.ubo_bytes(), env, num_frames=12, **kw)
+    assert np.mean(np.abs(after[..., :3] - oracle.render(w.width, w.height, basic, objs, env, num_frames=12, **kw)[..., :3]) > 1e-3) > 0.01, "the edit must be visible"
+    assert_bit_exact(pt.Result, after, "after moving a cuboid (partial upload beyond the sphere array)")
+    # 2: one more cuboid (count change only; its bytes were uploaded before the count was raised)
+    sc3 = copy.deepcopy(sc2)
+    extra = copy.deepcopy(sc2.cuboids[-1])
+    extra.instance = len(sc3.cuboids)
+    extra.position = (np.asarray(c.position, dtype=np.float32) + np.asarray((-4.0, 1.5, 0.0), dtype=np.float32)).astype(np.float32)
+    extra.dimensions = np.asarray((1.5, 1.5, 1.5), dtype=np.float32)
+    sc3.cuboids.append(extra)
+    d = extra.gpu_data()
+    pt.GameObjectsUBO.SubData(extra.buffer_offset, d.nbytes, d)
+    for _ in range(3):  # (masks cached again for the old count)
+        for _ in range(3):
+            pt.Render()
+        pt.Synchronize()
+    pt._numCuboids = sc3.num_cuboids
+    pt._push_params()
+    pt.ResetRenderer()
+    for _ in range(4):
+        for _ in range(3):
+            pt.Render()
+        pt.Synchronize()
+    kw3 = dict(kw, num_cuboids=sc3.num_cuboids)
+    assert_bit_exact(pt.Result, oracle.render(w.width, w.height, basic, sc3.ubo_bytes(), env, num_frames=12, **kw3), "after adding a cuboid")
+    pt.Dispose()
+
+
 def test_cached_tile_masks_in_the_multisample_kernel(pkg, native_lib, oracle):
     """The spp > 1 batch-pass kernel takes the cached masks for its fresh-tile passes (sample 0); continuations keep the per-bundle
     culling.  Small images only reach that kernel with the tuning knob batch_pass_min_tiles = 0."""
