@@ -34,7 +34,7 @@ if [ "$MODE" = collect ]; then
   for w in "${MAIN[@]}" "${EXTRA[@]}"; do IFS='|' read tag key args <<< "$w"
     python tools/summarize_profile.py ${RND}_$tag $RND $key ${RND}_default > /dev/null && [ -f gpurun_out/$RND/${RND}_${tag}_bench.json ] && cp gpurun_out/$RND/${RND}_${tag}_bench.json profiles/$RND/
   done
-  for f in pytest_gpu.log smoke.log bench_configs.jsonl driver_command_bench.json emulate_strong.json present_rate.json present_rate_group2.json \
+  for f in ${RND}_default_stats_unchained_timed.json pytest_gpu.log smoke.log bench_configs.jsonl driver_command_bench.json emulate_strong.json present_rate.json present_rate_group2.json \
            bench_2ranks_one_gpu.json bench_8ranks_one_gpu.json short_runs.log handover_stress.log fuzz.log profile_sections.log \
            ${RND}_default_kernel_stats_unchained.csv ${RND}_default_stats_unchained.json; do
     [ -f gpurun_out/$RND/$f ] && cp gpurun_out/$RND/$f profiles/$RND/$f
@@ -90,6 +90,7 @@ python tools/present_rate.py --devices 0,0 --json gpurun_out/$RND/present_rate_g
 python bench.py --gpus 2 --share-gpu --steps 256 --warmup 128 > gpurun_out/$RND/bench_2ranks_one_gpu.json 2> gpurun_out/$RND/bench_2ranks_one_gpu.err
 python bench.py --gpus 8 --share-gpu --steps 64 --warmup 64 --steady-ms 0 > gpurun_out/$RND/bench_8ranks_one_gpu.json 2> gpurun_out/$RND/bench_8ranks_one_gpu.err
 bash tools/short_runs.sh > gpurun_out/$RND/short_runs.log 2>&1
+bash tools/unchained_timed.sh $RND > gpurun_out/$RND/unchained_timed.log 2>&1
 if [ -x tools/ab/libP.so ]; then for sc in default stress glass; do MI355PT_LIB=$R/tools/ab/libP.so timeout 200 python tools/profile_sections.py $sc 0 640 2>&1 | grep -v amdgpu; done > gpurun_out/$RND/profile_sections.log; fi
 N=12000; NM=5000; F1=600; F2=400; F4=1000; if [ "$QUICK" = --quick ]; then N=3000; NM=2000; F1=200; F2=150; F4=400; fi
 { for L in "" _audit _chaos _audit_chaos; do echo "== libmi355pt$L.so"; timeout 900 tools/handover_stress.bin opentk-pathtracer_amd/libmi355pt$L.so $N $((700 + ${#L})) | grep -v "^\.\.\."; done
