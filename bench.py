@@ -292,7 +292,7 @@ def main():
     if args.share_gpu and not any(kv.startswith("chain_wait_us=") for kv in args.tune):
         # Debug mode, several PROCESSES oversubscribing one GPU: a launch never runs beside its predecessor.  With two launches of one
         # process on two hardware queues while another process's persistent kernels hold the machine, the chained launch's bounded wait
-        # for its pixels' previous frames expired in 1 of 12 runs (error -5, never a wrong image; round 4, CHANGELOG.md).  One process
+        # for its pixels' previous frames expired in about 1 of 15 runs (error -5, never a wrong image; round 4, CHANGELOG.md).  One process
         # per GPU - the mode this bench exists for - never saw it.
         args.tune = list(args.tune) + ["chain_wait_us=0"]
     for kv in args.tune:
