@@ -248,8 +248,9 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--env", default=None, choices=["atmosphere256", "sky2048", "sky64"])
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--frame-batch", type=int, default=64,
-                    help="frames one launch may pipeline (pt_set_frame_batch; 1 = one launch per Render())")
+    ap.add_argument("--frame-batch", type=int, default=0,
+                    help="frames one launch may pipeline (pt_set_frame_batch; 1 = one launch per Render(); 0 = the library's automatic "
+                         "choice: 64, or 256 on a share of fewer than 12,000 tiles)")
     ap.add_argument("--clock-warmup-ms", type=float, default=80.0,
                     help="wall time of untimed rendering before the W warm-up steps (GPU clock ramp); 0 = none")
     ap.add_argument("--strong-4k", action="store_true",
@@ -289,12 +290,6 @@ def main():
                 time.sleep(1.0)
             time.sleep(2.0)
     from opentk_pathtracer_amd import distributed as D
-    if args.share_gpu and not any(kv.startswith("chain_wait_us=") for kv in args.tune):
-        # Debug mode, several PROCESSES oversubscribing one GPU: a launch never runs beside its predecessor.  With two launches of one
-        # process on two hardware queues while another process's persistent kernels hold the machine, the chained launch's bounded wait
-        # for its pixels' previous frames expired in about 1 of 15 runs (error -5, never a wrong image; round 4, CHANGELOG.md).  One process
-        # per GPU - the mode this bench exists for - never saw it.
-        args.tune = list(args.tune) + ["chain_wait_us=0"]
     for kv in args.tune:
         key, _, val = kv.partition("=")
         pkg.native.debug_set(key, int(val))
@@ -320,7 +315,7 @@ def main():
         scene = pkg.scene.stress_scene(int(os.environ["BENCH_STRESS_SPHERES"]))
     cam = pkg.camera.Camera()
     csrc_hash = pkg.native.csrc_hash()
-    frames_per_launch = args.frame_batch if args.variant == 0 else 1
+    frames_per_launch = (args.frame_batch or 64) if args.variant == 0 else 1
 
     def group_handle_check(W, H, basic, warmup, steps, full):
         """The same W + K frames through ONE in-process pt_create_multi handle over all devices (peer copies over xGMI), compared bit for
@@ -554,7 +549,7 @@ def main():
         kernel_ms = m["kernel_s"] * 1e3 / args.steps
         algo_bytes = ALGO_BYTES_PER_PIXEL_FRAME * W * rows  # per frame on one GPU (rank 0's rows)
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        wl_key = f"{scene_name}_{W}x{H}_d{depth}_spp{args.spp}_{env_name}_g{world}" + (f"_variant{args.variant}" if args.variant else "") + (f"_fb{args.frame_batch}" if args.frame_batch != 64 else "") + ("_strong4k" if args.strong_4k else "") + ("_weak" if args.weak and world > 1 else "") + ("_nogrid" if "no_sphere_grid=1" in args.tune else "") + ("_nocarry" if "carry_last=0" in args.tune else "")
+        wl_key = f"{scene_name}_{W}x{H}_d{depth}_spp{args.spp}_{env_name}_g{world}" + (f"_variant{args.variant}" if args.variant else "") + (f"_fb{args.frame_batch}" if args.frame_batch not in (0, 64) else "") + ("_strong4k" if args.strong_4k else "") + ("_weak" if args.weak and world > 1 else "") + ("_nogrid" if "no_sphere_grid=1" in args.tune else "") + ("_nocarry" if "carry_last=0" in args.tune else "")
         if world == 1:
             where = "one GPU" + (f" (BASELINE configs[{baseline_index}])" if baseline_index is not None and (W, H) == (1920, 1080) else "")
         else:

@@ -148,10 +148,11 @@ PT_API int pt_set_environment(pt_handle h, int face_size, int format, const void
  * pt_render until the launch before last has left the machine (bounded; like a full command queue).  A single frame is launched
  * that way too whenever the GPU still runs the previous one. */
 PT_API int pt_render(pt_handle h, int *out_total_samples);
-/* Largest number of frames one launch may pipeline (1..64).  1 = every pt_render launches at once (lowest latency for a host that
- * never calls anything else between frames, e.g. one that presents through interop).  A handle on which this was never called
- * pipelines up to 64 frames per launch — and up to 256 when it owns fewer than 12,000 tiles (a 1/8 share of a 1080p image: the
- * fixed cost of a launch is 7 % of a 64-frame launch there); a limit set here is kept exactly as given. */
+/* Largest number of frames one launch may pipeline (1..64; 0 = back to automatic).  1 = every pt_render launches at once (lowest
+ * latency for a host that never calls anything else between frames, e.g. one that presents through interop).  A handle on which this
+ * was never called (or was last called with 0) pipelines up to 64 frames per launch — and up to 256 when it owns fewer than 12,000
+ * tiles (a 1/8 share of a 1080p image: the fixed cost of a launch is 7 % of a 64-frame launch there); a limit set here is kept
+ * exactly as given. */
 PT_API int pt_set_frame_batch(pt_handle h, int max_frames);
 
 /* What ScreenEffect.Render reads (src/MainWindow.cs:51): blocks until the stream is idle and copies this

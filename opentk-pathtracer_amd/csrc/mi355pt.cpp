@@ -64,7 +64,35 @@ void make_srgb_lut(float *lut)
 namespace ptimpl {
 // Launch what pt_render deferred, then make the main stream wait for every stripe kernel still in flight (before
 // anything that reads their output or overwrites their inputs).
-int join_stripes(pt_handle h)
+hipEvent_t next_launch_event(pt_handle h)
+{
+    hipEvent_t &e = h->launchEvents[h->launchEventNext++ % pt_renderer::kLaunchEvents];
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    return e;
+}
+
+// Hand-over repair: the launches since the last join, in launch order, behind the joined streams (call with the helper streams joined
+// into h->stream).  On the device each pass is a single load unless a launch was abandoned (pt_repair_kernel).
+static int enqueue_repairs(pt_handle h)
+{
+    if (h->unverified.empty()) return PT_OK;
+    for (const pt_renderer::LaunchRecord &r : h->unverified) PT_HIP(h, pt::launch_repair(r.a, h->dRepairCtl, h->stream));
+    PT_HIP(h, pt::launch_repair_done(h->dAbandon, h->dQueue, h->stripeQueueBase[0], h->dQueue + kChainQueueWord, h->chainQueueBase,
+                                     h->dRepairCtl, h->stream));
+    h->unverified.clear();
+    return PT_OK;
+}
+
+// The host found the abandon flag raised: from here on the device is treated as contended (launches of this handle no longer overlap for a
+// while), and present slots tone-mapped from a snapshot since the last epoch are tone-mapped again when they are waited for.
+static void note_abandonment(pt_handle h)
+{
+    *(volatile unsigned int *)h->hostErrWord = 0;
+    h->abandonEpoch++;
+    h->overlapHoldoff = 256;
+}
+
+int join_stripes(pt_handle h, bool repairNow)
 {
     if (h->pendingFrames > 0) {
         // whatever follows a join is ordered by the streams again, so this launch need not leave its tags in the image: its
@@ -87,26 +115,37 @@ int join_stripes(pt_handle h)
             h->stripePending[j] = false;
         }
     }
+    // hand-over repair of the launches since the last join (everything they wrote is behind h->stream now).  A caller that synchronises
+    // h->stream next and then calls settle_handover() leaves it to that — unless the image still carries tags: the alpha pass that
+    // follows such a join would wipe out what the repair reads.
+    if (!h->unverified.empty() && (repairNow || h->tagsLive)) {
+        if (h->hostErrWord && *(volatile unsigned int *)h->hostErrWord) note_abandonment(h);
+        if (int rc = enqueue_repairs(h)) return rc;
+    }
     return PT_OK;
 }
 
-// Frame pipelining: did any resolve give up waiting for its pixel's previous frame?  Call with h->stream synchronised.
-int check_handover(pt_handle h)
+// h->stream has been synchronised behind join_stripes(h, false): every launch of the handle is complete.  Usually that is all there is
+// to know (flag down: forget the launches); an abandoned launch is repaired here, behind one more synchronisation.
+int settle_handover(pt_handle h)
 {
-    if (!h->batchLaunched) return PT_OK;
-    h->batchLaunched = false;
     if (h->hostErrWord && *(volatile unsigned int *)h->hostErrWord) {
-        *(volatile unsigned int *)h->hostErrWord = 0;
-        return fail(h, PT_E_HIP, "frame pipelining: a pixel's previous frame never arrived (result is not trustworthy)");
+        note_abandonment(h);
+        // (the launches the flag belongs to may already have been repaired by an earlier join; then nothing is left to do here)
+        if (!h->unverified.empty()) {
+            if (int rc = enqueue_repairs(h)) return rc;
+            PT_HIP(h, hipStreamSynchronize(h->stream));
+        }
     }
+    h->unverified.clear();
     return PT_OK;
 }
 
 // The host is about to observe the accumulation image (read it, hand out its pointer, synchronise on a bound buffer):
 // chained launches leave frame tags in its alpha channel, the reference's constant is 1 (compute.glsl:129).
-int fix_alpha(pt_handle h)
+int fix_alpha(pt_handle h, bool repairNow)
 {
-    if (int rc = join_stripes(h)) return rc;
+    if (int rc = join_stripes(h, repairNow)) return rc;
     if (h->tagsLive) {
         PT_HIP(h, pt::launch_set_alpha(h->accum(), h->tilePixels(), h->stream));
         h->tagsLive = false;
@@ -139,6 +178,17 @@ int ensure_accum(pt_handle h)
         h->accumCapacity = 0;
         PT_HIP(h, hipMalloc((void **)&h->dAccum, need * sizeof(float4)));
         h->accumCapacity = need;
+    }
+    // FrameArgs::tileFlags: sized with the image so that pt_render never allocates
+    const size_t flagTiles = (size_t)((h->width + 7) / 8) * (size_t)((h->rows + 7) / 8);
+    if (flagTiles > h->tileFlagTiles) {
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->dTileFlags) PT_HIP(h, hipFree(h->dTileFlags));
+        h->dTileFlags = nullptr;
+        h->tileFlagTiles = 0;
+        PT_HIP(h, hipMalloc((void **)&h->dTileFlags, flagTiles * sizeof(unsigned int)));
+        PT_HIP(h, hipMemsetAsync(h->dTileFlags, 0, flagTiles * sizeof(unsigned int), h->stream));
+        h->tileFlagTiles = flagTiles;
     }
 #ifdef PT_AUDIT
     if (need > h->auditCapacity) {
@@ -229,7 +279,6 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     PT_CREATE_HIP(hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking));
     h->stream = h->ownStream;
     PT_CREATE_HIP(hipEventCreateWithFlags(&h->inputsReady, hipEventDisableTiming));
-    PT_CREATE_HIP(hipEventCreateWithFlags(&h->mainDone, hipEventDisableTiming));
     PT_CREATE_HIP(hipEventCreateWithFlags(&h->gatherReady, hipEventDisableTiming));
     PT_CREATE_HIP(hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking));
     PT_CREATE_HIP(hipEventCreate(&h->evBegin));
@@ -243,6 +292,23 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
     PT_CREATE_HIP(hipHostMalloc((void **)&h->hostErrWord, sizeof(unsigned int), hipHostMallocMapped));
     *h->hostErrWord = 0;
     PT_CREATE_HIP(hipHostGetDevicePointer((void **)&h->devErrWord, h->hostErrWord, 0));
+    PT_CREATE_HIP(hipMalloc((void **)&h->dAbandon, sizeof(unsigned int)));
+    PT_CREATE_HIP(hipMemsetAsync(h->dAbandon, 0xFF, sizeof(unsigned int), h->stream)); // ABANDON_NONE
+    PT_CREATE_HIP(hipMalloc((void **)&h->dRepairCtl, 4 * sizeof(unsigned int)));
+    PT_CREATE_HIP(hipMemsetAsync(h->dRepairCtl, 0, 4 * sizeof(unsigned int), h->stream));
+    {
+        // the hand-over's wall-clock budget in units of 1,024 ticks of the device's constant-rate counter (100 MHz on gfx950)
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id) != hipSuccess || khz <= 0) khz = 100000;
+        (void)hipGetLastError();
+        const pt::Tuning &t = pt::tuning();
+        const double unitsPerMs = (double)khz / 1024.0;
+        double budget = (double)t.handoverBudgetMs * unitsPerMs, check = (double)t.handoverCheckUs * unitsPerMs / 1000.0;
+        if (budget > 1.0e9) budget = 1.0e9; // (the kernels compare signed 32-bit differences: ~2.8 hours)
+        if (check > budget / 4.0) check = budget / 4.0; // (short test budgets: look often enough)
+        h->waitBudgetUnits = (unsigned int)budget;
+        h->waitCheckUnits = (unsigned int)check;
+    }
     PT_CREATE_HIP(hipHostMalloc((void **)&h->hostStarted, ptimpl::kStartedWords * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(h->hostStarted, 0, ptimpl::kStartedWords * sizeof(unsigned int));
     PT_CREATE_HIP(hipHostGetDevicePointer((void **)&h->devStarted, h->hostStarted, 0));
@@ -293,7 +359,6 @@ PT_API int pt_destroy(pt_handle h)
     ptimpl::free_slots(h);
     if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
     if (h->gatherReady) (void)hipEventDestroy(h->gatherReady);
-    if (h->chainDone) (void)hipEventDestroy(h->chainDone);
     for (int j = 0; j < ptimpl::kMaxStripes; j++)
         if (h->stripeStream[j]) (void)hipStreamSynchronize(h->stripeStream[j]);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -302,7 +367,11 @@ PT_API int pt_destroy(pt_handle h)
         if (h->stripeStream[j]) (void)hipStreamDestroy(h->stripeStream[j]);
     }
     if (h->inputsReady) (void)hipEventDestroy(h->inputsReady);
-    if (h->mainDone) (void)hipEventDestroy(h->mainDone);
+    for (hipEvent_t e : h->launchEvents)
+        if (e) (void)hipEventDestroy(e); // (mainDone / chainDone alias entries of this ring)
+    if (h->dAbandon) (void)hipFree(h->dAbandon);
+    if (h->dRepairCtl) (void)hipFree(h->dRepairCtl);
+    if (h->dTileFlags) (void)hipFree(h->dTileFlags);
     if (h->dObjects) (void)hipFree(h->dObjects);
     if (h->dGrid) (void)hipFree(h->dGrid);
     if (h->dLut) (void)hipFree(h->dLut);
@@ -333,6 +402,7 @@ PT_API int pt_set_size(pt_handle h, int width, int height)
     if (h->isGroup()) return ptimpl::group_set_size(h, width, height);
     if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc; // (the launches so far — and their hand-over repair passes — belong to the buffers as they are)
     h->width = width;
     h->height = height;
     h->y0 = 0;
@@ -351,6 +421,7 @@ PT_API int pt_set_tile(pt_handle h, int y0, int rows)
     if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (y0 < 0 || rows <= 0 || y0 + rows > h->height) return fail(h, PT_E_BAD_ARGUMENT, "tile outside the image");
     if (int rc = bind_device(h)) return rc;
+    if (int rc = join_stripes(h)) return rc; // (see pt_set_size)
     h->y0 = y0;
     h->rows = rows;
     h->bandRows = 0;
@@ -375,6 +446,7 @@ PT_API int pt_set_interleaved_tile(pt_handle h, int rank, int world, int band_ro
         rows += (top < h->height ? top : h->height) - b * band_rows;
     }
     if (rows <= 0) return fail(h, PT_E_BAD_ARGUMENT, "this rank owns no rows (image too small for world * band_rows)");
+    if (int rc = join_stripes(h)) return rc; // (see pt_set_size)
     h->y0 = 0;
     h->rows = (int)rows;
     h->bandRows = band_rows;
@@ -607,6 +679,36 @@ int launch_frames(pt_handle h, int firstFrame, int n)
     a.tagged = tagged ? 1 : 0;
     a.keepTags = 0;
     a.chainTag = 0.0f;
+    a.abandonWord = nullptr;
+    a.tileFlags = nullptr;
+    a.waitBudget = h->waitBudgetUnits;
+    a.waitCheckInterval = h->waitCheckUnits;
+    // Hand-over bound (pt_renderer.hpp): a tagged launch gets a sequence number and the handle's abandon word, and is remembered — its
+    // kernel argument and an event behind it — until a join has put its repair pass behind it or it is seen complete with the flag down.
+    auto arm_handover = [&]() -> void { // (call with a.chainTag / a.keepTags set)
+        a.launchSeq = ++h->launchSeq;
+        if (a.launchSeq == 0 || a.launchSeq >= 0xfffffff0u) a.launchSeq = h->launchSeq = 1; // (0: a fresh roll call; ~0: "no launch abandoned")
+        a.abandonWord = h->dAbandon;
+        a.tileFlags = a.chainTag == 0.0f ? h->dTileFlags : nullptr; // (the first launch of a chain: alpha = 1 could mean "untouched" or "finished")
+    };
+    auto remember_launch = [&](hipEvent_t done) -> void {
+        // A launch seen COMPLETE with the flag DOWN — read in that order: an abandoning launch raises the flag before it ends — ran to its
+        // end and needs no repair pass.
+        auto flag_down = [&]() -> bool { return !(h->hostErrWord && *(volatile unsigned int *)h->hostErrWord); };
+        while (h->unverified.size() > 2 && hipEventQuery(h->unverified.front().done) == hipSuccess && flag_down()) h->unverified.pop_front();
+        (void)hipGetLastError(); // (hipErrorNotReady of the query is not an error)
+        if (h->unverified.size() >= (size_t)pt_renderer::kLaunchEvents / 2) { // (the event ring must not lap a remembered launch)
+            (void)hipEventSynchronize(h->unverified.front().done);
+            if (flag_down()) h->unverified.pop_front();
+        }
+        h->unverified.push_back({a, done});
+    };
+    if (tagged && h->hostErrWord && *(volatile unsigned int *)h->hostErrWord) {
+        // a launch of this handle was abandoned: put its repair (and that of everything launched since) behind a join before anything new
+        // builds on those frames
+        if (int rc = join_stripes(h)) return rc;
+        if (*(volatile unsigned int *)h->hostErrWord) ptimpl::note_abandonment(h);
+    }
 
     if (tagged && chainable) {
         // ---- chained launch: alternate between the main stream and the chain stream; the pixels' alpha tags order it behind
@@ -641,7 +743,9 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         }
         // Beside its predecessor (other stream) only if that launch is fully resident — then this launch can only ever get the slots
         // the predecessor's workgroups give up when they are done; otherwise behind it on the same stream (no overlap, always safe).
-        const bool mayChain = !h->chainBroken && h->lastWorkgroups > 0 && h->lastWorkgroups <= ptimpl::kStartedWords;
+        // (after an abandonment the device is evidently contended: for a while launches run behind their predecessor, the always-safe order)
+        if (h->overlapHoldoff > 0) h->overlapHoldoff--;
+        const bool mayChain = !h->chainBroken && h->lastWorkgroups > 0 && h->lastWorkgroups <= ptimpl::kStartedWords && h->overlapHoldoff == 0;
         auto all_started = [&]() -> bool {
             for (int i = 0; i < h->lastWorkgroups; i++)
                 if (((volatile unsigned int *)h->hostStarted)[i] != h->launchSeq) return false;
@@ -672,7 +776,6 @@ int launch_frames(pt_handle h, int firstFrame, int n)
             // the main stream; start there again, and let the chain stream see those inputs before its next launch
             if (int rc = join_stripes(h)) return rc;
             si = 0;
-            if (!h->chainDone) PT_HIP(h, hipEventCreateWithFlags(&h->chainDone, hipEventDisableTiming));
             PT_HIP(h, hipEventRecord(h->inputsReady, h->stream));
             h->chainNeedsInputs = true;
         }
@@ -690,8 +793,7 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         }
         if (a.snapshot && h->snapReadPending[h->snapshotIndex]) PT_HIP(h, hipStreamWaitEvent(st, h->snapRead[h->snapshotIndex], 0));
         a.startedFlags = h->devStarted;
-        a.launchSeq = ++h->launchSeq;
-        if (a.launchSeq == 0) a.launchSeq = ++h->launchSeq; // (0 is what a fresh array holds)
+        arm_handover();
         a.queue = h->dQueue + (si == 1 ? ptimpl::kChainQueueWord : 0); // each launch stream draws tickets from its own counter
         a.queueBase = si == 1 ? h->chainQueueBase : h->stripeQueueBase[0];
         unsigned int tickets = 0;
@@ -700,15 +802,18 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         (si == 1 ? h->chainQueueBase : h->stripeQueueBase[0]) += tickets;
         h->lastWorkgroups = workgroups;
         h->lastStreamIdx = si;
+        hipEvent_t done = ptimpl::next_launch_event(h);
+        if (!done) return fail(h, PT_E_HIP, "hipEventCreate failed");
+        PT_HIP(h, hipEventRecord(done, st));
+        remember_launch(done);
         if (si == 1) {
-            PT_HIP(h, hipEventRecord(h->chainDone, st));
+            h->chainDone = done;
             h->chainInFlight = h->chainPending = true;
-            if (a.snapshot) h->snapLaunches.push_back({st, h->chainDone, 0, h->tilePixels()});
         } else {
-            PT_HIP(h, hipEventRecord(h->mainDone, st));
+            h->mainDone = done;
             h->mainInFlight = true;
-            if (a.snapshot) h->snapLaunches.push_back({st, h->mainDone, 0, h->tilePixels()});
         }
+        if (a.snapshot) h->snapLaunches.push_back({st, done, 0, h->tilePixels()});
         h->chainBroken = false; // (join_stripes above set it; this launch re-opens the chain)
         h->mainDirty = true;    // a striped frame that follows must order its helper stripe behind this launch
         h->tagsLive = a.keepTags != 0;
@@ -725,10 +830,15 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         a.tilesY = (h->rows + 7) / 8;
         a.queue = h->dQueue;
         a.queueBase = h->stripeQueueBase[0];
+        if (tagged) arm_handover(); // (a tagged launch of an A/B variant: alone on the main stream, but its frames still hand pixels over)
         unsigned int tickets = 0;
         PT_HIP(h, pt::launch_integrate(a, h->stream, &tickets));
         h->stripeQueueBase[0] += tickets; // unsigned wrap-around is fine: the kernel subtracts queueBase modulo 2^32
-        PT_HIP(h, hipEventRecord(h->mainDone, h->stream));
+        hipEvent_t done = ptimpl::next_launch_event(h);
+        if (!done) return fail(h, PT_E_HIP, "hipEventCreate failed");
+        PT_HIP(h, hipEventRecord(done, h->stream));
+        if (tagged) remember_launch(done);
+        h->mainDone = done;
         h->mainInFlight = true;
         if (a.snapshot) h->snapLaunches.push_back({h->stream, h->mainDone, 0, h->tilePixels()});
     } else {
@@ -897,6 +1007,7 @@ int flush_with_snapshot(pt_handle h)
     if (!h->snapRead[k]) PT_HIP(h, hipEventCreateWithFlags(&h->snapRead[k], hipEventDisableTiming));
     h->snapshotTarget = h->dSnap[k];
     h->snapshotIndex = k;
+    h->snapGeneration[k]++;
     h->snapLaunches.clear();
     h->snapFrame = -1;
     const int rc = flush_frames(h);
@@ -980,11 +1091,14 @@ PT_API int pt_read_result(pt_handle h, float *dst, size_t row_pitch_bytes)
     if (row_pitch_bytes < rowBytes) return fail(h, PT_E_BAD_ARGUMENT, "row pitch smaller than a row");
     if (h->isGroup()) return ptimpl::group_read_result(h, dst, row_pitch_bytes);
     if (int rc = bind_device(h)) return rc;
-    if (int rc = ptimpl::fix_alpha(h)) return rc;
+    // (the frames first, then the hand-over check — a repair pass in the rare case — then the copy of a settled image)
+    if (int rc = ptimpl::fix_alpha(h, false)) return rc;
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    if (int rc = ptimpl::settle_handover(h)) return rc;
     PT_HIP(h, hipMemcpy2DAsync(dst, row_pitch_bytes, h->accum(), rowBytes, rowBytes, (size_t)h->rows,
                                hipMemcpyDeviceToHost, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
-    return ptimpl::check_handover(h);
+    return PT_OK;
 }
 
 PT_API int pt_write_result(pt_handle h, const float *src, size_t row_pitch_bytes, int frame_index)
@@ -1019,11 +1133,11 @@ PT_API int pt_present_rgba8(pt_handle h, uint8_t *dst, size_t row_pitch_bytes)
     if (h->isGroup()) return ptimpl::group_present_rgba8(h, dst, row_pitch_bytes);
     if (int rc = bind_device(h)) return rc;
     if (int rc = ensure_rgba8(h)) return rc;
-    if (int rc = ptimpl::tone_map_into(h, h->dRgba8)) return rc;
+    if (int rc = ptimpl::tone_map_into(h, h->dRgba8)) return rc; // (behind a join: the hand-over repair passes are in front of the tone map)
     PT_HIP(h, hipMemcpy2DAsync(dst, row_pitch_bytes, h->dRgba8, rowBytes, rowBytes, (size_t)h->rows, hipMemcpyDeviceToHost,
                                h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
-    return ptimpl::check_handover(h);
+    return PT_OK;
 }
 
 PT_API int pt_postprocess_device(pt_handle h, void **out_device_ptr, size_t *out_bytes)
@@ -1089,6 +1203,9 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
             s.frame = h->frame;
             s.rows = h->rows;
             s.width = h->width;
+            s.snapSource = h->dSnap[k];
+            s.snapGeneration = h->snapGeneration[k];
+            s.abandonEpoch = h->abandonEpoch;
             h->snapFrame = -1; // consumed
             h->snapLaunches.clear();
             return PT_OK;
@@ -1128,6 +1245,7 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
     s.frame = h->frame;
     s.rows = h->rows;
     s.width = h->width;
+    s.snapSource = nullptr; // (tone-mapped from the accumulation image behind a join: the repair passes ran in front of it)
     return PT_OK;
 }
 
@@ -1161,13 +1279,28 @@ PT_API int pt_present_wait(pt_handle h, int slot, const uint8_t **out_host_rgba8
         PT_HIP(h, hipEventSynchronize(s.copied));
         s.inFlight = false;
         s.valid = true;
-        // the image's frames are complete (the copy stream is behind them): did a frame hand-over give up?  (a group handle has no
-        // error word of its own: its parts' words are consulted)
-        std::vector<pt_handle> owners = h->isGroup() ? h->parts : std::vector<pt_handle>{h};
-        for (pt_handle p : owners) {
-            if (p->hostErrWord && *(volatile unsigned int *)p->hostErrWord) {
-                *(volatile unsigned int *)p->hostErrWord = 0;
-                return fail(h, PT_E_HIP, "frame pipelining: a pixel's previous frame never arrived (result is not trustworthy)");
+        // The image's frames are complete (the copy stream is behind them).  An image tone-mapped behind a JOIN had the hand-over repair
+        // passes in front of its tone map (group handles, presents from the accumulation image).  A SNAPSHOT present has no join: if a
+        // launch of the handle was abandoned since the tone map was enqueued, the snapshot may lack pixels — repair (the pass also
+        // completes the snapshot of the launch that wrote it), tone-map again, copy again.
+        if (!h->isGroup() && s.snapSource != nullptr) {
+            if (h->hostErrWord && *(volatile unsigned int *)h->hostErrWord) {
+                if (int rc = join_stripes(h)) return rc;
+                if (*(volatile unsigned int *)h->hostErrWord) ptimpl::note_abandonment(h);
+            }
+            if (s.abandonEpoch != h->abandonEpoch) {
+                int k = -1;
+                for (int i = 0; i < pt_renderer::kSnapshots; i++)
+                    if (h->dSnap[i] == s.snapSource && h->snapGeneration[i] == s.snapGeneration) k = i;
+                if (k < 0)
+                    return fail(h, PT_E_HIP, "present: a launch was abandoned and this slot's snapshot has been reused (call pt_present_wait on a slot before presenting into it again)");
+                if (int rc = join_stripes(h)) return rc;
+                void *const image = s.boundDev ? s.boundDev : s.dRgba8;
+                const size_t pixels = (size_t)s.rows * s.width;
+                PT_HIP(h, pt::launch_postprocess(h->dSnap[k], image, pixels, h->stream));
+                if (!s.boundDev) PT_HIP(h, hipMemcpyAsync(s.host, s.dRgba8, pixels * 4, hipMemcpyDeviceToHost, h->stream));
+                PT_HIP(h, hipStreamSynchronize(h->stream));
+                s.abandonEpoch = h->abandonEpoch;
             }
         }
     }
@@ -1190,9 +1323,9 @@ PT_API int pt_synchronize(pt_handle h)
     PT_CHECK_HANDLE(h);
     PT_FAN_OUT(h, pt_synchronize(part));
     if (int rc = bind_device(h)) return rc;
-    if (int rc = ptimpl::fix_alpha(h)) return rc; // (a bound buffer is observed after this call)
+    if (int rc = ptimpl::fix_alpha(h, false)) return rc; // (a bound buffer is observed after this call)
     PT_HIP(h, hipStreamSynchronize(h->stream));
-    return ptimpl::check_handover(h);
+    return ptimpl::settle_handover(h);
 }
 
 PT_API int pt_atmosphere_upload_data(pt_handle h, int byte_offset, int size, const void *src)
@@ -1357,6 +1490,28 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_set(const char *k
     return PT_OK;
 }
 
+// Test aid (not declared in the public header): the hand-over bound's counters of this handle (all parts of a group together).  Drains the
+// handle first.  out[0] = (pixel, frame) pairs the repair passes re-rendered, [1] = pixels whose tag fitted nothing the launch sequence can
+// have left (must stay 0), [2] = joins that had something to repair, [3] = times the host found the abandon flag raised.
+extern "C" __attribute__((visibility("default"))) int pt_debug_handover_stats(pt_handle h, unsigned int out[4])
+{
+    PT_CHECK_HANDLE(h);
+    if (!out) return fail(h, PT_E_BAD_ARGUMENT, "out == NULL");
+    if (int rc = pt_synchronize(h)) return rc;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    std::vector<pt_handle> hs = h->isGroup() ? h->parts : std::vector<pt_handle>{h};
+    for (pt_handle p : hs) {
+        if (int rc = bind_device(p)) return rc;
+        unsigned int ctl[4] = {0, 0, 0, 0};
+        PT_HIP(h, hipMemcpy(ctl, p->dRepairCtl, sizeof ctl, hipMemcpyDeviceToHost));
+        out[0] += ctl[0];
+        out[1] += ctl[1];
+        out[2] += ctl[2];
+        out[3] += p->abandonEpoch;
+    }
+    return PT_OK;
+}
+
 // Test aid (not declared in the public header): the sphere grid the NEXT launch would use for the current scene.
 // out[0..2] = cells per axis, out[3] = sphere references, out[4] = 1 if a grid exists (else the in-order loop runs).
 extern "C" __attribute__((visibility("default"))) int pt_debug_sphere_grid(pt_handle h, int out[5])
@@ -1423,11 +1578,11 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_audit_read(pt_han
 PT_API int pt_set_frame_batch(pt_handle h, int max_frames)
 {
     PT_CHECK_HANDLE(h);
-    if (max_frames < 1 || max_frames > 64) return fail(h, PT_E_BAD_ARGUMENT, "max_frames must be 1..64");
+    if (max_frames < 0 || max_frames > 64) return fail(h, PT_E_BAD_ARGUMENT, "max_frames must be 0..64");
     PT_FAN_OUT(h, pt_set_frame_batch(part, max_frames));
     if (int rc = flush_frames(h)) return rc;
-    h->maxBatch = max_frames;
-    h->maxBatchExplicit = true; // (a limit the host asked for bounds latency and deferral: never raised behind its back)
+    h->maxBatch = max_frames > 0 ? max_frames : 64;
+    h->maxBatchExplicit = max_frames > 0; // (a limit the host asked for bounds latency and deferral: never raised behind its back; 0 = automatic again)
     return PT_OK;
 }
 

@@ -128,12 +128,13 @@ int parts_ready_accum(pt_handle g, std::vector<const void *> &src, std::vector<h
     return PT_OK;
 }
 
+// (a part's rows were read behind a join of its streams: the hand-over repair passes ran in front of the read — see join_stripes)
 int parts_check_handover(pt_handle g)
 {
     for (pt_handle p : g->parts) {
         if (int rc = ptimpl::bind_device(p)) return part_fail(g, p, rc);
         PT_HIP(g, hipStreamSynchronize(p->stream));
-        if (int rc = ptimpl::check_handover(p)) return part_fail(g, p, rc);
+        if (int rc = ptimpl::settle_handover(p)) return part_fail(g, p, rc);
     }
     return PT_OK;
 }

@@ -53,7 +53,11 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
     };
 
     int avail = 0, parked = 0, qhead = 0; // wave-uniform: ring entries [0, avail); `parked` continuations from slot qhead on (FIFO, circular)
-    int stalled = 0;                      // wave-uniform: consecutive iterations in which no lane traced anything
+    // the hand-over's wall-clock bound (pt_kernel_common.hpp), kept per WAVEFRONT: waiting records move between lanes, ring and queue, so
+    // what is timed is "this wavefront has done nothing but wait since" (0: some lane traced in the last iteration)
+    HandoverBound bound;
+    bound.init();
+    unsigned int stallSince = 0u, noLaneWait = 0u;
     auto qslot = [&](int i) -> int { // slot of the i-th parked continuation
         int sl = qhead + i;
         return sl >= parkCapacity ? sl - parkCapacity : sl;
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         const float alpha = (rfj == ca->batchFrames - 1 && !ca->keepTags) ? 1.0f : frame_tag(ca->frame + rfj);
         return make_float4(f_mix(last.x, rirr.x, w), f_mix(last.y, rirr.y, w), f_mix(last.z, rirr.z, w), alpha);
     };
-    auto try_resolve = [&](int rpix, int rfj, v3 rirr, bool force) -> bool {
+    auto try_resolve = [&](int rpix, int rfj, v3 rirr) -> bool {
         const size_t pidx = (size_t)((rpix >> 16) * cold_args()->width + (rpix & 0xffff));
         float4 *ptr = a.accum + pidx;
         if (!a.tagged) {
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         CHAOS(20);
         float4 last = load_pixel_sc1(ptr);
         const float expected = rfj > 0 ? frame_tag(a.frame + rfj - 1) : a.chainTag;
-        if (expected != 0.0f && !force && last.w != expected) return false;
+        if (expected != 0.0f && last.w != expected) return false;
         if (AUDIT_SABOTAGED(a, rpix, rfj)) last.x += 1.0f; // (audit build + PT_AUDIT_SABOTAGE only: a simulated stale / torn read)
         CHAOS(21);
         const float4 next = fold(last, rirr, rfj);
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
     // retry it, oldest first) and the freed lanes pop the ring as usual: no queued work depends on a lane that only waits,
     // and every pixel still runs the same samples in the same order on its own RNG stream.  Should the queue itself be full
     // of waiting results (more than 150 finished pixels of one wavefront all waiting for other frames), the per-wavefront
-    // stall bound below ends the wait with the error word instead of hanging.  (Swapping waiting results with queued paths
+    // wall-clock bound below abandons the launch instead of hanging (the host's repair pass then renders what is missing).  (Swapping waiting results with queued paths
     // was tried first: it needs the path state to be assignable at a second place, which costs 20 spilled VGPRs.)
     auto rescue = [&]() -> void {
         const int room = parkCapacity - parked;
@@ -152,6 +156,8 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                         exhausted = true;
                         continue; // (parked continuations, if any, are next)
                     }
+                    if (unsigned int *flags = cold_args()->tileFlags) // (FrameArgs::tileFlags: where the launch's first frame ran)
+                        if (tile < numTilesFrame && lane == 0) flags[tile] = cold_args()->launchSeq;
                 }
                 ColdArgs ca = cold_args();
                 ColdFloats cam = (ColdFloats)ca;
@@ -227,10 +233,8 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                     tsample++;
                 }
                 bool tmore = tfin && tsample < a.spp;
-                if (twaiting) { // still waiting: back into the queue, as it was
-                    const bool force = stalled > FRAME_RETRY_LIMIT;
-                    if (!try_resolve(tpix, tfj, tirr, force)) tmore = true;
-                    else if (force) atomicOr(cold_args()->errorWord, 1u);
+                if (twaiting) { // still waiting: back into the queue, as it was (an abandoned launch drops it: the host's repair pass renders it)
+                    if (!try_resolve(tpix, tfj, tirr) && !bound.abandoned) tmore = true;
                 }
                 const unsigned long long pm = __ballot(tmore);
                 bool toRing = false; // overflow of the queue / a resolve that has to wait: through the ring, handled in the lane
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                     const int n = __builtin_popcountll(pm);
                     parked += n < room ? n : room;
                 }
-                if (tfin && tsample >= a.spp && !try_resolve(tpix, tfj, tirr, false)) {
+                if (tfin && tsample >= a.spp && !try_resolve(tpix, tfj, tirr) && !bound.abandoned) {
                     toRing = true;
                     ringCounters = a.rayDepth | (tsample << 12) | (tfj << 24); // "at full depth": resolved in the bounce loop
                 }
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         bool active = pix >= 0;
         if (__ballot(active) == 0ull) {
             if (exhausted && avail == 0 && parked == 0) break;
-            stalled++; // (only waiting records left in the queue: they are retried by the batch passes above)
+            (void)bound.tick(false, noLaneWait, stallSince, true); // (only waiting records left in the queue: they are retried — or, abandoned, dropped — by the batch passes above)
             if (parked > 0 && avail == 0) __builtin_amdgcn_s_sleep(8);
             continue;
         }
@@ -309,9 +313,10 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
             // path the lane pops next would have resumed someone else's walk: found by tools/handover_stress --multisample)
             active = pix >= 0;
         }
-        // (a wavefront that has done nothing but wait for FRAME_RETRY_LIMIT iterations in a row gives up the hand-over: waiting
-        // records move between lanes, ring and queue, so the bound is kept per wavefront, not per lane)
-        stalled = __ballot(pix >= 0 && !pending) == 0ull ? stalled + 1 : 0;
+        // (a wavefront that has done nothing but wait for FrameArgs::waitBudget abandons the launch: waiting records move between lanes,
+        // ring and queue, so the bound is kept per wavefront, not per lane)
+        const bool nothingTraced = __ballot(pix >= 0 && !pending) == 0ull;
+        if (nothingTraced || stallSince != 0u) (void)bound.tick(false, noLaneWait, stallSince, nothingTraced);
         if (active && needRay) { // fallback (queue was full): the next sample's primary ray, generated in the lane
             const int pxy = pixel_xy(pix);
             primary_ray(a, pxy & 0xffff, pxy >> 16, seed, ro, rd);
@@ -353,9 +358,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
             __builtin_amdgcn_wave_barrier();
         }
         if (pix >= 0 && pending) {
-            const bool force = stalled > FRAME_RETRY_LIMIT; // (bounded per wavefront: waiting records move between lanes, ring and queue)
-            if (try_resolve(pix, fj, irr, force)) {
-                if (force) atomicOr(cold_args()->errorWord, 1u);
+            if (try_resolve(pix, fj, irr) || bound.abandoned) { // (abandoned launch: a result that still has to wait is dropped, the host's repair pass renders it)
                 pix = -1;
                 pending = false;
             }

@@ -49,6 +49,107 @@ __global__ __launch_bounds__(256) void pt_integrate_kernel(const FrameArgs a)
     a.accum[idx] = next;                                         // imageStore (compute.glsl:129)
 }
 
+// ---- the repair pass of the hand-over bound (pt_kernel_common.hpp): what an ABANDONED tagged launch left undone.  Enqueued by the host
+// behind a join of the handle's streams for every launch since the previous join (FrameArgs by value: the launch's own inputs), so it
+// runs with nothing else of the handle in flight and plain loads and stores do; when no launch was abandoned — always, outside a
+// contended device — every workgroup leaves after one load.  One lane per pixel, a small grid striding over the tiles.  The pixel's
+// alpha says which frame it holds: tag(f) of this launch -> frames up to f are in; a tag of a later launch, or the 1 that the last
+// launch of a chain stores last -> all of them are; anything else -> none (its predecessor's last tag, the 1 / 0 of an image no tagged
+// launch has touched; FrameArgs::tileFlags tells the two meanings of 1 apart).  The missing frames are folded in frame order with the
+// arithmetic every kernel uses (compute.glsl:101-130), so the image is bit for bit the one the undisturbed launch would have left.
+// Launches are repaired in launch order (stream order of these kernels); a pixel is always handled by the same lane of the same
+// workgroup.  ctl: [0] += (pixel, frame) pairs rendered, [1] += pixels whose tag fits nothing the launch sequence can have left.
+__global__ __launch_bounds__(256) void pt_repair_kernel(const FrameArgs a, unsigned int *ctl)
+{
+    if (*(const volatile unsigned int *)a.abandonWord > a.launchSeq) return; // (uniform: nothing of this launch is missing)
+    SceneLds sc = stage_scene(a);
+    EnvRef env{a.env, (LdsFloats)sc.lut, a.envSize, a.envFormat};
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tiles = a.tilesX * a.tilesY, n = a.batchFrames;
+#ifdef PT_PROFILE
+    unsigned long long prof_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    for (int tile = (int)blockIdx.x * 4 + wave; tile < tiles; tile += (int)gridDim.x * 4) {
+        const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+        const int px = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+        if (px >= a.width || ly >= a.rows) continue;
+        const int gy = global_row(a, ly);
+        const size_t idx = (size_t)ly * a.width + px;
+        float4 last = a.accum[idx];
+        int done = 0, odd = 0;
+        if (last.w >= FRAME_TAG) {
+            const int rel = ((int)last.w - (int)FRAME_TAG - a.frame) & 1023;
+            if (rel < n) done = rel + 1;
+            else if (rel < 512) done = n;           // a later launch got this far: every frame of this one is in
+            else if (last.w != a.chainTag) odd = 1; // older than the predecessor's last frame: the launches before were not complete
+        } else if (last.w == 1.0f) {
+            // 1 is what the last frame of a launch that does not keep its tags stores — this launch's, or a later one's of the same chain —
+            // and what an image no tagged launch has touched holds.  A chained launch never meets the latter (its pixels start from the
+            // predecessor's tag); a launch that starts a chain knows from its tile flags whether its first frame ran on the tile (then
+            // the pixel held a tag at some point, and 1 means "finished")
+            done = (a.chainTag != 0.0f || (a.tileFlags && a.tileFlags[tile] == a.launchSeq)) ? n : 0;
+        } else if (a.chainTag != 0.0f) {
+            odd = 1; // (a chained launch never meets an untagged unfinished pixel)
+        }
+        for (int j = done; j < n; j++) {
+            uint32_t seed = pixel_seed(px, gy, a.frame + j); // compute.glsl:106
+            v3 irr = V(0.0f, 0.0f, 0.0f);
+            for (int sidx = 0; sidx < a.spp; sidx++) {
+                v3 ro, rd;
+                primary_ray(a, px, gy, seed, ro, rd);
+                irr = v_add(irr, radiance(a, sc, env, ro, rd, seed));
+            }
+            irr = v_scale(irr, f_div_ieee(1.0f, (float)a.spp));
+            const float w = f_div_ieee(1.0f, (float)(a.frame + j + 1));
+            const float alpha = (j == n - 1 && !a.keepTags) ? 1.0f : frame_tag(a.frame + j);
+            const float4 next = make_float4(f_mix(last.x, irr.x, w), f_mix(last.y, irr.y, w), f_mix(last.z, irr.z, w), alpha);
+            AUDIT_RESOLVE(a, idx, a.frame + j, last, next, 8);
+            last = next;
+        }
+        if (done < n) {
+            a.accum[idx] = last;
+            if (a.snapshot) a.snapshot[idx] = make_float4(last.x, last.y, last.z, 1.0f);
+            atomicAdd(ctl, (unsigned int)(n - done));
+        }
+        if (odd) atomicAdd(ctl + 1, 1u);
+    }
+}
+
+// ... and behind the repair passes of a join: the handle's abandon word and ticket counters as a fresh chain expects them (an abandoned
+// launch draws fewer tickets than the host accounted for).  ctl[2] counts the joins that had something to repair.
+__global__ void pt_repair_done_kernel(unsigned int *abandonWord, unsigned int *queueMain, unsigned int expectMain, unsigned int *queueChain,
+                                      unsigned int expectChain, unsigned int *ctl)
+{
+    if (*abandonWord == ABANDON_NONE) return;
+    *abandonWord = ABANDON_NONE;
+    *queueMain = expectMain;
+    *queueChain = expectChain;
+    ctl[2] += 1u;
+}
+
+hipError_t launch_repair(const FrameArgs &args, unsigned int *ctl, hipStream_t stream)
+{
+    FrameArgs a = args;
+    a.materialsInLds = 1;
+    a.gridLdsBytes = 0;
+    a.tileMasks = nullptr;
+    a.timeline = nullptr;
+    const int tiles = a.tilesX * a.tilesY;
+    if (tiles <= 0 || a.abandonWord == nullptr) return hipSuccess;
+    int nwg = 2 * a.numCUs;
+    if (nwg > (tiles + 3) / 4) nwg = (tiles + 3) / 4;
+    const size_t lds = scene_lds_bytes(a.numSpheres, a.numCuboids, a.envFormat, true);
+    hipLaunchKernelGGL(pt_repair_kernel, dim3(nwg), dim3(256), lds, stream, a, ctl);
+    return hipGetLastError();
+}
+
+hipError_t launch_repair_done(unsigned int *abandonWord, unsigned int *queueMain, unsigned int expectMain, unsigned int *queueChain,
+                              unsigned int expectChain, unsigned int *ctl, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pt_repair_done_kernel, dim3(1), dim3(1), 0, stream, abandonWord, queueMain, expectMain, queueChain, expectChain, ctl);
+    return hipGetLastError();
+}
+
 // ---- variants 2..6: wave-level pixel pool with path regeneration.
 // Russian roulette and environment misses end paths after very different numbers of bounces (mean 2.7 of 8 in the
 // default scene), so a wave that keeps one pixel per lane idles most lanes most of the time.  Here a wavefront
@@ -245,7 +346,11 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     // parked resolves of this wavefront (pipelined spp = 1 launches only; behind the rings — such launches have no drain pool)
     ParkedResolve *parkedList = (ParkedResolve *)(ringBase + NWAVES * 64 * ENTRY_BYTES + LANE_LAST_BYTES) + wave * a.parkedMax;
     const bool parking = SPP1 && a.tagged && !compaction && a.parkedMax > 0;
-    int nparked = 0, parkSpins = 0; // wave-uniform
+    int nparked = 0; // wave-uniform
+    bool parkProgress = false;         // ... the last service round resolved at least one parked entry
+    unsigned int parkSince = 0u;       // ... wait_clock() | 1 since when the list has made no progress (0: empty, or it just did)
+    HandoverBound bound;               // the hand-over's wall-clock bound (pt_kernel_common.hpp)
+    bound.init();
     const int donateMax = a.drainCompaction < DONATE_MAX ? a.drainCompaction : DONATE_MAX; // a wavefront this thin donates
     const bool leader = lane == 0;
 
@@ -264,14 +369,16 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     uint32_t seed = 0;
     v3 ro = V(0, 0, 0), rd = V(0, 0, 1), throughput = V(1, 1, 1), rad = V(0, 0, 0), irr = V(0, 0, 0);
     // SPP1 / frame pipelining: index of the path's frame inside the batch, "ended, waiting for its pixel's previous
-    // frame" flag, and the number of failed resolve attempts
+    // frame" flag, and since when it waits
     int fj = 0;
     bool pending = false;
-    // One register, two lives.  While the lane's path is being traced (!pending): GRID kernels keep the parameter from which the grid walk
-    // of the current bounce continues (>= 0 while it is unfinished, else -1: pt_device.hpp, WALK SLICES).  Once the path has ended and
-    // waits for its pixel (pending): the bits count the failed resolve attempts.
+    // GRID kernels: the parameter from which the grid walk of the current bounce continues (>= 0 while it is unfinished, else -1:
+    // pt_device.hpp, WALK SLICES); dead in the other kernels
     float walkFrom = -1.0f, walkFresh = -1.0f;
-    auto retries = [&]() -> int { return __float_as_int(walkFrom); };
+    // wait_clock() | 1 at the lane's first failed resolve (0: not waiting); every site that loads a path into the lane goes through
+    // begin_path(), which resets both
+    unsigned int waitSince = 0u;
+    auto begin_path = [&]() -> void { pending = false; walkFrom = -1.0f; waitSince = 0u; };
     // (CARRY: bit 14 of fj = the lane's slot of laneLast holds the pixel's accumulation value as the tile pass read it)
 
     // compute.glsl:125-129 for one finished path of frame `rfj` of the batch.  False = the pixel still holds an older
@@ -303,7 +410,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             if (rfj == cold_args()->batchFrames - 1) snap[rpix] = make_float4(next.x, next.y, next.z, 1.0f);
     };
     // False = the pixel still holds an older frame (only possible inside a batch): try again in the next iteration.
-    auto try_resolve = [&](int rpix, int rfj, v3 rirr, bool force) -> bool {
+    auto try_resolve = [&](int rpix, int rfj, v3 rirr) -> bool {
         float4 *ptr = a.accum + rpix;
         if (!a.tagged) {
             float4 last = *ptr;
@@ -316,7 +423,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         CHAOS(10);
         float4 last = load_pixel_sc1(ptr);
         const float expected = rfj > 0 ? frame_tag(a.frame + rfj - 1) : a.chainTag; // (0 = the launch's first frame has no predecessor in flight)
-        if (expected != 0.0f && !force && last.w != expected) return false;
+        if (expected != 0.0f && last.w != expected) return false;
         if (AUDIT_SABOTAGED(a, rpix, rfj)) last.x += 1.0f; // (audit build + PT_AUDIT_SABOTAGE only: a simulated stale / torn read)
         CHAOS(11);
         const float4 next = fold(last, rirr, rfj);
@@ -346,7 +453,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         return fits;
     };
     // retry the parked resolves: lane l takes entry l; the ones that still have to wait are compacted to the front
-    auto service_parked = [&](bool force) -> void {
+    auto service_parked = [&]() -> void {
+        parkProgress = false;
         if (nparked == 0) return;
         CHAOS(4);
         const bool mine = lane < nparked;
@@ -354,15 +462,14 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         bool keep = false;
         if (mine) {
             e = parkedList[lane];
-            keep = !try_resolve(e.pix, e.fj, V(e.irr[0], e.irr[1], e.irr[2]), force);
+            keep = !try_resolve(e.pix, e.fj, V(e.irr[0], e.irr[1], e.irr[2]));
         }
         const unsigned long long km = __ballot(keep);
         __builtin_amdgcn_wave_barrier(); // every entry has been read before the survivors are written back
         if (keep) parkedList[__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u))] = e;
         const int left = __builtin_popcountll(km);
-        parkSpins = left == nparked ? parkSpins + 1 : 0;
+        parkProgress = left < nparked;
         nparked = left;
-        if (force && lane == 0) atomicOr(cold_args()->errorWord, 1u);
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -411,6 +518,10 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         } else {
                             cull_spheres(sc, a.numSpheres, valid, to, td, masks);
                         }
+                        // (a launch that starts on alpha = 1 and ends on alpha = 1 notes where its first frame ran: all the repair pass has to
+                        // tell an untouched pixel from a finished one, see FrameArgs::tileFlags)
+                        if (unsigned int *flags = ca->tileFlags)
+                            if (tfj == 0 && lane == 0) flags[tile] = ca->launchSeq;
                         bool tcont = false, tkeep = false; // tkeep: the path goes to the ring (it continues, or its resolve must wait)
                         [[maybe_unused]] bool plastOk = false; // (CARRY)
                         [[maybe_unused]] float4 plast = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -432,7 +543,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                                 commit_resolve(tpix, tfj, v_add(V(0.0f, 0.0f, 0.0f), trad), V(plast.x, plast.y, plast.z));
                             } else if (!tcont) { // the path ended at its first bounce: compute.glsl:125-129 right away
                                 v3 tirr = v_add(V(0.0f, 0.0f, 0.0f), trad);
-                                tkeep = !try_resolve(tpix, tfj, tirr, false);
+                                tkeep = !try_resolve(tpix, tfj, tirr);
                             }
                         }
                         if (parking) { // resolves that have to wait for the previous frame: parked (else through the ring)
@@ -472,6 +583,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         const float invW = ca->invW, invH = ca->invH;
                         int tfj, tx, ty; // frame of the batch this (frame, tile) ticket belongs to; tile column, row
                         fast_divmod(tile, numTilesFrame, ca->tilesFrameMagic, tfj, tile);
+                        if (unsigned int *flags = ca->tileFlags) // (FrameArgs::tileFlags: where the launch's first frame ran)
+                            if (tfj == 0 && lane == 0) flags[tile] = ca->launchSeq;
                         fast_divmod(tile, tilesX, ca->tilesXMagic, ty, tx);
                         int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
                         RingEntry e;
@@ -508,8 +621,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         if (e.bounce & PATH_HAS_LAST) fj |= 0x4000;
                         laneLast[0] = e.last[0]; laneLast[64] = e.last[1]; laneLast[128] = e.last[2];
                     }
-                    pending = false;
-                    walkFrom = -1.0f;
+                    begin_path();
                     seed = e.seed;
                     ro = V(e.ro[0], e.ro[1], e.ro[2]);
                     rd = V(e.rd[0], e.rd[1], e.rd[2]);
@@ -535,8 +647,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         irr = V(0.0f, 0.0f, 0.0f);
                         sample = 0;
                         fj = e.pad;
-                        pending = false;
-                        walkFrom = -1.0f;
+                        begin_path();
                         bounce = 0;
                         needRay = false;
                     }
@@ -567,9 +678,9 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                             PathState st = pool[taken + rank];
                             pix = st.pix;
                             bounce = (st.counters >> 12) & 0xfff;
+                            begin_path(); // (an adopted path that was waiting starts its wait anew; a donor never holds an unfinished walk: see the donation)
                             pending = (st.counters >> 25) & 1;
                             fj = (st.counters >> 26) & 0x3f;
-                            walkFrom = pending ? 0.0f : -1.0f;
                             if constexpr (CARRY) {
                                 if (st.counters & 1) fj |= 0x4000;
                                 laneLast[0] = st.irr[0]; laneLast[64] = st.irr[1]; laneLast[128] = st.irr[2];
@@ -595,7 +706,11 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         const unsigned long long am = __ballot(active);
         if (am == 0ull) {
             if (parking && nparked > 0) { // nothing to trace: look after the parked resolves (they must be gone before leaving)
-                service_parked(parkSpins > FRAME_RETRY_LIMIT);
+                service_parked();
+                if (nparked > 0) {
+                    unsigned int none = 0u;
+                    if (bound.tick(false, none, parkSince, !parkProgress)) nparked = 0; // (abandoned launch: the host's repair pass renders them)
+                }
                 if (nparked > 0 && exhausted && avail == 0) __builtin_amdgcn_s_sleep(8);
             }
             if (!(exhausted && avail == 0 && nparked == 0)) continue;
@@ -683,7 +798,6 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             if (trace && !(GRID && walkFrom >= 0.0f)) { // (else: the grid walk of this bounce continues in the next iteration, pt_device.hpp WALK SLICES)
                 bounce++;
                 pending = !cont || bounce >= a.rayDepth;
-                if (pending) walkFrom = 0.0f; // (= no failed resolve attempt yet)
             }
 #ifdef PT_PROFILE
             prof_t = __builtin_readcyclecounter();
@@ -695,13 +809,9 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             }
             if (active && pending) {
                 v3 firr = v_add(V(0.0f, 0.0f, 0.0f), rad);
-                const bool force = retries() > FRAME_RETRY_LIMIT;
-                if (try_resolve(pix, fj, firr, force)) {
-                    if (force) atomicOr(cold_args()->errorWord, 1u); // host-visible error word
+                if (try_resolve(pix, fj, firr)) {
                     pix = -1;
                     pending = false;
-                } else {
-                    walkFrom = __int_as_float(retries() + 1);
                 }
             }
             if (parking) {
@@ -711,10 +821,22 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                     pix = -1;
                     pending = false;
                 }
-                service_parked(parkSpins > FRAME_RETRY_LIMIT);
+                service_parked();
             }
-            // nothing but waiting paths left in this wavefront: do not hammer the pixel
-            if ((__ballot(pix >= 0 && pending) != 0ull || nparked > 0) && __ballot(pix >= 0 && !pending) == 0ull && avail == 0) __builtin_amdgcn_s_sleep(8);
+            // results that wait for their pixel's previous frame (in their lanes, or parked): the wall-clock bound; an abandoned launch drops them
+            const bool waits = pix >= 0 && pending;
+            const unsigned long long waitMask = __ballot(waits);
+            if (waitMask != 0ull || nparked > 0) {
+                if (bound.tick(waits, waitSince, parkSince, nparked > 0 && !parkProgress)) {
+                    if (waits) {
+                        pix = -1;
+                        pending = false;
+                    }
+                    nparked = 0;
+                } else if (__ballot(pix >= 0 && !pending) == 0ull && avail == 0) {
+                    __builtin_amdgcn_s_sleep(8); // nothing but waiting paths left in this wavefront: do not hammer the pixel
+                }
+            }
         } else {
         if (active && needRay) { // only for spp > 1: the next sample continues the pixel's RNG stream (compute.glsl:110)
             primary_ray(a, px, py, seed, ro, rd);
@@ -734,24 +856,33 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                     irr = v_add(irr, rad);
                     sample++;
                     if (sample < a.spp) needRay = true;
-                    else { pending = true; walkFrom = 0.0f; } // the pixel's last sample: fold into the accumulation image (no failed attempt yet)
+                    else pending = true; // the pixel's last sample: fold into the accumulation image
                 }
             }
 #ifdef PT_PROFILE
             prof_t = __builtin_readcyclecounter();
 #endif
             if (active && pending) {
-                const bool force = retries() > FRAME_RETRY_LIMIT;
-                if (try_resolve(pix, fj, irr, force)) {
-                    if (force) atomicOr(cold_args()->errorWord, 1u);
+                if (try_resolve(pix, fj, irr)) {
                     pix = -1;
                     pending = false;
-                } else {
-                    walkFrom = __int_as_float(retries() + 1);
                 }
             }
         }
-        if (__ballot(active && pending) != 0ull && __ballot(active && !pending) == 0ull) __builtin_amdgcn_s_sleep(8);
+        {
+            const bool waits = pix >= 0 && pending;
+            if (__ballot(waits) != 0ull) {
+                unsigned int noList = 0u;
+                if (bound.tick(waits, waitSince, noList, false)) { // (abandoned launch: waiting results are dropped, the host's repair pass renders them)
+                    if (waits) {
+                        pix = -1;
+                        pending = false;
+                    }
+                } else if (__ballot(pix >= 0 && !pending) == 0ull) {
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+        }
         } // !SPP1
         PROF_MARK(7) // resolve
     }

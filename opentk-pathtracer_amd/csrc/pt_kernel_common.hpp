@@ -91,7 +91,8 @@ PT_DEV int xcd_band_id(int b, int nwg)
 // with ONE 16-byte device-scope (sc1) store and read with ONE 16-byte sc1 load — single-copy atomic and coherent
 // across the 8 XCD L2s — so colour and tag always belong together.  A resolve that finds its predecessor missing is
 // simply retried in the wavefront's next iteration (never a spin loop: the predecessor may live in another lane of
-// the same wavefront); after FRAME_RETRY_LIMIT attempts it proceeds anyway and raises the launch's error word.
+// the same wavefront).  The wait is bounded by WALL CLOCK (FrameArgs::waitBudget), and a result whose wait runs out is
+// never folded onto a stale pixel: its launch is abandoned and the host re-renders what is missing (see "hand-over bound" below).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr float FRAME_TAG = 2.0f;
 // the tag of (absolute) frame f: distinct for any two frames that can be in flight together, exact in binary32.  Launches
@@ -99,7 +100,63 @@ constexpr float FRAME_TAG = 2.0f;
 // two launches on different streams overlap like the frames inside one launch do (the second fills the wavefront slots the
 // first one's drain frees) — the host restores alpha = 1 before anything can observe the image (pt_set_alpha_kernel).
 PT_DEV float frame_tag(int absFrame) { return FRAME_TAG + (float)(absFrame & 1023); }
-constexpr int FRAME_RETRY_LIMIT = 1 << 22;
+
+// ---- hand-over bound (round 5): wall clock, and giving up means ABANDONING the launch — never a fold onto a stale pixel.
+// Time is the constant-rate counter (s_memrealtime, 100 MHz) >> 10: one unit = 10.24 us, 32 bits wrap after 12 hours (differences are
+// taken modulo 2^32).  A lane (or parked list) notes when it started to wait; once per FrameArgs::waitCheckInterval a waiting wavefront
+// looks at the handle's abandon word and at its own waits: one of them older than FrameArgs::waitBudget -> the wavefront abandons the
+// launch (atomicMin of the launch's sequence number into the abandon word, host-visible flag raised); a launch whose sequence number is
+// >= the abandon word stops drawing tickets (queue_pop_tile) and its wavefronts DROP the results that still wait: their pixels keep
+// the tag of the last frame that was folded, which is all the host's repair pass (pt_repair_kernel) needs to re-render exactly the
+// missing (pixel, frame) pairs behind the launch, in order.  Results that do not have to wait are folded as usual, abandoned or not.
+PT_DEV unsigned int wait_clock() { return (unsigned int)((unsigned long long)wall_clock64() >> 10); }
+constexpr unsigned int ABANDON_NONE = 0xffffffffu;
+// has this launch (or an earlier one of its handle whose frames it builds on) been abandoned?  Device-scope load, wave-uniform.
+PT_DEV bool launch_abandoned()
+{
+    ColdArgs ca = cold_args();
+    if (ca->abandonWord == nullptr) return false;
+    const unsigned int w = __hip_atomic_load((const unsigned int *)ca->abandonWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane((int)(w <= ca->launchSeq)) != 0;
+}
+// give the launch up (any lane may call; one atomic per wavefront is enough, more are harmless)
+PT_DEV void abandon_launch()
+{
+    ColdArgs ca = cold_args();
+    if (ca->abandonWord == nullptr) return;
+    if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(true))) {
+        atomicMin((unsigned int *)ca->abandonWord, ca->launchSeq);
+        __hip_atomic_fetch_or((unsigned int *)ca->errorWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// Wave-uniform state of the bound.  tick() is called once per iteration in which something of the wavefront waits (lanes: `waits`, with
+// the lane's waitSince; lists: listSince = 0 when the list is empty or made progress); returns true when waiting results must be DROPPED.
+struct HandoverBound {
+    unsigned int nextCheck; // wait_clock() value from which the abandon word is looked at again
+    bool abandoned;         // latched
+    PT_DEV void init() { nextCheck = wait_clock(); abandoned = false; }
+    PT_DEV bool tick(bool waits, unsigned int &waitSince, unsigned int &listSince, bool listStuck)
+    {
+        const unsigned int now = wait_clock();
+        if (waits && waitSince == 0u) waitSince = now | 1u;
+        if (!listStuck) listSince = 0u;
+        else if (listSince == 0u) listSince = now | 1u;
+        if (!abandoned && (int)(now - nextCheck) >= 0) { // (wave-uniform, taken once per waitCheckInterval)
+            ColdArgs ca = cold_args();
+            nextCheck = now + ca->waitCheckInterval;
+            // (signed differences: a start time is stored with its lowest bit set — 0 means "not waiting" — and may lie one unit ahead)
+            const int budget = (int)ca->waitBudget;
+            const bool expired = (waits && (int)(now - waitSince) > budget) || (listSince != 0u && (int)(now - listSince) > budget);
+            if (__ballot(expired) != 0ull) {
+                abandon_launch();
+                abandoned = true;
+            } else {
+                abandoned = launch_abandoned();
+            }
+        }
+        return abandoned;
+    }
+};
 constexpr int MAX_BATCH_FRAMES = 256; // (one workgroup fills the weight table: <= its 256 threads; tags cover 1,024 frames)
 
 PT_DEV float4 load_pixel_sc1(const float4 *p)
@@ -206,7 +263,9 @@ PT_DEV int queue_pop_tile(BlockQueue *q)
                 ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
                 const long long first = ((ca->tagged ? 0ll : (long long)gridDim.x) + ticket) * chunk; // tagged launches have no static chunks
                 const long long last = first + chunk < numTiles ? first + chunk : numTiles;
-                if (first >= numTiles) {
+                // (an abandoned launch hands out no more work: what it leaves undone is re-rendered by the host's repair pass — the ticket
+                // just drawn is simply not used, the host resets the counters after a repair)
+                if (first >= numTiles || (ca->tagged && launch_abandoned())) {
                     if (leader) lds_store(&q->done, 1u);
                 } else {
                     if (leader) atomicExch(&q->pair, ((unsigned long long)last << 32) | (unsigned long long)first);

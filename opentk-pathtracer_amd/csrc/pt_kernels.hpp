@@ -33,7 +33,7 @@ struct FrameArgs {
     int tilesX, tilesY;     // 8x8-pixel tiles covering width x rows
     int variant;            // kernel variant for A/B runs; all variants are bit-identical in output
     unsigned int *queue;    // global chunk-ticket counter of the persistent kernel (monotonic across launches)
-    unsigned int *errorWord; // set to 1 when a frame hand-over of the pipelining gives up (host-visible memory)
+    unsigned int *errorWord; // host-visible flag: a launch of this handle ABANDONED its hand-over (see abandonWord); the host repairs
     unsigned int queueBase; // value of *queue when this launch starts (every launch consumes exactly numChunks tickets)
     int numCUs;             // compute units of the device (grid sizing of persistent variants)
     int queueChunk;         // tiles per global ticket of the persistent kernel's queue
@@ -53,7 +53,17 @@ struct FrameArgs {
     // Launch chaining: every workgroup of a tagged launch stores launchSeq into startedFlags[blockIdx.x] (host-visible memory)
     // when it starts, so that the host can tell whether the launch is fully RESIDENT (see launch_frames in mi355pt.cpp)
     unsigned int *startedFlags;
-    unsigned int launchSeq;
+    unsigned int launchSeq; // sequence number of this launch on its handle (every tagged launch has one; never 0)
+    // Hand-over bound (round 5).  A result whose pixel does not show the previous frame's tag within waitBudget (wall clock, units of
+    // 1,024 ticks of the constant 100 MHz counter) is NOT folded onto a stale pixel: the launch is ABANDONED — abandonWord (device
+    // memory, one per handle, ~0u = none) receives the lowest abandoned launchSeq, every launch of that or a later sequence number stops
+    // drawing tickets and drops the results that still wait — and the host re-renders exactly the missing (pixel, frame) pairs behind
+    // it with pt_repair_kernel (every pixel's alpha tag says which frame it holds), so the image is the one an undisturbed launch
+    // produces.  tileFlags (only the first launch of a chain: chainTag == 0): one word per 8x8 tile = launchSeq of the last such launch
+    // whose FIRST frame ran its tile pass there (tells an untouched pixel from a finished one where both hold alpha = 1).
+    unsigned int *abandonWord;
+    unsigned int *tileFlags;
+    unsigned int waitBudget, waitCheckInterval; // (same unit; the abandon word is looked at once per waitCheckInterval while a wavefront waits)
     // Sphere grid of large scenes (pt_sphere_grid.hpp; nullptr = none): a uniform grid over the spheres' bounds, per cell the
     // ascending list of the spheres whose (slightly inflated) bounding box touches it.  Packed as uint16 starts[cells + 1]
     // followed by uint8 refs[starts[cells]]; staged into LDS by the kernels that traverse it.
@@ -109,6 +119,13 @@ struct AtmoArgs {
 // ticketsConsumed: by how much the launch advances *a.queue (the caller adds it to the next launch's queueBase)
 // workgroups: the grid size of the launch (persistent kernels)
 hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int *ticketsConsumed, int *workgroups = nullptr);
+// Hand-over repair (pt_repair_kernel): enqueued behind a join of the handle's streams, once per tagged launch since the previous join, in
+// launch order — a no-op unless a.abandonWord says the launch (or one it builds on) was abandoned; then every pixel's missing frames of the
+// launch described by `a` are re-rendered.  ctl = 4 device words (pairs rendered, inconsistent pixels, joins with repairs, spare).
+hipError_t launch_repair(const FrameArgs &a, unsigned int *ctl, hipStream_t stream);
+// ... followed by ONE of these: abandon word and ticket counters back to what a fresh chain expects
+hipError_t launch_repair_done(unsigned int *abandonWord, unsigned int *queueMain, unsigned int expectMain, unsigned int *queueChain,
+                              unsigned int expectChain, unsigned int *ctl, hipStream_t stream);
 hipError_t launch_atmosphere(const AtmoArgs &a, hipStream_t stream);
 // masks[kTileMaskWords * tile + w] for every 8x8 tile of the launch described by `a` (tilesX x tilesY tiles; see FrameArgs::tileMasks)
 hipError_t launch_tile_masks(const FrameArgs &a, unsigned long long *masks, hipStream_t stream);

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -43,6 +44,10 @@ struct PresentSlot {
     bool inFlight = false;        // a copy from dRgba8 / into host was enqueued and not yet waited for
     bool valid = false;           // host holds an image (after pt_present_wait)
     int frame = 0, rows = 0, width = 0;
+    // snapshot presents (no join between the frames' launch and the tone map): the snapshot the image was tone-mapped from, and the
+    // handle's abandon epoch at that time — if a launch was abandoned meanwhile, pt_present_wait repairs and tone-maps again
+    const void *snapSource = nullptr;
+    unsigned int snapGeneration = 0, abandonEpoch = 0;
 };
 } // namespace ptimpl
 
@@ -77,9 +82,26 @@ struct pt_renderer {
     unsigned char *dGrid = nullptr; // (kMaxCells + 1) * 2 + kMaxRefs bytes
     float *dLut = nullptr;          // 256-entry sRGB table
     unsigned int *dQueue = nullptr; // global chunk-ticket counter of the persistent kernel (never reset: epoch scheme)
-    // error word of the frame pipelining: ONE page-locked host word the kernels can reach (mapped): it is only ever
-    // written when a hand-over fails, and the host reads it without a copy once the stream is drained
+    // Hand-over bound (round 5; pt_kernel_common.hpp).  A tagged launch whose wait for a pixel's previous frame runs out of its
+    // wall-clock budget ABANDONS itself instead of folding onto a stale pixel: dAbandon (device word, ~0u = none) receives the lowest
+    // abandoned launch sequence number, hostErrWord (ONE page-locked host word the kernels can reach) is raised so that the host
+    // notices without a copy.  Every tagged launch since the last join of the handle's streams is kept in `unverified` (its kernel
+    // argument + an event behind it); a join enqueues pt_repair_kernel for each of them, in order, behind the joined streams — a no-op
+    // on the device unless dAbandon says otherwise — and forgets them; launches seen complete with hostErrWord == 0 are forgotten
+    // earlier.  Whatever the host or a later launch reads behind a join is therefore the image an undisturbed run produces.
     unsigned int *hostErrWord = nullptr, *devErrWord = nullptr;
+    unsigned int *dAbandon = nullptr;
+    unsigned int *dRepairCtl = nullptr;   // 4 words: (pixel, frame) pairs re-rendered, inconsistent pixels, joins with repairs, spare
+    unsigned int *dTileFlags = nullptr;   // FrameArgs::tileFlags: one word per 8x8 tile of the handle's rows
+    size_t tileFlagTiles = 0;
+    struct LaunchRecord { pt::FrameArgs a; hipEvent_t done; };
+    std::deque<LaunchRecord> unverified;
+    static constexpr int kLaunchEvents = 256; // ring of "launch done" events (mainDone / chainDone alias the latest ones)
+    hipEvent_t launchEvents[kLaunchEvents] = {};
+    unsigned int launchEventNext = 0;
+    unsigned int abandonEpoch = 0;        // bumped whenever the host finds hostErrWord raised (present slots remember it)
+    int overlapHoldoff = 0;               // launches that still run BEHIND their predecessor after an abandonment (a contended device)
+    unsigned int waitBudgetUnits = 0, waitCheckUnits = 0; // FrameArgs::waitBudget / waitCheckInterval for this device's wall clock
     int queueChunk = 0;             // tiles per global ticket; 0 = automatic (tuning knob queue_chunk)
     unsigned long long *dTimeline = nullptr; // tuning only (pt_debug_timeline)
     // Frame pipelining: consecutive pt_render calls are collected and launched as ONE batch kernel (see pt_integrate_persistent.hip)
@@ -159,6 +181,7 @@ struct pt_renderer {
     hipEvent_t snapRead[kSnapshots] = {nullptr, nullptr, nullptr};
     bool snapReadPending[kSnapshots] = {false, false, false};
     int snapNext = 0;
+    unsigned int snapGeneration[kSnapshots] = {0, 0, 0}; // bumped whenever a launch is told to write the buffer
     float4 *snapshotTarget = nullptr;            // set around the flush of pt_present_rgba8_async: the launch's FrameArgs::snapshot
     int snapshotIndex = -1;
     int snapFrame = -1;                          // frame counter value whose image the snapshot written last holds (-1: none)
@@ -204,9 +227,13 @@ int hip_fail(pt_handle h, hipError_t e, const char *what);
 
 int bind_device(pt_handle h);
 int flush_frames(pt_handle h);  // launch the frames pt_render deferred
-int join_stripes(pt_handle h);  // flush + make h->stream wait for every helper stream
-int check_handover(pt_handle h); // frame-pipelining error word (call after the stream has been synchronised)
-int fix_alpha(pt_handle h);      // join + restore alpha = 1 if the image still carries frame tags (before the host observes it)
+// flush + make h->stream wait for every helper stream + (repairNow) enqueue the hand-over repair passes of the launches since the last
+// join behind them.  repairNow = false is for callers that synchronise h->stream right away and then call settle_handover(): the
+// repair kernels are then only enqueued when the host-visible flag says a launch was abandoned (nothing at all on the usual path)
+int join_stripes(pt_handle h, bool repairNow = true);
+int settle_handover(pt_handle h); // h->stream synchronised after join_stripes(h, false): repair if the flag is up, forget the launches
+hipEvent_t next_launch_event(pt_handle h);
+int fix_alpha(pt_handle h, bool repairNow = true); // join + restore alpha = 1 if the image still carries frame tags (before the host observes it)
 int ensure_stripe(pt_handle h, int j); // create stripe stream j (j > 0) and its event on first use
 hipStream_t stripe_stream(pt_handle h, int j); // stripe 0 runs on the main stream
 // tone map this handle's rows into `dst` (RGBA8, compact rows) on h->stream, behind every frame rendered so far

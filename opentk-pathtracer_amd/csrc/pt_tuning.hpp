@@ -6,6 +6,7 @@
 //   Python: native.debug_set("no_sphere_grid", 1); bench.py --tune key=value; tools/handover_stress.bin --tune key=value
 #pragma once
 #include <cstring>
+#include <type_traits>
 
 namespace pt {
 
@@ -21,6 +22,8 @@ struct Tuning {
     int noSingleTagged = 0;        // 1: single frames never chain
     int shortWorkgroupsPerCU = 5;  // workgroups per CU of launches of fewer than 8 frames
     long chainWaitUs = 60000;      // back-pressure: how long a launch waits for its predecessor to become resident
+    long handoverBudgetMs = 2000;  // hand-over bound: a result that has waited this long (wall clock) for its pixel's previous frame abandons its launch
+    long handoverCheckUs = 1000;   // ... and how often a waiting wavefront looks at the abandon word and at its own waits
     // kernel selection (pt_integrate_persistent.hip: launch_integrate)
     int parkedMax = -1;            // >= 0: parked resolves per wavefront
     int noBatchPass = 0;           // 1: spp > 1 keeps the in-lane sample chain
@@ -50,7 +53,7 @@ inline bool tuning_set(const char *key, long long v)
     Tuning &t = tuning();
 #define PT_KNOB(name, field)                 \
     if (std::strcmp(key, name) == 0) {       \
-        t.field = (decltype(t.field))v;      \
+        t.field = static_cast<std::remove_reference_t<decltype(t.field)>>(v); \
         return true;                         \
     }
     PT_KNOB("drain_compaction", drainCompaction)
@@ -62,6 +65,8 @@ inline bool tuning_set(const char *key, long long v)
     PT_KNOB("no_single_tagged", noSingleTagged)
     PT_KNOB("short_wg", shortWorkgroupsPerCU)
     PT_KNOB("chain_wait_us", chainWaitUs)
+    PT_KNOB("handover_budget_ms", handoverBudgetMs)
+    PT_KNOB("handover_check_us", handoverCheckUs)
     PT_KNOB("parked_max", parkedMax)
     PT_KNOB("no_batch_pass", noBatchPass)
     PT_KNOB("batch_pass_min_tiles", batchPassMinTiles)

@@ -234,3 +234,14 @@ def debug_set(key: str, value: int) -> None:
     if rc != PT_OK:
         raise NativeError(rc, f"pt_debug_set({key!r}): unknown knob")
 
+
+
+def debug_handover_stats(handle) -> dict:
+    """Counters of the hand-over bound (csrc/pt_kernel_common.hpp) through pt_debug_handover_stats — exported, not in the public header.
+    Drains the handle.  `inconsistent` must stay 0."""
+    L = load()
+    L.pt_debug_handover_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+    L.pt_debug_handover_stats.restype = C.c_int
+    out = (C.c_uint * 4)()
+    check(L.pt_debug_handover_stats(handle, out), handle)
+    return {"pairs_repaired": int(out[0]), "inconsistent": int(out[1]), "joins_with_repairs": int(out[2]), "flag_seen": int(out[3])}

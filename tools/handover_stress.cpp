@@ -52,6 +52,7 @@ struct Api {
     const char *(*last_error)(H);
     int (*audit_read)(H, unsigned int *, int);
     int (*debug_set)(const char *, long long);
+    int (*handover_stats)(H, unsigned int *); // optional: pt_debug_handover_stats (hand-over bound: repaired pairs, inconsistent pixels, joins, flag)
 };
 
 static bool load_api(const char *path, Api &a)
@@ -75,6 +76,7 @@ static bool load_api(const char *path, Api &a)
     SYM(devptr, "pt_result_device_ptr") SYM(set_variant, "pt_set_variant") SYM(device_count, "pt_device_count")
     SYM(last_error, "pt_last_error") SYM(audit_read, "pt_debug_audit_read") SYM(debug_set, "pt_debug_set")
 #undef SYM
+    *(void **)&a.handover_stats = dlsym(so, "pt_debug_handover_stats");
     return true;
 }
 
@@ -369,6 +371,16 @@ int main(int argc, char **argv)
     H cache[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int cacheUses[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     H refHandle = nullptr;
+    // hand-over bound: what the repair passes of the handles under test did (counters are per handle and cumulative: read before a handle goes)
+    unsigned long long repairTotals[4] = {0, 0, 0, 0};
+    auto retire = [&](H &hh) {
+        if (!hh) return;
+        unsigned int st[4] = {0, 0, 0, 0};
+        if (a.handover_stats && a.handover_stats(hh, st) == 0)
+            for (int k = 0; k < 4; k++) repairTotals[k] += st[k];
+        a.destroy(hh);
+        hh = nullptr;
+    };
     for (long ci = 0; ci < cases; ci++) {
         Rng r(master.next());
         Case c = make_case(r, maxParts, withOps, multisample);
@@ -380,8 +392,7 @@ int main(int argc, char **argv)
             H &t = cache[c.parts];
             int rc = 0;
             if (t && (freshHandles || ++cacheUses[c.parts] >= 16)) {
-                a.destroy(t);
-                t = nullptr;
+                retire(t);
                 cacheUses[c.parts] = 0;
             }
             if (t) {
@@ -409,10 +420,7 @@ int main(int argc, char **argv)
                 nviol = a.audit_read(t, records.data(), 64);
                 if (nviol == -1000) nviol = 0;
             }
-            if (!ok) { // a handle that reported an error is not reused
-                a.destroy(t);
-                t = nullptr;
-            }
+            if (!ok) retire(t); // a handle that reported an error is not reused
             // ---- the comparison side: variant 1, one plain launch per frame, one device
             H &s = refHandle;
             if (!s && ref.create(devices[0], c.W, c.H, &s) != 0) { std::printf("case %ld: reference create failed\n", ci); g_failures++; continue; }
@@ -476,10 +484,12 @@ int main(int argc, char **argv)
             std::fflush(stdout);
         }
     }
-    for (H &hh : cache)
-        if (hh) a.destroy(hh);
+    for (H &hh : cache) retire(hh);
     if (refHandle) ref.destroy(refHandle);
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("hand-over bound: %llu (pixel, frame) pairs re-rendered by repair passes in %llu joins, abandon flag seen %llu times, %llu inconsistent pixels\n",
+                repairTotals[0], repairTotals[2], repairTotals[3], repairTotals[1]);
+    if (repairTotals[1] != 0) g_failures++;
     std::printf("handover_stress: lib %s seed %llu: %ld cases run, %ld frames, %ld images compared, %d failures, %ld audit violations, %.1f s\n", libPath,
                 (unsigned long long)seed, ran, framesRendered, snapsCompared, g_failures, auditViolations, el);
     return (g_failures || auditViolations) ? 1 : 0;
