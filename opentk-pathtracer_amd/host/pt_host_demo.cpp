@@ -4,7 +4,7 @@
 //   OnResize / OnUpdateFrame camera uploads (:131-132,278-279), then N x PathTracer.Render() (:49)
 // and writes the RGBA32F `Result` (raw floats, row 0 = bottom) so it can be compared with the oracle.
 //
-//   pt_host_demo render <W> <H> <frames> <out.f32> [rayDepth] [atmosphereSize]
+//   pt_host_demo render <W> <H> <frames> <out.f32> [rayDepth] [atmosphereSize] [env-out.f32 (the cube as pt_read_environment returns it)]
 //   pt_host_demo frame-loop <W> <H> <frames> <out.rgba8> <devices e.g. 0 or 0,0,0>
 //                      the frame loop of MainWindow.OnRenderFrame (:40-69) with the NON-BLOCKING present on one GPU or a group of
 //                      GPUs: Render(); PresentAsync(f % 3); PresentWait((f + 1) % 3); writes the last image shown + its frame index
@@ -53,6 +53,12 @@ int main(int argc, char **argv)
             for (int i = 0; i < frames; i++) pathTracer.Render();
             std::vector<float> img = pathTracer.Result();
             write_file(argv[5], img.data(), img.size() * sizeof(float));
+            if (argc > 8) { // the environment the frames were rendered with, read back through the C ABI
+                std::vector<float> cube((size_t)6 * atmo * atmo * 4);
+                int face = 0;
+                if (pt_read_environment(pathTracer.Handle(), cube.data(), &face) != PT_OK || face != atmo) throw std::runtime_error("pt_read_environment failed");
+                write_file(argv[8], cube.data(), cube.size() * sizeof(float));
+            }
             std::printf("rendered %dx%d, %d samples/pixel\n", W, H, pathTracer.Samples());
             return 0;
         }

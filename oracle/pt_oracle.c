@@ -211,6 +211,40 @@ typedef struct {
 
 typedef struct { uint64_t samples, bounces, sphereTests, cuboidTests, envLookups, rngDraws; } Stats;
 
+/* ---- decision margins (-DPT_ORACLE_MARGINS, _build/libpt_oracle_margins.so; tests/test_decision_margins.py).
+ * The integrator BRANCHES on computed floats: object acceptance (compute.glsl:234,247 with :269 `discriminant < 0`, :293 `t1 <= t2`,
+ * `t2 > 0`, `t1 < T`, and GetSmallestPositive's `t1 < 0`, :347-350), lobe selection (:201, :208), refract's `k < 0`, Russian roulette
+ * (:169) and the cuboid normal's step() (:322-332).  Two conforming evaluations of the same GLSL differ in the last bits of their
+ * floats — GLSL leaves the precision of /, sqrt, inversesqrt, sin, cos, exp implementation-defined — so in a small fraction of pixels
+ * one of these comparisons comes out the other way and the path is a different path.  And a path tracer AMPLIFIES: a direction that
+ * is off by delta moves the next hit point by T * delta, the normal of a sphere of radius r there by T * delta / r, and the bounce
+ * doubles that, so after a few bounces on curved surfaces last-bit differences are percent-level differences.
+ *
+ * This variant carries, next to every path, a first-order bound of its own error PER UNIT OF RELATIVE ERROR eps of the arithmetic's
+ * primitives: position error dp (world units / eps), direction error dd (1 / eps), relative throughput error dthr — started at the
+ * camera, propagated through every intersection, normal and BSDF lobe — and records per pixel and frame
+ *   margin = the smallest eps at which ONE of the path's comparisons would come out the other way: |a - b| / (error of a - b per
+ *            unit eps), over every comparison that could change the result (single-flip analysis, see trace_margins);
+ *   cont   = the absolute colour error per unit eps that the pixel suffers WITHOUT any flip (environment gradient x direction error,
+ *            radiance x throughput error).
+ * The image it renders is bit for bit the plain oracle's (tested).  With that, layer-2 parity is a per-pixel statement: a pixel that
+ * differs from the reference's own output by more than the band must have margin < TAU_FLIP or band / cont < TAU_FLIP (it is
+ * sensitive to errors of the size conforming implementations differ by), and every pixel that needs more than TAU_SAFE agrees. */
+#ifdef PT_ORACLE_MARGINS
+#define ERR_FRESH 4.0f /* error a freshly computed quantity carries, in units of eps x its magnitude (a handful of roundings) */
+static __thread float tl_margin = INFINITY, tl_cont = 0.0f;
+static __thread float tl_dp, tl_dd, tl_dthr;  /* the current ray's error bounds per unit eps (see above) */
+static __thread float tl_hit_dT, tl_hit_r;    /* set by ray_trace for the accepted hit: error of T per unit eps; sphere radius (0: cuboid) */
+static __thread float tl_dcos, tl_refr_k;     /* error of dot(direction, normal) at the current hit; refract()'s k of the current bounce */
+static __thread int tl_lobe;                  /* lobe the current bounce took: 0 diffuse, 1 specular, 2 refractive */
+static inline void margin_eps(float diff, float err)
+{
+    float m = fabsf(diff) / fmaxf(err, 1e-30f);
+    if (m < tl_margin) tl_margin = m; /* (NaN: not smaller, ignored — a NaN comparison is false on every implementation) */
+}
+static inline float fin0(float x) { return fabsf(x) < FLOAT_MAX ? fabsf(x) : 0.0f; }
+#endif
+
 /* ------------------------------------------------------------------ RNG (compute.glsl:334-344) */
 static inline uint32_t pcg_hash(uint32_t *seed)
 {
@@ -377,12 +411,113 @@ static v3 cuboid_normal(v3 mn, v3 mx, v3 p)
     n.x = f_sign(cs.x) * f_step(fabsf(fabsf(cs.x) - half.x), EPSILON);
     n.y = f_sign(cs.y) * f_step(fabsf(fabsf(cs.y) - half.y), EPSILON);
     n.z = f_sign(cs.z) * f_step(fabsf(fabsf(cs.z) - half.z), EPSILON);
+#ifdef PT_ORACLE_MARGINS
+    { /* compute.glsl:322-332: step(EPSILON, | |p - centre| - halfsize |) per axis decides which faces the normal sees (a hit point within
+         EPSILON of an edge); error = the hit point's + fresh rounding of the coordinates involved */
+        float sc_ = f_max(f_max(fabsf(p.x), fabsf(p.y)), fabsf(p.z));
+        sc_ = f_max(sc_, f_max(f_max(fabsf(mx.x), fabsf(mx.y)), fabsf(mx.z)));
+        sc_ = f_max(sc_, f_max(f_max(fabsf(mn.x), fabsf(mn.y)), fabsf(mn.z)));
+        const float e_ = tl_dp + ERR_FRESH * sc_; /* (the caller has put the hit point's error into tl_dp) */
+        margin_eps(fabsf(fabsf(cs.x) - half.x) - EPSILON, e_);
+        margin_eps(fabsf(fabsf(cs.y) - half.y) - EPSILON, e_);
+        margin_eps(fabsf(fabsf(cs.z) - half.z) - EPSILON, e_);
+    }
+#endif
     return v_normalize(n);
 }
 
 typedef struct {
     float T; int fromInside; v3 nearHitPos, normal; Material m;
 } HitInfo;
+
+#ifdef PT_ORACLE_MARGINS
+/* Margins of RayTrace's acceptance chains (compute.glsl:234,247: `Intersect(...) && t2 > 0 && t1 < T`, with :269 `discriminant < 0`,
+ * :293 `t1 <= t2`, and GetSmallestPositive's `t1 < 0`, :347-350), as a SINGLE-FLIP analysis: which one comparison, coming out the
+ * other way, changes the object the ray hits or the distance?
+ *   - the winner's own chain, against the T it was compared with;
+ *   - any other object of which exactly ONE condition fails when T is the final distance: that flip would make it the hit (this
+ *     includes the second-nearest candidate's `t1 < T`);
+ *   - when some accepted object CONTAINS the origin the reference's rule depends on the visiting order (the entry-distance quirk); then
+ *     every object's chain is counted against the running T at its turn (a superset of the relevant flips).
+ * A negative discriminant is treated as a grazing hit (square root 0).  Errors per unit eps, with e(t) = dp + |t| dd the ray's
+ * sideways displacement at parameter t: sphere — discriminant r^2 - dperp^2: 2 dperp e(|b|) + fresh; b: |oc| dd + dp + fresh; a root
+ * -b -+ sqrt(disc): error of b + error of disc / (2 sqrt(disc)); cuboid — a slab distance (m - o) / d along an axis:
+ * (dp + fresh) / |d| + |t| dd / |d|, the worst axis that is not parallel to the ray. */
+typedef struct { int d1, d2, d3, isSphere; float u1, u2, du, disc, ddisc; } Chain;
+static Chain chain_sphere(v3 o, v3 d, const float *s)
+{
+    Chain k;
+    v3 oc = v_sub(o, V(s[0], s[1], s[2]));
+    float b = v_dot(d, oc), oo = v_dot(oc, oc), c = fmaf(-s[3], s[3], oo);
+    k.disc = fmaf(b, b, -c);
+    float sq = pt_sqrt(f_max(k.disc, 0.0f));
+    k.u1 = -b - sq; k.u2 = -b + sq;
+    const float e = tl_dp + fabsf(b) * tl_dd;
+    const float dperp = sqrtf(f_max(oo - b * b, 0.0f));
+    k.ddisc = 2.0f * dperp * e + ERR_FRESH * f_max(b * b, f_max(oo, s[3] * s[3]));
+    const float db = sqrtf(oo) * tl_dd + tl_dp + ERR_FRESH * fabsf(b);
+    k.du = db + k.ddisc / (2.0f * f_max(sq, 1e-20f)) + ERR_FRESH * f_max(fabsf(b), sq);
+    k.d1 = !(k.disc < 0.0f); k.d2 = 1; k.d3 = k.u2 > 0.0f; k.isSphere = 1;
+    return k;
+}
+static Chain chain_cuboid(v3 o, v3 d, v3 invd, const float *q)
+{
+    Chain k;
+    (void)d;
+    k.d2 = ray_cuboid(o, d, invd, V(q[0], q[1], q[2]), V(q[4], q[5], q[6]), &k.u1, &k.u2);
+    const float tmax = f_max(fin0(k.u1), fin0(k.u2));
+    const float oa[3] = { o.x, o.y, o.z }, ia[3] = { invd.x, invd.y, invd.z };
+    float du = 0.0f;
+    for (int a = 0; a < 3; a++) {
+        const float iv = fabsf(ia[a]);
+        if (!(iv < 1e18f)) continue; /* (an axis the ray is parallel to has infinite slab distances that never decide anything) */
+        const float m = f_max(f_max(fabsf(q[a]), fabsf(q[4 + a])), fabsf(oa[a]));
+        du = f_max(du, (tl_dp + ERR_FRESH * m) * iv + tmax * (tl_dd * iv + ERR_FRESH));
+    }
+    k.du = du; k.d1 = 1; k.d3 = k.u2 > 0.0f; k.isSphere = 0; k.disc = 1.0f; k.ddisc = 1.0f;
+    return k;
+}
+/* the chain's comparisons against distance T (error dT): asWinner = all of them (they all hold), else the single failing one */
+static void chain_margins(const Chain *k, float T, float dT, int asWinner)
+{
+    const int d4 = k->u1 < T;
+    const int fails = !k->d1 + !k->d2 + !k->d3 + !d4;
+    if (asWinner ? fails != 0 : fails != 1) return;
+    if (k->isSphere && (asWinner || !k->d1)) margin_eps(k->disc, k->ddisc);
+    if (!k->isSphere && (asWinner || !k->d2)) margin_eps(k->u2 - k->u1, 2.0f * k->du);
+    if (asWinner || !k->d3) margin_eps(k->u2, k->du);
+    if ((asWinner || !d4) && T != FLOAT_MAX) margin_eps(k->u1 - T, k->du + dT);
+    if (asWinner) margin_eps(k->u1, k->du); /* GetSmallestPositive: entry or exit distance */
+}
+static void trace_margins(const Ctx *c, v3 o, v3 d, v3 invd, int winner, int prevWinner, float Tfinal, float TbeforeWinner, int anyInside)
+{
+    const float *ob = c->objects;
+    Chain ch[320];
+    const int ns = c->numSpheres, nc = c->numCuboids;
+    for (int i = 0; i < ns; i++) ch[i] = chain_sphere(o, d, ob + (size_t)i * SPHERE_STRIDE);
+    for (int i = 0; i < nc; i++) ch[256 + i] = chain_cuboid(o, d, invd, ob + CUBOIDS_OFFSET + (size_t)i * CUBOID_STRIDE);
+    tl_hit_dT = winner >= 0 ? ch[winner].du : 0.0f;
+    if (anyInside) {
+        float T = FLOAT_MAX, dT = 0.0f; /* running distance and its error: the order-dependent case */
+        for (int pass = 0; pass < 2; pass++)
+            for (int i = 0; i < (pass ? nc : ns); i++) {
+                const Chain *k = &ch[pass ? 256 + i : i];
+                const int d4 = k->u1 < T, fails = !k->d1 + !k->d2 + !k->d3 + !d4;
+                if (fails == 0) chain_margins(k, T, dT, 1);
+                else if (fails == 1) chain_margins(k, T, dT, 0);
+                if (fails == 0) { T = k->u1 < 0.0f ? k->u2 : k->u1; dT = k->du; }
+            }
+        return;
+    }
+    const float dTfinal = winner >= 0 ? ch[winner].du : 0.0f, dTbefore = prevWinner >= 0 ? ch[prevWinner].du : 0.0f;
+    for (int pass = 0; pass < 2; pass++)
+        for (int i = 0; i < (pass ? nc : ns); i++) {
+            const int id = pass ? 256 + i : i;
+            if (id == winner) chain_margins(&ch[id], TbeforeWinner, dTbefore, 1);
+            else chain_margins(&ch[id], Tfinal, dTfinal, 0);
+        }
+}
+#endif
 
 /* compute.glsl:226-258 RayTrace.  The acceptance test uses the ENTRY distance t1 against the stored
  * GetSmallestPositive(t1,t2) (compute.glsl:234,247,347-350): an object that contains the origin (t1<0) always
@@ -393,9 +528,18 @@ static int ray_trace(const Ctx *c, v3 o, v3 d, HitInfo *h, Stats *st)
     float T = FLOAT_MAX, t1, t2, wt2 = 0.0f;
     int winner = -1;
     const float *ob = c->objects;
+#ifdef PT_ORACLE_MARGINS
+    float Tbefore = FLOAT_MAX; /* the T the final winner was compared with ... */
+    int prevWinner = -1;       /* ... and the object that had set it */
+    int anyInside = 0;         /* an accepted object contained the origin */
+#define NOTE_ACCEPT() do { Tbefore = T; prevWinner = winner; anyInside |= t1 < 0.0f; } while (0)
+#else
+#define NOTE_ACCEPT() ((void)0)
+#endif
     for (int i = 0; i < c->numSpheres; i++) {
         const float *s = ob + (size_t)i * SPHERE_STRIDE;
         if (ray_sphere(o, d, V(s[0], s[1], s[2]), s[3], &t1, &t2) && t2 > 0.0f && t1 < T) {
+            NOTE_ACCEPT();
             T = t1 < 0.0f ? t2 : t1;
             wt2 = t2;
             winner = i;
@@ -405,11 +549,18 @@ static int ray_trace(const Ctx *c, v3 o, v3 d, HitInfo *h, Stats *st)
     for (int i = 0; i < c->numCuboids; i++) {
         const float *q = ob + CUBOIDS_OFFSET + (size_t)i * CUBOID_STRIDE;
         if (ray_cuboid(o, d, invd, V(q[0], q[1], q[2]), V(q[4], q[5], q[6]), &t1, &t2) && t2 > 0.0f && t1 < T) {
+            NOTE_ACCEPT();
             T = t1 < 0.0f ? t2 : t1;
             wt2 = t2;
             winner = 256 + i;
         }
     }
+#undef NOTE_ACCEPT
+#ifdef PT_ORACLE_MARGINS
+    trace_margins(c, o, d, invd, winner, prevWinner, T, Tbefore, anyInside);
+    tl_hit_r = (winner >= 0 && winner < 256) ? fabsf(ob[(size_t)winner * SPHERE_STRIDE + 3]) : 0.0f;
+    if (winner >= 0 && T != FLOAT_MAX) tl_dp = tl_dp + T * tl_dd + tl_hit_dT; /* from here on: the error of the hit point (o + d T) */
+#endif
     if (st) { st->sphereTests += (uint64_t)c->numSpheres; st->cuboidTests += (uint64_t)c->numCuboids; }
     if (winner < 0 || !(T != FLOAT_MAX)) return 0; /* compute.glsl:257 */
     h->T = T;
@@ -454,6 +605,12 @@ static v3 f_refract(v3 i, v3 n, float eta)
 {
     float ni = v_dot(n, i);
     float k = fmaf(-(eta * eta), fmaf(-ni, ni, 1.0f), 1.0f);
+#ifdef PT_ORACLE_MARGINS
+    /* GLSL refract(): k < 0 = total internal reflection.  k = 1 - eta^2 (1 - (n.i)^2): error 2 eta^2 |n.i| x (error of n.i) + fresh;
+       the caller keeps the error of n.i (direction error + normal error) in tl_dthr's neighbour tl_dcos */
+    margin_eps(k, 2.0f * eta * eta * fabsf(ni) * tl_dcos + ERR_FRESH * f_max(1.0f, eta * eta));
+    tl_refr_k = k;
+#endif
     if (k < 0.0f) return V(0.0f, 0.0f, 0.0f);
     float f = fmaf(eta, ni, pt_sqrt(k));
     return V(fmaf(eta, i.x, -(f * n.x)), fmaf(eta, i.y, -(f * n.y)), fmaf(eta, i.z, -(f * n.z)));
@@ -473,6 +630,22 @@ static float bsdf(v3 *ro, v3 *rd, const HitInfo *h, int *isRefractive, uint32_t 
     v3 diffuseRay = cosine_sample_hemisphere(h->normal, seed);
     float prob;
     float roll = rand01(seed);
+#ifdef PT_ORACLE_MARGINS
+    /* compute.glsl:201,208.  The roll is exact (integer hash); spec carries the Fresnel term's error when the material is specular:
+       F = r0 + (1 - r0)(1 - cos)^5 -> at most 5 x the error of cos.  (A material with neither lobe takes the third branch whatever the roll.) */
+    float dspec_ = ERR_FRESH + (h->m.specularChance > 0.0f ? 5.0f * tl_dcos : 0.0f);
+    if (spec > 0.0f || refr > 0.0f) {
+        margin_eps(spec - roll, dspec_);
+        if (!(spec > roll)) margin_eps(spec + refr - roll, dspec_ + ERR_FRESH);
+    }
+    tl_lobe = spec > roll ? 1 : (spec + refr > roll ? 2 : 0);
+    tl_refr_k = 1.0f;
+    /* the chosen lobe's probability divides the throughput (compute.glsl:164): its relative error */
+    {
+        const float prob_ = f_max(tl_lobe == 1 ? spec : tl_lobe == 2 ? refr : 1.0f - spec - refr, EPSILON);
+        tl_dthr += (h->m.specularChance > 0.0f ? dspec_ / prob_ : 0.0f) + ERR_FRESH;
+    }
+#endif
     if (spec > roll) {
         v3 refl = f_reflect(*rd, h->normal);
         *rd = v_normalize(v_mix(refl, diffuseRay, h->m.specularRoughness * h->m.specularRoughness));
@@ -505,18 +678,66 @@ static v3 radiance(const Ctx *c, v3 ro, v3 rd, uint32_t *seed, Stats *st)
                 throughput.y *= f_exp(-h.m.absorbance.y * h.T);
                 throughput.z *= f_exp(-h.m.absorbance.z * h.T);
             }
+#ifdef PT_ORACLE_MARGINS
+            /* (ray_trace left the hit point's error in tl_dp and the error of T in tl_hit_dT.)  Normal: a sphere's is (p - c) / r, a
+               cuboid's is constant on a face.  Beer's law: exp(-a T).  dot(direction, normal): both errors. */
+            const float dn_ = tl_hit_r > 0.0f ? tl_dp / tl_hit_r + ERR_FRESH : ERR_FRESH;
+            if (h.fromInside) tl_dthr += f_max(h.m.absorbance.x, f_max(h.m.absorbance.y, h.m.absorbance.z)) * tl_hit_dT + ERR_FRESH;
+            tl_dcos = tl_dd + dn_;
+#endif
             int isRefractive;
             float prob = bsdf(&ro, &rd, &h, &isRefractive, seed);
+#ifdef PT_ORACLE_MARGINS
+            /* the new ray: a diffuse direction depends on the normal only; a reflection doubles the normal's error and keeps the
+               incoming one; a refraction does the same and blows up towards the critical angle (1 / sqrt(k)); roughness mixes in the
+               diffuse direction (bounded by the same).  New origin = hit point + EPSILON x direction. */
+            {
+                float dd_;
+                if (tl_lobe == 0) dd_ = dn_ + ERR_FRESH;
+                else if (tl_lobe == 1) dd_ = tl_dd + 2.0f * dn_ + ERR_FRESH;
+                else dd_ = (tl_dd + 2.0f * dn_) * (1.0f + 2.0f / sqrtf(f_max(tl_refr_k, 1e-12f))) + ERR_FRESH;
+                tl_dd = dd_;
+                tl_dp = tl_dp + EPSILON * dd_ + ERR_FRESH * f_max(f_max(fabsf(ro.x), fabsf(ro.y)), f_max(fabsf(ro.z), 1.0f));
+                /* emissive hit: radiance += emissiv x throughput (its relative error so far) */
+                const float em_ = f_max(h.m.emissiv.x * throughput.x, f_max(h.m.emissiv.y * throughput.y, h.m.emissiv.z * throughput.z));
+                tl_cont += em_ * tl_dthr;
+            }
+#endif
             rad = V(fmaf(h.m.emissiv.x, throughput.x, rad.x), fmaf(h.m.emissiv.y, throughput.y, rad.y),
                     fmaf(h.m.emissiv.z, throughput.z, rad.z));
             if (!isRefractive) throughput = v_mul(throughput, h.m.albedo);
             throughput = v_scale(throughput, f_rcp(prob));
             float p = f_max(throughput.x, f_max(throughput.y, throughput.z));
+#ifdef PT_ORACLE_MARGINS
+            {
+                uint32_t peek = *seed;
+                float roll_ = rand01(&peek);
+                if (i + 1 < c->rayDepth) margin_eps(roll_ - p, p * tl_dthr + ERR_FRESH * p); /* compute.glsl:169 (after the last bounce the outcome no longer matters) */
+            }
+#endif
             if (rand01(seed) > p) break;
             throughput = v_scale(throughput, f_rcp(p));
         } else {
             rgb e = sample_env(c, rd);
             if (st) st->envLookups++;
+#ifdef PT_ORACLE_MARGINS
+            { /* no flip, still an error: the environment's change over the direction's error (finite differences along two tangents,
+                 1e-3 rad) and the throughput's relative error — absolute colour error per unit eps, summed over the pixel's paths */
+                v3 t1_ = fabsf(rd.x) < 0.9f ? V(1.0f, 0.0f, 0.0f) : V(0.0f, 1.0f, 0.0f);
+                v3 ta = v_normalize(V(rd.y * t1_.z - rd.z * t1_.y, rd.z * t1_.x - rd.x * t1_.z, rd.x * t1_.y - rd.y * t1_.x));
+                v3 tb = V(rd.y * ta.z - rd.z * ta.y, rd.z * ta.x - rd.x * ta.z, rd.x * ta.y - rd.y * ta.x);
+                const float hstep = 1e-3f;
+                rgb ea = sample_env(c, v_normalize(v_fma(ta, hstep, rd))), eb = sample_env(c, v_normalize(v_fma(tb, hstep, rd)));
+                float worst = 0.0f;
+                const float er[3] = { e.r, e.g, e.b }, ear[3] = { ea.r, ea.g, ea.b }, ebr[3] = { eb.r, eb.g, eb.b }, th[3] = { throughput.x, throughput.y, throughput.z };
+                for (int ch = 0; ch < 3; ch++) {
+                    const float grad = (fabsf(ear[ch] - er[ch]) + fabsf(ebr[ch] - er[ch])) / hstep;
+                    const float err = fabsf(th[ch]) * (grad * tl_dd + fabsf(er[ch]) * (tl_dthr + ERR_FRESH));
+                    if (err > worst) worst = err;
+                }
+                tl_cont += worst;
+            }
+#endif
             rad = V(fmaf(e.r, throughput.x, rad.x), fmaf(e.g, throughput.y, rad.y), fmaf(e.b, throughput.z, rad.z));
             break;
         }
@@ -557,6 +778,12 @@ static void shade_pixel(const Ctx *c, int px, int py, int frame, const float *la
         mat_vec(c->invView, ox, oy, 0.0f, 1.0f, org); /* :120 */
         v3 ro = V(org[0], org[1], org[2]);
         v3 rd = v_normalize(v_sub(focal, ro));
+#ifdef PT_ORACLE_MARGINS
+        /* the primary ray's own error: a few roundings of two matrix products, a normalisation, the lens sample's sin / cos */
+        tl_dd = 2.0f * ERR_FRESH;
+        tl_dp = 2.0f * ERR_FRESH * f_max(f_max(fabsf(ro.x), fabsf(ro.y)), f_max(fabsf(ro.z), 1.0f));
+        tl_dthr = 0.0f;
+#endif
         if (st) st->samples++;
         irr = v_add(irr, radiance(c, ro, rd, &seed, st));
     }
@@ -623,6 +850,8 @@ static void make_ctx(Ctx *c, const PtoParams *p, const float *basic, const float
 
 typedef struct {
     const Ctx *c; float *image; int y0, rows, frame, wantStats;
+    float *margins;              /* optional (PT_ORACLE_MARGINS builds): rows x width x 2: the frame's smallest decision margin per pixel (the
+                                    eps that flips a comparison), and its flip-free colour error per unit eps */
     int nextChunk;               /* atomic: next chunk of PTO_CHUNK_ROWS rows to hand out */
     Stats st[PTO_MAX_THREADS];   /* per participant (slot 0 = the calling thread) */
 } FrameJob;
@@ -640,8 +869,18 @@ static void render_chunks(FrameJob *j, int slot)
             float *row = j->image + (size_t)r * c->width * 4;
             for (int x = 0; x < c->width; x++) {
                 float out[4];
+#ifdef PT_ORACLE_MARGINS
+                tl_margin = INFINITY;
+                tl_cont = 0.0f;
+#endif
                 shade_pixel(c, x, y, j->frame, row + 4 * x, out, j->wantStats ? &j->st[slot] : NULL);
                 memcpy(row + 4 * x, out, 16);
+#ifdef PT_ORACLE_MARGINS
+                if (j->margins) {
+                    j->margins[2 * ((size_t)r * c->width + x)] = tl_margin;
+                    j->margins[2 * ((size_t)r * c->width + x) + 1] = tl_cont / (float)c->spp;
+                }
+#endif
             }
         }
     }
@@ -682,6 +921,7 @@ static void *pool_worker(void *arg)
  * accumulating onto its current contents exactly like one PathTracer.Render() call (PathTracer.cs:114-123).
  * stats (optional, 6 x uint64): samples, bounces, sphereTests, cuboidTests, envLookups, reserved.
  * Not re-entrant (one frame at a time per process: the pool is shared); the callers are single-threaded test / bench code. */
+static float *g_next_margins = NULL; /* handed to the next pto_render_frame by pto_render_frame_margins (single-threaded callers) */
 PTO_API int pto_render_frame(const PtoParams *p, const float *basic144, const float *objects26624, const void *env,
                              float *image, int y0, int rows, int frame, int nthreads, uint64_t *stats)
 {
@@ -696,6 +936,8 @@ PTO_API int pto_render_frame(const PtoParams *p, const float *basic144, const fl
     pthread_mutex_lock(&serial);
     memset(&job, 0, sizeof job);
     job.c = &c; job.image = image; job.y0 = y0; job.rows = rows; job.frame = frame; job.wantStats = stats != NULL;
+    job.margins = g_next_margins;
+    g_next_margins = NULL;
     int helpers = nthreads - 1;
     pthread_mutex_lock(&g_pool.mu);
     while (g_pool.created < helpers) { /* grow the pool; a thread that cannot be created (EAGAIN) just means fewer helpers */
@@ -725,14 +967,46 @@ PTO_API int pto_render_frame(const PtoParams *p, const float *basic144, const fl
     return 0;
 }
 
-/* Evaluate `n` listed pixels of frame `frame` starting from `last` (n x 4 floats; pass zeros for frame 0). */
-PTO_API int pto_render_pixels(const PtoParams *p, const float *basic144, const float *objects26624, const void *env,
-                              const int *xy, int n, int frame, const float *last, float *out)
+/* Decision margins (see "decision margins" above): pto_render_frame + margins[rows * width * 2] = per pixel (the smallest relative
+ * error eps of the arithmetic's primitives that flips one of the frame's data-dependent comparisons (+inf: none), the absolute colour
+ * error per unit eps without a flip).  Returns -1 in builds without -DPT_ORACLE_MARGINS. */
+PTO_API int pto_render_frame_margins(const PtoParams *p, const float *basic144, const float *objects26624, const void *env,
+                                     float *image, int y0, int rows, int frame, int nthreads, float *margins)
+{
+#ifdef PT_ORACLE_MARGINS
+    g_next_margins = margins;
+    return pto_render_frame(p, basic144, objects26624, env, image, y0, rows, frame, nthreads, NULL);
+#else
+    (void)p; (void)basic144; (void)objects26624; (void)env; (void)image; (void)y0; (void)rows; (void)frame; (void)nthreads; (void)margins;
+    return -1;
+#endif
+}
+
+/* Evaluate `n` listed pixels of frame `frame` starting from `last` (n x 4 floats; pass zeros for frame 0).  margins (optional,
+ * PT_ORACLE_MARGINS builds): n x 2 floats, each pixel's (smallest decision margin, flip-free colour error per unit eps) of this frame. */
+PTO_API int pto_render_pixels_margins(const PtoParams *p, const float *basic144, const float *objects26624, const void *env,
+                                      const int *xy, int n, int frame, const float *last, float *out, float *margins)
 {
     Ctx c;
     make_ctx(&c, p, basic144, objects26624, env);
-    for (int i = 0; i < n; i++) shade_pixel(&c, xy[2 * i], xy[2 * i + 1], frame, last + 4 * i, out + 4 * i, NULL);
+    for (int i = 0; i < n; i++) {
+#ifdef PT_ORACLE_MARGINS
+        tl_margin = INFINITY;
+        tl_cont = 0.0f;
+#endif
+        shade_pixel(&c, xy[2 * i], xy[2 * i + 1], frame, last + 4 * i, out + 4 * i, NULL);
+#ifdef PT_ORACLE_MARGINS
+        if (margins) { margins[2 * i] = tl_margin; margins[2 * i + 1] = tl_cont / (float)c.spp; }
+#else
+        if (margins) { margins[2 * i] = INFINITY; margins[2 * i + 1] = 0.0f; }
+#endif
+    }
     return 0;
+}
+PTO_API int pto_render_pixels(const PtoParams *p, const float *basic144, const float *objects26624, const void *env,
+                              const int *xy, int n, int frame, const float *last, float *out)
+{
+    return pto_render_pixels_margins(p, basic144, objects26624, env, xy, n, frame, last, out, NULL);
 }
 
 /* Per-pixel bounce counts of one frame (diagnostics for the divergence study in DESIGN.md): counts[y*W+x] = number

@@ -16,11 +16,12 @@ LIB_PATH = os.path.join(HERE, "_build", "libpt_oracle.so")
 LIB_TRUEDIV_PATH = os.path.join(HERE, "_build", "libpt_oracle_truediv.so")
 LIB_EXACT_PATH = os.path.join(HERE, "_build", "libpt_oracle_exact.so")  # fidelity study: IEEE 1/x, sqrt, 1/sqrt, a/b
 LIB_NANMARK_PATH = os.path.join(HERE, "_build", "libpt_oracle_nanmark.so")  # diagnostic: env lookups with a NaN direction return 1000
+LIB_MARGINS_PATH = os.path.join(HERE, "_build", "libpt_oracle_margins.so")  # decision margins per pixel (tests/test_decision_margins.py)
 
 
 def build(force: bool = False) -> None:
     src = os.path.join(HERE, "pt_oracle.c")
-    libs = (LIB_PATH, LIB_TRUEDIV_PATH, LIB_EXACT_PATH, LIB_NANMARK_PATH)
+    libs = (LIB_PATH, LIB_TRUEDIV_PATH, LIB_EXACT_PATH, LIB_NANMARK_PATH, LIB_MARGINS_PATH)
     stale = not all(os.path.exists(p) for p in libs) or min(os.path.getmtime(p) for p in libs) < os.path.getmtime(src)
     if force or stale:
         subprocess.run(["make", "-C", HERE, "-B" if force else "-s", "all"], check=True, capture_output=True)
@@ -40,10 +41,14 @@ def _ptr(a, t=_fp):
 
 
 class Oracle:
-    def __init__(self, true_division: bool = False, exact: bool = False, mark_nan_env: bool = False):
+    def __init__(self, true_division: bool = False, exact: bool = False, mark_nan_env: bool = False, margins: bool = False):
         build()
-        self.lib = C.CDLL(LIB_NANMARK_PATH if mark_nan_env else LIB_EXACT_PATH if exact else (LIB_TRUEDIV_PATH if true_division else LIB_PATH))
+        self.lib = C.CDLL(LIB_MARGINS_PATH if margins else LIB_NANMARK_PATH if mark_nan_env else LIB_EXACT_PATH if exact else (LIB_TRUEDIV_PATH if true_division else LIB_PATH))
         L = self.lib
+        L.pto_render_frame_margins.restype = C.c_int
+        L.pto_render_frame_margins.argtypes = [C.POINTER(PtoParams), _fp, _fp, C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+        L.pto_render_pixels_margins.restype = C.c_int
+        L.pto_render_pixels_margins.argtypes = [C.POINTER(PtoParams), _fp, _fp, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, _fp, _fp, _fp]
         L.pto_render_frame.restype = C.c_int
         L.pto_render_frame.argtypes = [C.POINTER(PtoParams), _fp, _fp, C.c_void_p, _fp, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.POINTER(C.c_uint64)]
@@ -123,6 +128,46 @@ class Oracle:
             keys = ["samples", "bounces", "sphere_tests", "cuboid_tests", "env_lookups", "reserved"]
             return out, {k: int(v) for k, v in zip(keys, total)}
         return out
+
+    def render_with_margins(self, width, height, basic_ubo, objects_ubo, env_faces, *, num_spheres, num_cuboids, ray_depth, spp=1,
+                            focal_length=20.0, aperture=0.14, num_frames=1, threads=None, dump_each=False):
+        """Oracle(margins=True) only: frames [0, num_frames) accumulated from zero -> (image (H, W, 4), margin (H, W), cont (H, W)):
+        per pixel the smallest relative error eps of the arithmetic's primitives that flips one of the data-dependent comparisons of
+        any frame so far, and the largest flip-free absolute colour error per unit eps of any frame so far (pt_oracle.c,
+        PT_ORACLE_MARGINS); with dump_each all three per frame."""
+        basic, objs, env = self._inputs(basic_ubo, objects_ubo, env_faces)
+        p = self._params(width, height, num_spheres, num_cuboids, ray_depth, spp, focal_length, aperture, env)
+        threads = threads or os.cpu_count() or 1
+        img = np.zeros((height, width, 4), dtype=np.float32)
+        cum = np.full((height, width), np.inf, dtype=np.float32)
+        cont = np.zeros((height, width), dtype=np.float32)
+        m = np.empty((height, width, 2), dtype=np.float32)
+        imgs, margins, conts = [], [], []
+        for f in range(num_frames):
+            rc = self.lib.pto_render_frame_margins(C.byref(p), _ptr(basic), _ptr(objs), env.ctypes.data_as(C.c_void_p), _ptr(img), 0, height, f,
+                                                   threads, _ptr(m))
+            assert rc == 0, "this oracle build records no margins (Oracle(margins=True))"
+            cum = np.minimum(cum, m[..., 0])
+            cont = np.maximum(cont, m[..., 1])
+            if dump_each:
+                imgs.append(img.copy())
+                margins.append(cum.copy())
+                conts.append(cont.copy())
+        return (np.stack(imgs), np.stack(margins), np.stack(conts)) if dump_each else (img, cum, cont)
+
+    def render_pixels_margins(self, width, height, basic_ubo, objects_ubo, env_faces, xy, *, num_spheres, num_cuboids,
+                              ray_depth, spp=1, focal_length=20.0, aperture=0.14, frame=0, last=None):
+        """render_pixels + the listed pixels' (margin, cont) of this frame (Oracle(margins=True)): (n, 4), (n,), (n,)."""
+        basic, objs, env = self._inputs(basic_ubo, objects_ubo, env_faces)
+        p = self._params(width, height, num_spheres, num_cuboids, ray_depth, spp, focal_length, aperture, env)
+        xy = np.ascontiguousarray(xy, dtype=np.int32)
+        n = xy.shape[0]
+        last = np.zeros((n, 4), np.float32) if last is None else np.ascontiguousarray(last, np.float32)
+        out = np.zeros((n, 4), dtype=np.float32)
+        m = np.zeros((n, 2), dtype=np.float32)
+        self.lib.pto_render_pixels_margins(C.byref(p), _ptr(basic), _ptr(objs), env.ctypes.data_as(C.c_void_p),
+                                           xy.ctypes.data_as(C.POINTER(C.c_int)), n, frame, _ptr(last), _ptr(out), _ptr(m))
+        return out, m[:, 0].copy(), m[:, 1].copy()
 
     def render_pixels(self, width, height, basic_ubo, objects_ubo, env_faces, xy, *, num_spheres, num_cuboids,
                       ray_depth, spp=1, focal_length=20.0, aperture=0.14, frame=0, last=None):
