@@ -144,9 +144,14 @@ PT_API int pt_set_environment(pt_handle h, int face_size, int format, const void
  * (uploads and parameter changes apply to LATER frames only, exactly as with one launch per call; every read,
  * pt_synchronize and pt_timer_* first launch what is pending).  The image is bit-identical either way.
  * Back-pressure: consecutive launches overlap on two internal streams (the second moves into the wavefront slots the first one's
- * drain frees), which needs the first one resident; a host that is more than two launches ahead of the GPU is therefore held in
- * pt_render until the launch before last has left the machine (bounded; like a full command queue).  A single frame is launched
- * that way too whenever the GPU still runs the previous one. */
+ * drain frees), which needs the first one resident.  pt_render does not wait for that: a full batch whose predecessor is not resident
+ * yet simply stays pending (the GPU has two launches queued, nothing idles) and is launched by a later call; only a host that runs
+ * more than 16 launches ahead is held, for at most 2 ms per call.  Calls that block anyway (pt_synchronize, reads, presents) launch
+ * what is pending and may wait for residency in between.  A single frame is launched that way too whenever the GPU still runs the
+ * previous one.
+ * pt_render cannot fail for a reason of the frame pipelining (PathTracer.cs:114-123 cannot either): a launch whose hand-over of a
+ * pixel between two frames does not complete in time (a GPU shared with other work) abandons itself instead of producing a wrong
+ * pixel, and the library re-renders exactly what is missing behind it before anything can observe the image. */
 PT_API int pt_render(pt_handle h, int *out_total_samples);
 /* Largest number of frames one launch may pipeline (1..64; 0 = back to automatic).  1 = every pt_render launches at once (lowest
  * latency for a host that never calls anything else between frames, e.g. one that presents through interop).  A handle on which this

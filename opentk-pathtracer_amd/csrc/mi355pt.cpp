@@ -179,7 +179,17 @@ int ensure_accum(pt_handle h)
         PT_HIP(h, hipMalloc((void **)&h->dAccum, need * sizeof(float4)));
         h->accumCapacity = need;
     }
-    // FrameArgs::tileFlags: sized with the image so that pt_render never allocates
+    // cached tile masks (FrameArgs::tileMasks) and FrameArgs::tileFlags: sized with the image so that pt_render never allocates or synchronises
+    if ((size_t)((h->width + 7) / 8) * (size_t)((h->rows + 7) / 8) > h->tileMaskTiles) {
+        const size_t tiles = (size_t)((h->width + 7) / 8) * (size_t)((h->rows + 7) / 8);
+        PT_HIP(h, hipStreamSynchronize(h->stream)); // (callers have joined the handle's streams: nothing reads the old buffer any more)
+        if (h->dTileMasks) PT_HIP(h, hipFree(h->dTileMasks));
+        h->dTileMasks = nullptr;
+        h->tileMaskTiles = 0;
+        h->tileMasksValid = false;
+        PT_HIP(h, hipMalloc((void **)&h->dTileMasks, tiles * pt::kTileMaskWords * sizeof(unsigned long long)));
+        h->tileMaskTiles = tiles;
+    }
     const size_t flagTiles = (size_t)((h->width + 7) / 8) * (size_t)((h->rows + 7) / 8);
     if (flagTiles > h->tileFlagTiles) {
         PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -410,6 +420,7 @@ PT_API int pt_set_size(pt_handle h, int width, int height)
     h->bandRows = 0;
     h->frame = 0; // PathTracer.cs:133
     h->tileMasksValid = false;
+    h->launchesSinceInputChange = 0;
     if (int rc = ensure_accum(h)) return rc;
     return clear_accum(h);
 }
@@ -427,6 +438,7 @@ PT_API int pt_set_tile(pt_handle h, int y0, int rows)
     h->bandRows = 0;
     h->frame = 0;
     h->tileMasksValid = false;
+    h->launchesSinceInputChange = 0;
     if (int rc = ensure_accum(h)) return rc;
     return clear_accum(h);
 }
@@ -454,6 +466,7 @@ PT_API int pt_set_interleaved_tile(pt_handle h, int rank, int world, int band_ro
     h->bandRank = rank;
     h->frame = 0;
     h->tileMasksValid = false;
+    h->launchesSinceInputChange = 0;
     if (int rc = ensure_accum(h)) return rc;
     return clear_accum(h);
 }
@@ -576,7 +589,9 @@ bool gpu_busy(pt_handle h);
 
 // Launch frames [firstFrame, firstFrame + n) with the handle's current inputs.  n == 1: the striped frame; n > 1: one
 // batch kernel on the main stream (pt_integrate_persistent.hip, frame pipelining).
-int launch_frames(pt_handle h, int firstFrame, int n)
+// waitUs: how long the call may wait for the predecessor launch to become resident (back-pressure of launch chaining, see below);
+// lastOfFlush: this launch holds the newest pending frame (only it may store alpha = 1 last / write a present snapshot).
+int launch_frames(pt_handle h, int firstFrame, int n, long waitUs, bool lastOfFlush)
 {
     if (int rc = bind_device(h)) return rc;
     if (!h->snapshotTarget) h->snapFrame = -1; // frames rendered without a present snapshot: an older snapshot no longer shows the image
@@ -719,7 +734,8 @@ int launch_frames(pt_handle h, int firstFrame, int n)
         a.audit = h->dAudit;
         a.snapshot = h->snapshotTarget;
         a.tilesY = (h->rows + 7) / 8;
-        a.keepTags = h->flushFinal ? 0 : 1;
+        a.keepTags = (h->flushFinal && lastOfFlush) ? 0 : 1;
+        if (!lastOfFlush) a.snapshot = nullptr; // (the snapshot shows the flush's LAST frame)
         // Cached tile masks (the tile pass of the spp = 1 kernels, the fresh-tile batch passes of the spp > 1 kernel): valid masks are simply used; stale ones are rebuilt once the camera / lens / spheres /
         // tiling have been left alone for two launches — the launches still in flight read the old buffer, so the rebuild joins the two
         // launch streams first (chainBroken: this launch starts on the main stream, behind the mask kernel)
@@ -727,17 +743,11 @@ int launch_frames(pt_handle h, int firstFrame, int n)
             h->launchesSinceInputChange++;
             if (!h->tileMasksValid && h->launchesSinceInputChange > 2) {
                 if (int rc = join_stripes(h)) return rc;
-                const size_t tiles = (size_t)a.tilesX * a.tilesY;
-                if (tiles > h->tileMaskTiles) {
-                    PT_HIP(h, hipStreamSynchronize(h->stream)); // (a launch may still read the old buffer)
-                    if (h->dTileMasks) PT_HIP(h, hipFree(h->dTileMasks));
-                    h->dTileMasks = nullptr;
-                    h->tileMaskTiles = 0;
-                    PT_HIP(h, hipMalloc((void **)&h->dTileMasks, tiles * pt::kTileMaskWords * sizeof(unsigned long long)));
-                    h->tileMaskTiles = tiles;
+                // (the buffer is sized by ensure_accum with the image: nothing is allocated on the render path)
+                if ((size_t)a.tilesX * a.tilesY <= h->tileMaskTiles) {
+                    PT_HIP(h, pt::launch_tile_masks(a, h->dTileMasks, h->stream));
+                    h->tileMasksValid = true;
                 }
-                PT_HIP(h, pt::launch_tile_masks(a, h->dTileMasks, h->stream));
-                h->tileMasksValid = true;
             }
             if (h->tileMasksValid) a.tileMasks = h->dTileMasks;
         }
@@ -759,9 +769,10 @@ int launch_frames(pt_handle h, int firstFrame, int n)
             // Back-pressure (round 3): the host is more than one launch ahead of the GPU — the predecessor still queues behind ITS
             // predecessor.  Launching behind it on the same stream would expose a full drain + ramp per launch (0.096 ms at 1080p);
             // instead the call waits until the predecessor is resident (i.e. until the launch before it has left the machine) and
-            // then chains.  The host thread is never more than two launches ahead; bounded, so a GPU shared with another process
-            // falls back to the always-safe same-stream order.
-            const long waitLimitUs = pt::tuning().chainWaitUs;
+            // then chains.  Bounded, so a GPU shared with another process falls back to the always-safe same-stream order.  Round 5:
+            // pt_render itself no longer waits here — it keeps frames pending until the predecessor is resident (launch_ready) and
+            // only a call that blocks anyway (pt_synchronize, a read, a present) waits, for at most chain_wait_us.
+            const long waitLimitUs = waitUs;
             const auto t0 = std::chrono::steady_clock::now();
             for (long spins = 0; !resident; spins++) {
                 const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -926,13 +937,48 @@ int ensure_rgba8(pt_handle h)
 
 namespace ptimpl {
 
-int flush_frames(pt_handle h)
+// frames one launch may hold for this handle right now (pt_set_frame_batch; automatic: 64, or 256 on a small share)
+int batch_limit(pt_handle h)
 {
-    const int n = h->pendingFrames;
-    if (n == 0) return PT_OK;
-    h->pendingFrames = 0; // first: launch_frames calls join_stripes
-    return launch_frames(h, h->frame - n, n);
+    // (a GPU that owns a small share of the image — fewer than 12,000 tiles per frame, e.g. 1/8 of 1080p — pipelines up to 256 frames
+    // per launch when the batch size was left at its default: every launch boundary costs ~0.1 ms of drain + ramp, 7 % of a 64-frame
+    // launch there; spp > 1 keeps 64, its kernels carry the frame index in 7 bits)
+    if (!h->maxBatchExplicit && h->spp == 1 && (long long)((h->width + 7) / 8) * ((h->rows + 7) / 8) < 12000) return 256;
+    return h->maxBatch < 1 ? 1 : h->maxBatch;
 }
+
+// Would a tagged launch issued now start BESIDE its predecessor (the predecessor is resident), or on an idle chain?  (Otherwise it would
+// have to queue behind it on the same stream, or wait: pt_render keeps the frames pending instead.)
+bool launch_ready(pt_handle h)
+{
+    if (h->chainBroken || h->lastWorkgroups <= 0 || h->lastWorkgroups > kStartedWords || h->overlapHoldoff > 0) return true; // (no chaining decision to wait for)
+    for (int i = 0; i < h->lastWorkgroups; i++)
+        if (((volatile unsigned int *)h->hostStarted)[i] != h->launchSeq) return false;
+    return true;
+}
+
+// Launch the pending frames, oldest first, in launches of at most batch_limit() frames.  waitUs: how long EACH launch may wait for its
+// predecessor to become resident (pt_render passes 0 or a small bound and relies on launch_ready(); blocking entry points pass the
+// tuning knob chain_wait_us).  maxLaunches > 0: stop after that many launches (the rest stays pending).
+int flush_frames_bounded(pt_handle h, long waitUs, int maxLaunches)
+{
+    const int limit = batch_limit(h);
+    int launches = 0;
+    while (h->pendingFrames > 0 && (maxLaunches <= 0 || launches < maxLaunches)) {
+        const int pending = h->pendingFrames;
+        // (only the default kernel pipelines: any other configuration never has more than one frame pending)
+        const int n = pending < limit ? pending : limit;
+        const int first = h->frame - pending;
+        h->pendingFrames = 0; // (launch_frames calls join_stripes, which flushes what is pending: nothing, while this launch is built)
+        const int rc = launch_frames(h, first, n, waitUs, pending == n);
+        h->pendingFrames = pending - n;
+        if (rc) return rc;
+        launches++;
+    }
+    return PT_OK;
+}
+
+int flush_frames(pt_handle h) { return flush_frames_bounded(h, pt::tuning().chainWaitUs, 0); }
 
 // PostProcessing/fragment.glsl:17-26 over this handle's rows into `dst`, ordered behind every frame rendered so far
 int tone_map_into(pt_handle h, void *dst)
@@ -987,7 +1033,7 @@ int ensure_slot_host(pt_handle h, int slot, size_t pixels)
 // Launch the pending frames with a present snapshot attached: their launch stores its last frame's pixels into snapshot buffer
 // h->snapNext while it resolves them (FrameArgs::snapshot).  On return h->snapLaunches lists the launches that write it (empty if
 // a kernel variant without snapshot support rendered the frames) and h->snapFrame is the frame count the snapshot shows.
-int flush_with_snapshot(pt_handle h)
+int flush_with_snapshot(pt_handle h, long waitUs)
 {
     const int k = h->snapNext;
     const size_t pixels = h->tilePixels();
@@ -1010,7 +1056,7 @@ int flush_with_snapshot(pt_handle h)
     h->snapGeneration[k]++;
     h->snapLaunches.clear();
     h->snapFrame = -1;
-    const int rc = flush_frames(h);
+    const int rc = flush_frames_bounded(h, waitUs, 0);
     h->snapshotTarget = nullptr;
     if (rc) return rc;
     if (!h->snapLaunches.empty()) {
@@ -1070,15 +1116,20 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     // follows tone-maps that copy, and the tone map never stands between two frames.  (Launched NOW, not by the present: a host
     // that first waits for a present slot and then presents must find the GPU busy.  If no present follows, the copy is ignored.)
     if (presentsEveryFrame && (h->variant == 0 || h->variant >= 10) && !h->externalStream() && !ptimpl::timeline_blocks_pipelining(h))
-        return ptimpl::flush_with_snapshot(h);
+        return ptimpl::flush_with_snapshot(h, pt::tuning().renderWaitUs);
     // Frames are only held back while the GPU still has integrator work of this handle in flight: deferring can then
     // never idle the device, and a host that leaves time between its frames gets every frame launched at once.
-    // (a GPU that owns a small share of the image — fewer than 12,000 tiles per frame, e.g. 1/8 of 1080p — pipelines up to 256 frames
-    // per launch when the batch size was left at its default: every launch boundary costs ~0.1 ms of drain + ramp, 7 % of a 64-frame
-    // launch there; spp > 1 keeps 64, its kernels carry the frame index in 7 bits)
-    int maxBatch = h->maxBatch;
-    if (!h->maxBatchExplicit && h->spp == 1 && (long long)((h->width + 7) / 8) * ((h->rows + 7) / 8) < 12000) maxBatch = 256;
-    if (!batchable || h->pendingFrames >= maxBatch || !gpu_busy(h)) return flush_frames(h);
+    if (!batchable) return flush_frames(h);
+    if (!gpu_busy(h)) return ptimpl::flush_frames_bounded(h, 0, 0); // (idle device: nothing to wait for)
+    const int limit = ptimpl::batch_limit(h);
+    if (h->pendingFrames < limit) return PT_OK;
+    // A full batch.  Round 5: pt_render never sits in the back-pressure wait (it was up to chain_wait_us = 60 ms): the batch is launched
+    // when it can start beside its predecessor (that one is resident: the launch before it has left the machine); until then the
+    // frames simply stay pending — the GPU has two launches' worth of work queued, nothing idles — and whichever call comes next
+    // looks again.  Only a host that runs more than 16 launches ahead is held, for at most 2 ms per call, and then queues the batch
+    // behind its predecessor.
+    if (ptimpl::launch_ready(h)) return ptimpl::flush_frames_bounded(h, 0, 1);
+    if (h->pendingFrames >= 16 * limit) return ptimpl::flush_frames_bounded(h, pt::tuning().renderWaitUs, 1);
     return PT_OK;
 }
 
@@ -1175,7 +1226,7 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
     // chains its launch beside this one.
     const bool snapshotCapable = (h->variant == 0 || h->variant >= 10) && !h->externalStream() && !ptimpl::timeline_blocks_pipelining(h);
     if (snapshotCapable && h->pendingFrames > 0)
-        if (int rc = ptimpl::flush_with_snapshot(h)) return rc;
+        if (int rc = ptimpl::flush_with_snapshot(h, pt::tuning().renderWaitUs)) return rc;
     if (snapshotCapable && h->pendingFrames == 0 && h->snapFrame == h->frame && !h->snapLaunches.empty()) {
         // (the frames' launch — flushed just now, or by the pt_render before this call — wrote snapshot buffer snapshotIndex)
         {

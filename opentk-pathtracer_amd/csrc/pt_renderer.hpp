@@ -226,7 +226,10 @@ int hip_fail(pt_handle h, hipError_t e, const char *what);
     } while (0)
 
 int bind_device(pt_handle h);
-int flush_frames(pt_handle h);  // launch the frames pt_render deferred
+int flush_frames(pt_handle h);  // launch the frames pt_render deferred (a blocking entry point's flush: may wait chain_wait_us per launch)
+int flush_frames_bounded(pt_handle h, long waitUs, int maxLaunches);
+int batch_limit(pt_handle h);
+bool launch_ready(pt_handle h);
 // flush + make h->stream wait for every helper stream + (repairNow) enqueue the hand-over repair passes of the launches since the last
 // join behind them.  repairNow = false is for callers that synchronise h->stream right away and then call settle_handover(): the
 // repair kernels are then only enqueued when the host-visible flag says a launch was abandoned (nothing at all on the usual path)

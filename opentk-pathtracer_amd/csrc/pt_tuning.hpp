@@ -3,6 +3,8 @@
 // The product library reads NO environment variables: a knob only ever changes through pt_debug_set(key, value), an entry point that
 // is exported but NOT declared in include/mi355pt.h (like the other pt_debug_* test aids).  One set of knobs per process, read where
 // they apply (plain loads of this struct — nothing is parsed per launch); a knob affects renderers / launches created after it is set.
+// Knobs are SET-UP state: set them from one thread while no other thread is inside the library (nothing here is atomic; log_launch is
+// counted down by whichever thread launches).
 //   Python: native.debug_set("no_sphere_grid", 1); bench.py --tune key=value; tools/handover_stress.bin --tune key=value
 #pragma once
 #include <cstring>
@@ -21,7 +23,8 @@ struct Tuning {
     int auditSabotage = 0;         // -DPT_AUDIT builds only: every n-th (pixel, frame) folds into a perturbed colour
     int noSingleTagged = 0;        // 1: single frames never chain
     int shortWorkgroupsPerCU = 5;  // workgroups per CU of launches of fewer than 8 frames
-    long chainWaitUs = 60000;      // back-pressure: how long a launch waits for its predecessor to become resident
+    long chainWaitUs = 60000;      // back-pressure: how long a launch issued by a BLOCKING entry point waits for its predecessor to become resident
+    long renderWaitUs = 2000;      // ... and the most pt_render itself ever waits (only when the host is 16 launches ahead)
     long handoverBudgetMs = 2000;  // hand-over bound: a result that has waited this long (wall clock) for its pixel's previous frame abandons its launch
     long handoverCheckUs = 1000;   // ... and how often a waiting wavefront looks at the abandon word and at its own waits
     // kernel selection (pt_integrate_persistent.hip: launch_integrate)
@@ -65,6 +68,7 @@ inline bool tuning_set(const char *key, long long v)
     PT_KNOB("no_single_tagged", noSingleTagged)
     PT_KNOB("short_wg", shortWorkgroupsPerCU)
     PT_KNOB("chain_wait_us", chainWaitUs)
+    PT_KNOB("render_wait_us", renderWaitUs)
     PT_KNOB("handover_budget_ms", handoverBudgetMs)
     PT_KNOB("handover_check_us", handoverCheckUs)
     PT_KNOB("parked_max", parkedMax)

@@ -1,0 +1,56 @@
+"""GPU tests added in round 5 (besides tests/test_gpu_handover_bound.py and the GPU leg of tests/test_decision_margins.py):
+  * pt_render never sits in the launch chaining's back-pressure wait (it was bounded by 60 ms): frames whose batch cannot start beside
+    its predecessor yet stay pending; the image is the same as ever;
+  * frames pending over several launches' worth are launched oldest first in launches of at most pt_set_frame_batch frames, the last of
+    them alone storing the reference's alpha = 1.
+Run with `pytest -m gpu` on an MI355X.  Nothing here reads /root/reference.
+"""
+import time
+
+import numpy as np
+import pytest
+
+import configs
+from test_gpu_abi_round2 import make_tracer
+from test_gpu_parity import assert_bit_exact, oracle_render
+
+pytestmark = pytest.mark.gpu
+
+
+def test_render_returns_promptly_while_the_gpu_is_launches_behind(pkg, native_lib):
+    """PathTracer.Render() (PathTracer.cs:114-123) enqueues and returns.  2,000 Render() calls at 1080p as fast as the host can issue
+    them (the GPU needs ~0.11 ms per frame, the host ~1 us per call, so the host is soon dozens of launches ahead): no single call may
+    take longer than the documented 2 ms bound (+ slack for a noisy host), and all but a handful must take microseconds."""
+    w = configs.Workload("prompt", "default", 1920, 1080, 8, "sky_f32_32")
+    pt = make_tracer(pkg, w)
+    for _ in range(70):
+        pt.Render()
+    pt.Synchronize()
+    times = np.empty(2000)
+    for i in range(times.size):
+        t = time.perf_counter()
+        pt.Render()
+        times[i] = time.perf_counter() - t
+    t_sync = time.perf_counter()
+    pt.Synchronize()
+    t_sync = time.perf_counter() - t_sync
+    img = pt.Result
+    pt.Dispose()
+    print(f"pt_render: max {1e3 * times.max():.3f} ms, 99.9th percentile {1e3 * np.quantile(times, 0.999):.3f} ms, median {1e6 * np.median(times):.1f} us; "
+          f"pt_synchronize afterwards {1e3 * t_sync:.1f} ms")
+    assert times.max() < 6e-3, f"a pt_render call took {1e3 * times.max():.2f} ms"
+    assert np.quantile(times, 0.99) < 1e-3
+    assert np.isfinite(img).all() and (img[..., 3] == 1).all()
+
+
+def test_frames_pending_over_many_launches_render_the_reference_image(pkg, native_lib, oracle):
+    """300 Render() calls issued while the GPU is busy stay pending far beyond one launch's worth and are launched by the read as five
+    launches of <= 64 frames (oldest first; only the last stores alpha = 1): the image equals the oracle's 300-frame accumulation."""
+    w = configs.Workload("manypending", "default", 160, 90, 6, "sky_f32_32", frames=300)
+    pt = make_tracer(pkg, w)
+    pt.SetFrameBatch(64)
+    for _ in range(w.frames):
+        pt.Render()
+    got = pt.Result
+    pt.Dispose()
+    assert_bit_exact(got, oracle_render(oracle, w), "300 frames, pending over several launches")
