@@ -186,7 +186,7 @@ def cpu_baseline(pkg, scene, basic, env, width, height, depth, spp, workload_nam
                     "workload": workload_name}
         except Exception:
             pass
-    return out, st["bounces"] / max(1, st["samples"])
+    return out, st["bounces"] / max(1, st["samples"]), st["env_lookups"] / max(1, st["samples"])
 
 
 def self_spawn(args) -> int:
@@ -544,6 +544,8 @@ def main():
 
     if rank == 0:
         W, H, rows = m["W"], m["H"], m["rows"]
+        if args.variant == 0 and not args.frame_batch:  # the library's automatic choice (include/mi355pt.h: pt_set_frame_batch)
+            frames_per_launch = 256 if (args.spp == 1 and ((W + 7) // 8) * ((rows + 7) // 8) < 12000) else 64
         samples = W * H * args.spp * args.steps
         ms_per_step = m["elapsed"] * 1e3 / args.steps
         kernel_ms = m["kernel_s"] * 1e3 / args.steps
@@ -577,6 +579,21 @@ def main():
                                                (2 if args.variant == 0 else (args.variant // 10 if 20 <= args.variant < 50 else 1))),
                          "frames_per_launch": frames_per_launch,
                          "algorithmic_bytes_per_launch": algo_bytes * frames_per_launch,
+                         # average duration of one launch of the timed region (HIP events on the library's own streams; frac =
+                         # algorithmic_bytes_per_launch / avg_launch_ns_timed_region / peak can be recomputed from this line alone)
+                         "avg_launch_ns_timed_region": round(kernel_ms * 1e6 * frames_per_launch),
+                         "launches_in_timed_region": round(args.steps / frames_per_launch, 3),
+                         "provenance": {
+                             "achieved": {"measured_in_this_run": True, "how": "HIP events around the timed region on the library's streams"},
+                             "frac": {"measured_in_this_run": True},
+                             "kernel_ms": {"measured_in_this_run": True},
+                             "avg_launch_ns_timed_region": {"measured_in_this_run": True},
+                             "traffic": {"measured_in_this_run": False, "source": "profiles/traffic.json" if traffic else None,
+                                         "csrc_hash": csrc_hash if traffic else None,
+                                         "how": "rocprofv3 PMC passes of tools/round_profiles.sh (separate runs of this command on the same kernel "
+                                                "sources: used only when the entry's csrc_hash equals this library's)"},
+                             "valu_issue": {"measured_in_this_run": False, "source": "profiles/valu_insts.json", "csrc_hash": csrc_hash,
+                                            "how": "SQ_INSTS_VALU of a rocprofv3 PMC pass (same rule); the RATE divides it by this run's kernel_ms"}},
                          "note": "32 B/pixel/frame (float4 load + store of the accumulation image); kernel_ms = GPU time per "
                                  "step (= frame) from HIP events on the library's streams. The default kernel pipelines up to "
                                  "frames_per_launch consecutive frames inside ONE launch (achieved = algorithmic_bytes_per_launch "
@@ -632,11 +649,23 @@ def main():
                 "ms_per_step": round(m4k["elapsed"] * 1e3 / m4k["steps"], 5), "steps": m4k["steps"], "scaling": "strong",
                 "kernel_ms": round(k4, 5), "present_ms": round(m4k["present_ms"], 3), "checks": m4k["checks"],
                 "roofline_frac_hbm": round(a4 / HBM_PEAK_GBS, 5)}
-        mean_bounces = None
+        mean_bounces = miss_fraction = None
         if world == 1 and not args.no_cpu_baseline:
             env_cpu = m["env_cpu"] if env_name != "sky2048" else pkg.envmap.synthetic_sky_srgb8(2048)
             wl_name = {("default", 8, "atmosphere256"): "C2_default_1080p_d8_atmo"}.get((scene_name, depth, env_name)) if (W, H) == (1920, 1080) and args.spp == 1 else None
-            out["cpu_baseline"], mean_bounces = cpu_baseline(pkg, scene, m["basic"], env_cpu, W, H, depth, args.spp, wl_name)
+            out["cpu_baseline"], mean_bounces, miss_fraction = cpu_baseline(pkg, scene, m["basic"], env_cpu, W, H, depth, args.spp, wl_name)
+            # SURVEY section 8d's secondary byte figure: + 4 environment texels per path that ends in a miss (64 B for the RGBA32F cubes,
+            # 16 B for sRGB8) — with a 100 MB cube (sky2048) those taps are not cache-resident, and the measured traffic shows them
+            tap_bytes = (16 if env_name == "sky2048" else 64) * miss_fraction * args.spp
+            sec = algo_bytes + tap_bytes * W * rows
+            out["roofline"]["secondary"] = {
+                "algorithmic_bytes_per_step_with_env_taps": round(sec), "paths_ending_in_a_miss_per_sample": round(miss_fraction, 4),
+                "bytes_per_miss": 16 if env_name == "sky2048" else 64, "achieved": round(sec / (kernel_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+                "frac": round(sec / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "traffic_ratio": (round(traffic / sec, 3) if traffic else None),
+                "measured_in_this_run": True,
+                "note": "SURVEY 8d's optional figure: 32 B per pixel and frame + 4 environment texels per path that ends in a miss (counted by "
+                        "the oracle on one frame of this workload, this run)"}
         if mean_bounces is not None:
             fl = flops_per_sample(mean_bounces, scene.num_spheres, scene.num_cuboids)
             tf = fl * (W * rows * args.spp) / (kernel_ms * 1e-3) / 1e12

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 using ptimpl::fail;
@@ -340,16 +341,26 @@ PT_API int pt_create_multi(const int *device_ids, int n_devices, int width, int 
     g->stream = g->ownStream;
     PT_GROUP_HIP(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
 #undef PT_GROUP_HIP
-    // direct xGMI copies between the root and every peer (without it hipMemcpyPeerAsync stages through the host)
+    // direct xGMI copies between the root and every peer.  Without peer access hipMemcpyPeerAsync would silently stage every gather through
+    // host memory: a group that cannot reach a device directly is refused (tuning knob allow_staged_gather = 1 accepts it, for a box
+    // whose topology really has no link), loudly — SCALE numbers must never come from a host-staged gather by accident.
     for (int i = 1; i < n_devices; i++) {
         const int d = device_ids[i];
         if (d == g->device) continue;
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, g->device, d) == hipSuccess && can) {
+        int canRootToPeer = 0, canPeerToRoot = 0;
+        const hipError_t e1 = hipDeviceCanAccessPeer(&canRootToPeer, g->device, d), e2 = hipDeviceCanAccessPeer(&canPeerToRoot, d, g->device);
+        if ((e1 != hipSuccess || e2 != hipSuccess || !canRootToPeer || !canPeerToRoot) && pt::tuning().allowStagedGather == 0) {
+            (void)hipGetLastError();
+            const std::string msg = "pt_create_multi: no peer access between device " + std::to_string(g->device) + " and device " + std::to_string(d) +
+                                    " (hipDeviceCanAccessPeer = 0): the gather would be staged through the host";
+            ptimpl::group_destroy(g);
+            return fail(nullptr, PT_E_HIP, msg);
+        }
+        if (canRootToPeer) {
             (void)hipSetDevice(g->device);
             (void)hipDeviceEnablePeerAccess(d, 0); // hipErrorPeerAccessAlreadyEnabled is fine
         }
-        if (hipDeviceCanAccessPeer(&can, d, g->device) == hipSuccess && can) {
+        if (canPeerToRoot) {
             (void)hipSetDevice(d);
             (void)hipDeviceEnablePeerAccess(g->device, 0);
         }

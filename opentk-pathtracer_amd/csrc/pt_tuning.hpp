@@ -19,6 +19,7 @@ struct Tuning {
     int frameBatch = 0;            // 1..64: initial pt_set_frame_batch
     int queueChunk = 0;            // 1..1024: tiles per global ticket (0 = automatic)
     int groupBand = -1;            // group handles: band height (0 = contiguous row blocks; else a multiple of 8)
+    int allowStagedGather = 0;     // group handles: 1 = accept devices without peer access (their gather is staged through the host)
     // launches (mi355pt.cpp: launch_frames)
     int auditSabotage = 0;         // -DPT_AUDIT builds only: every n-th (pixel, frame) folds into a perturbed colour
     int noSingleTagged = 0;        // 1: single frames never chain
@@ -64,6 +65,7 @@ inline bool tuning_set(const char *key, long long v)
     PT_KNOB("frame_batch", frameBatch)
     PT_KNOB("queue_chunk", queueChunk)
     PT_KNOB("group_band", groupBand)
+    PT_KNOB("allow_staged_gather", allowStagedGather)
     PT_KNOB("audit_sabotage", auditSabotage)
     PT_KNOB("no_single_tagged", noSingleTagged)
     PT_KNOB("short_wg", shortWorkgroupsPerCU)
