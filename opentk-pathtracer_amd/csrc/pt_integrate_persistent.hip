@@ -1027,7 +1027,16 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         // CARRY (the pixel travels with its path, see PathEntryCarry): full-size images of scenes whose materials stay in LDS — the 12 more
         // bytes per ring entry and the 3 KB of lane slots are what the parked resolves take elsewhere, and only a GPU that owns few
         // tiles per frame needs those (+0.3 % at full 1080p); with the sphere grid, or on a small share, the plain kernel stays
-        bool carry = spp1 && !useGrid && !perWaveTimeline && tiles >= 12000 && tune.carryLast != 0 && a.drainCompaction == 0;
+        // Sphere-grid scenes (round 5, knob grid_carry): the grid kernel carries the pixel too, at FIVE workgroups per CU (its rings and lane
+        // slots need 4.9 KB more than six leave room for; 96 VGPRs instead of 80)
+        const bool gridCarry = useGrid && spp1 && tune.gridCarry != 0 && tiles >= 12000 && tune.carryLast != 0 && a.drainCompaction == 0 && !perWaveTimeline;
+        if (gridCarry && blocksPerCU > 5) {
+            blocksPerCU = 5;
+            nwg = a.numCUs * blocksPerCU;
+            if (nwg > numChunks) nwg = numChunks;
+            if (nwg < 1) nwg = 1;
+        }
+        bool carry = spp1 && (!useGrid || gridCarry) && !perWaveTimeline && tiles >= 12000 && tune.carryLast != 0 && a.drainCompaction == 0;
         auto queue_bytes = [&](bool c) -> size_t {
             if (useBatchPass) return (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry));
             return (spp1 ? frame_weight_bytes(a.batchFrames) : 0) +
@@ -1052,6 +1061,11 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
             if (wgFull > (size_t)blocksPerCU) wgFull = (size_t)blocksPerCU;
             if (wgLean > (size_t)blocksPerCU) wgLean = (size_t)blocksPerCU;
             const bool lean = wgLean > wgFull || forceLean || useGrid; // (the grid kernel is only instantiated for materials in device memory)
+            if (carry && gridCarry && wgLean >= (size_t)blocksPerCU) { // (the carrying grid kernel: materials in device memory like every grid kernel)
+                a.materialsInLds = 0;
+                ldsTotal = ldsLean;
+                break;
+            }
             if (carry && (lean || wgFull < (size_t)blocksPerCU)) { // (the carrying kernel exists with materials in LDS only, and must not cost a workgroup)
                 carry = false;
                 a.parkedMax = parkedMaxPlain;
@@ -1088,6 +1102,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         else if (spp1 && matLds && carry) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_SPP1_WAVES, false, true, true, false, true, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1 && matLds && a.drainCompaction == 0) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_SPP1_WAVES, false, true, true, false, false, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1 && matLds) PT_LAUNCH_PERSISTENT(false, true, true);
+        else if (spp1 && useGrid && carry) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, 5, false, true, false, true, true, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1 && useGrid) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_GRID_MIN_WAVES, false, true, false, true, false, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1) PT_LAUNCH_PERSISTENT(false, true, false);
         else if (useBatchPass) (void)launch_multisample(a, nwg, ldsTotal, stream, matLds, useGrid);

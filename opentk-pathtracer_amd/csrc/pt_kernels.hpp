@@ -70,7 +70,7 @@ struct FrameArgs {
     const unsigned char *grid;
     int gridBytes;          // size of the packed grid
     int gridLdsBytes;       // set by the launch: LDS bytes the staged grid takes (0 = this launch does not traverse it)
-    unsigned int tilesFrameMagic, tilesXMagic; // floor(2^32 / (tilesX * tilesY)), floor(2^32 / tilesX): split_ticket (pt_kernel_common.hpp)
+    unsigned int tilesFrameMagic, tilesXMagic; // floor(2^32 / (tilesX * tilesY)), floor(2^32 / tilesX): the tile pass splits a ticket's (frame, tile) pair with them
     float invW, invH;       // 1 / width, 1 / height: IEEE quotients, computed once on the host (what the tile pass used to divide out per tile)
     int sceneLdsBytes;      // set by the launch: scene_lds_bytes(...) of this launch = where the frame table starts (one scalar load where a
                             // pixel is resolved, instead of re-deriving it from five other fields)
