@@ -14,9 +14,11 @@ PT_DEV void atmo_rsi(v3 r0, v3 rd, float sr, float &x, float &y) // :58-71
     float c = f_fma(-sr, sr, v_dot(r0, r0));
     float d = f_fma(b, b, -(4.0f * a * c));
     if (d < 0.0f) { x = 1e5f; y = -1e5f; return; }
-    float sq = f_sqrt(d), den = 2.0f * a;
-    x = (-b - sq) / den;
-    y = (-b + sq) / den;
+    // (the contract's pt_sqrt and ONE pt-f32 reciprocal: the correctly rounded sqrt and two divisions were 138 issue cycles of this
+    // function, which runs 53 times per texel)
+    float sq = pt_sqrt(d), rden = f_rcp(2.0f * a);
+    x = (-b - sq) * rden;
+    y = (-b + sq) * rden;
 }
 
 PT_DEV v3 atmosphere(v3 r, v3 r0, v3 pSun, float iSun, float rPlanet, float rAtmos, v3 kRlh, float kMie, float shRlh,
@@ -38,20 +40,21 @@ PT_DEV v3 atmosphere(v3 r, v3 r0, v3 pSun, float iSun, float rPlanet, float rAtm
     float base = 1.0f + gg - 2.0f * mu * g;
     float pMie = 3.0f / (8.0f * PI) * ((1.0f - gg) * (mumu + 1.0f)) / ((base * f_sqrt(base)) * (2.0f + gg));
     float invShRlh = -1.0f / shRlh, invShMie = -1.0f / shMie;
+    const float invJSteps = f_div_ieee(1.0f, (float)jSteps); // uniform
     for (int i = 0; i < iSteps; i++) {
         v3 iPos = v_fma(r, f_fma(iStepSize, 0.5f, iTime), r0);
-        float iHeight = f_sqrt(v_dot(iPos, iPos)) - rPlanet;
+        float iHeight = pt_sqrt(v_dot(iPos, iPos)) - rPlanet;
         float odStepRlh = pt_exp(iHeight * invShRlh) * iStepSize;
         float odStepMie = pt_exp(iHeight * invShMie) * iStepSize;
         iOdRlh += odStepRlh;
         iOdMie += odStepMie;
         float sx, sy;
         atmo_rsi(iPos, pSun, rAtmos, sx, sy);
-        float jStepSize = sy / (float)jSteps;
+        float jStepSize = sy * invJSteps;
         float jTime = 0.0f, jOdRlh = 0.0f, jOdMie = 0.0f;
         for (int j = 0; j < jSteps; j++) {
             v3 jPos = v_fma(pSun, f_fma(jStepSize, 0.5f, jTime), iPos);
-            float jHeight = f_sqrt(v_dot(jPos, jPos)) - rPlanet;
+            float jHeight = pt_sqrt(v_dot(jPos, jPos)) - rPlanet;
             jOdRlh = f_fma(pt_exp(jHeight * invShRlh), jStepSize, jOdRlh);
             jOdMie = f_fma(pt_exp(jHeight * invShMie), jStepSize, jOdMie);
             jTime += jStepSize;

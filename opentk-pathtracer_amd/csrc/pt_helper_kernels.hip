@@ -124,27 +124,60 @@ hipError_t launch_postprocess(const float4 *accum, void *outRgba8, size_t n, hip
 
 // ---------------------------------------------------------------------------------------------- atmosphere
 // device functions: pt_atmosphere.hpp
-__global__ __launch_bounds__(256) void atmo_precompute_kernel(const AtmoArgs a)
+// One lane per cube texel — of HALF the cube when the sun stands in the plane x = 0, which is where the reference's host always puts it
+// (AtmosphericScatterer.cs:35-45: LightPosition = (0, sin, cos) x 1.496e11).  The scattering integral depends on the view direction r
+// only through dot products with r0 = (0, R, 0) and pSun = (0, sy, sz) and through squares of the x components of points r0 + t r and
+// their offsets along pSun: negating r.x negates those x components and changes nothing else, bit for bit.  The cube's texel grid is
+// symmetric under x -> -x (texel x of faces +-Y, +-Z pairs with texel S - x of the same face, +X with -X; column x = 0 has no partner
+// because ndc = 2 x / S - 1 never reaches +1), so a lane computes its texel's direction AND its partner's (two small matrix products),
+// and when pSun.x == 0 and the two directions are exact mirror images the lower texel of the pair computes the colour once and stores it
+// twice, so the kernel does half the work.  Any other sun position or view matrix fails the test and the lane computes its partner's
+// colour too: every texel is then evaluated on its own, as before.  Verified against the oracle,
+// which computes every texel directly: bit-identical cubes (tests/test_gpu_parity.py, sizes 24 ... 2048).
+PT_DEV v3 atmo_texel_direction(const AtmoArgs &a, int face, int x, int y)
 {
-    const int S = a.size;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)6 * S * S) return;
-    int x = (int)(i % S), y = (int)((i / S) % S), face = (int)(i / ((size_t)S * S));
     // main :30-56 — ndc from the texel's integer coordinate (no half-texel offset)
+    const int S = a.size;
     float ndcx = f_fma((float)x / (float)S, 2.0f, -1.0f), ndcy = f_fma((float)y / (float)S, 2.0f, -1.0f);
     float eye[4], wd[4];
     mat_vec(a.invProj, ndcx, ndcy, -1.0f, 0.0f, eye);
     mat_vec(a.invView[face], eye[0], eye[1], -1.0f, 0.0f, wd);
-    v3 dir = v_normalize(V(wd[0], wd[1], wd[2]));
-    v3 col = atmosphere(dir, V(0.0f, 6376e3f, 0.0f), V(a.lightPos[0], a.lightPos[1], a.lightPos[2]), a.lightIntensity,
-                        6371e3f, 6471e3f, V(5.5e-6f, 13.0e-6f, 22.4e-6f), 21e-6f, 8e3f, 1.2e3f, 0.758f, a.iSteps,
-                        a.jSteps);
-    a.out[i] = make_float4(col.x, col.y, col.z, 1.0f);
+    return v_normalize(V(wd[0], wd[1], wd[2]));
+}
+
+// canonical texels per cube row: all S of face +X, column 0 of face -X, and columns 0 .. S / 2 of the four other faces
+__host__ __device__ inline int atmo_half_columns(int S) { return S / 2 + 1; }
+__host__ __device__ inline int atmo_row_lanes(int S) { return S + 1 + 4 * atmo_half_columns(S); }
+
+__global__ __launch_bounds__(256) void atmo_precompute_kernel(const AtmoArgs a)
+{
+    const int S = a.size, C = atmo_half_columns(S), T = atmo_row_lanes(S);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)S * T) return;
+    // lane -> the LOWER texel of a mirrored pair, or a texel without partner (the grid holds only those: no idle wavefronts, and the
+    // work spreads over the 8 XCDs whatever the size — with one lane per texel the leaving half landed on 4 of the 8)
+    const int y = (int)(i / T);
+    int r = (int)(i % T), face, x;
+    if (r < S) { face = 0; x = r; }
+    else if (r == S) { face = 1; x = 0; }
+    else { r -= S + 1; face = 2 + r / C; x = r % C; }
+    const v3 dir = atmo_texel_direction(a, face, x, y);
+    const v3 r0 = V(0.0f, 6376e3f, 0.0f), sun = V(a.lightPos[0], a.lightPos[1], a.lightPos[2]), kRlh = V(5.5e-6f, 13.0e-6f, 22.4e-6f);
+    const v3 col = atmosphere(dir, r0, sun, a.lightIntensity, 6371e3f, 6471e3f, kRlh, 21e-6f, 8e3f, 1.2e3f, 0.758f, a.iSteps, a.jSteps);
+    a.out[((size_t)face * S + y) * S + x] = make_float4(col.x, col.y, col.z, 1.0f);
+    // the texel's mirror image under x -> -x, if it has one that is not itself
+    const int mface = face < 2 ? 1 - face : face, mx = S - x;
+    if (x < 1 || (mface == face && mx == x)) return;
+    const v3 pdir = atmo_texel_direction(a, mface, mx, y);
+    v3 pcol = col;
+    if (!(a.lightPos[0] == 0.0f && pdir.x == -dir.x && pdir.y == dir.y && pdir.z == dir.z)) // not an exact mirror image: computed on its own
+        pcol = atmosphere(pdir, r0, sun, a.lightIntensity, 6371e3f, 6471e3f, kRlh, 21e-6f, 8e3f, 1.2e3f, 0.758f, a.iSteps, a.jSteps);
+    a.out[((size_t)mface * S + y) * S + mx] = make_float4(pcol.x, pcol.y, pcol.z, 1.0f);
 }
 
 hipError_t launch_atmosphere(const AtmoArgs &a, hipStream_t stream)
 {
-    size_t n = (size_t)6 * a.size * a.size;
+    const size_t n = (size_t)a.size * atmo_row_lanes(a.size);
     hipLaunchKernelGGL(atmo_precompute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

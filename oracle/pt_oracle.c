@@ -29,7 +29,8 @@
  *   - normalize(v)  = v * f_rsqrt(dot(v,v))
  *   - sqrt(x)       = pt_sqrt(x) on the per-bounce path (sphere roots, hemisphere / lens sampling, refract): the same
  *                     seed, TWO Newton steps, then s = x*y; s += fma(-s,s,x) * (y/2)  (<= 0.501 ulp; GLSL inherits
- *                     sqrt's precision from 1/inversesqrt = 2 ulp).  The atmosphere precompute keeps IEEE sqrtf.
+ *                     sqrt's precision from 1/inversesqrt = 2 ulp).  The atmosphere precompute uses it for its per-step
+ *                     roots and heights too (round 5; the once-per-texel terms keep IEEE sqrtf and `/`).
  *   - mix(x,y,a)    = fma(y, a, x*(1-a))                       (GLSL 4.50 section 8.3 definition)
  *   - min/max       = IEEE minNum/maxNum (fminf/fmaxf); GLSL leaves NaN handling undefined
  *   - sin/cos/exp   = the fixed polynomial algorithms below (<= ~1.5 ulp), pow(x,5) = x*(x^2)^2,
@@ -1142,9 +1143,11 @@ static void atmo_rsi(v3 r0, v3 rd, float sr, float *x, float *y) /* :58-71 */
     float c = fmaf(-sr, sr, v_dot(r0, r0));
     float d = fmaf(b, b, -(4.0f * a * c));
     if (d < 0.0f) { *x = 1e5f; *y = -1e5f; return; }
-    float sq = sqrtf(d), den = 2.0f * a;
-    *x = (-b - sq) / den;
-    *y = (-b + sq) / den;
+    /* (round 5: the per-step roots use the contract's pt_sqrt and ONE pt-f32 reciprocal instead of sqrtf and two IEEE divisions —
+       the correctly rounded forms are 52 / 43 issue cycles each on gfx950, and this function runs 53 times per texel) */
+    float sq = pt_sqrt(d), rden = f_rcp(2.0f * a);
+    *x = (-b - sq) * rden;
+    *y = (-b + sq) * rden;
 }
 
 static v3 atmosphere(v3 r, v3 r0, v3 pSun, float iSun, float rPlanet, float rAtmos, v3 kRlh, float kMie,
@@ -1166,20 +1169,21 @@ static v3 atmosphere(v3 r, v3 r0, v3 pSun, float iSun, float rPlanet, float rAtm
     float base = 1.0f + gg - 2.0f * mu * g;
     float pMie = 3.0f / (8.0f * PI) * ((1.0f - gg) * (mumu + 1.0f)) / ((base * sqrtf(base)) * (2.0f + gg));
     float invShRlh = -1.0f / shRlh, invShMie = -1.0f / shMie; /* exp(-h/sh) evaluated as exp(h * (-1/sh)) */
+    const float invJSteps = 1.0f / (float)jSteps;               /* uniform IEEE reciprocal: sy / jSteps is evaluated as sy * (1 / jSteps) */
     for (int i = 0; i < iSteps; i++) {
         v3 iPos = v_fma(r, fmaf(iStepSize, 0.5f, iTime), r0);
-        float iHeight = sqrtf(v_dot(iPos, iPos)) - rPlanet;
+        float iHeight = pt_sqrt(v_dot(iPos, iPos)) - rPlanet;
         float odStepRlh = f_exp(iHeight * invShRlh) * iStepSize;
         float odStepMie = f_exp(iHeight * invShMie) * iStepSize;
         iOdRlh += odStepRlh;
         iOdMie += odStepMie;
         float sx, sy;
         atmo_rsi(iPos, pSun, rAtmos, &sx, &sy);
-        float jStepSize = sy / (float)jSteps;
+        float jStepSize = sy * invJSteps;
         float jTime = 0.0f, jOdRlh = 0.0f, jOdMie = 0.0f;
         for (int j = 0; j < jSteps; j++) {
             v3 jPos = v_fma(pSun, fmaf(jStepSize, 0.5f, jTime), iPos);
-            float jHeight = sqrtf(v_dot(jPos, jPos)) - rPlanet;
+            float jHeight = pt_sqrt(v_dot(jPos, jPos)) - rPlanet;
             jOdRlh = fmaf(f_exp(jHeight * invShRlh), jStepSize, jOdRlh);
             jOdMie = fmaf(f_exp(jHeight * invShMie), jStepSize, jOdMie);
             jTime += jStepSize;

@@ -54,3 +54,28 @@ def test_frames_pending_over_many_launches_render_the_reference_image(pkg, nativ
     got = pt.Result
     pt.Dispose()
     assert_bit_exact(got, oracle_render(oracle, w), "300 frames, pending over several launches")
+
+
+def test_atmosphere_half_cube_by_symmetry_equals_the_oracle_texel_for_texel(pkg, native_lib, oracle):
+    """Round 5: with the sun in the plane x = 0 (where the reference's host always puts it, AtmosphericScatterer.cs:35-45) the kernel
+    computes the lower texel of every x-mirrored pair and stores it twice — after checking per pair that the two view directions are
+    exact mirror images.  The oracle computes every texel on its own: the cubes must be bit-identical for even and odd sizes (odd: the
+    pairing x <-> S - x has no fixed column), for a size where whole wavefronts leave (512), and for a sun OFF the plane, where the test
+    fails for every pair and the kernel computes every texel as before."""
+    ubo = pkg.camera.atmospheric_data_ubo()
+    pt = pkg.PathTracer(None, 64, 64, 8, 1, 20.0, 0.14)
+    cases = [(24, 0.5, None), (33, 0.3, None), (128, 0.52, None), (512, 0.5, None), (96, 0.4, 3.0e10)]
+    for size, t, sun_x in cases:
+        lp = np.array(pkg.camera.atmosphere_light_pos(t), dtype=np.float32)
+        if sun_x is not None:
+            lp[0] = sun_x
+        at = pkg.AtmosphericScatterer(size, ubo, lp, pt)
+        pt.EnvironmentMap = at  # (renders)
+        got = at.Result
+        want = oracle.atmosphere(size, ubo, lp)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"size {size}, time {t}, sun x {sun_x}: HIP atmosphere differs from the oracle"
+        if sun_x is None and size & (size - 1) == 0:  # the symmetry itself, in the oracle's own cube (power-of-two sizes: x / S is exact): texel x of +-Y, +-Z == texel S - x, +X == -X mirrored
+            for face in (2, 3, 4, 5):
+                assert np.array_equal(want[face][:, 1:].view(np.uint32), want[face][:, :0:-1].view(np.uint32))
+            assert np.array_equal(want[0][:, 1:].view(np.uint32), want[1][:, :0:-1].view(np.uint32))
+    pt.Dispose()
