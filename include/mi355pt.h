@@ -202,8 +202,8 @@ PT_API int pt_present_bind_device_image(pt_handle h, int slot, void *device_rgba
 PT_API int pt_write_result(pt_handle h, const float *src_rgba32f, size_t row_pitch_bytes, int frame_index);
 
 PT_API int pt_get_frame_index(pt_handle h, int *out_frame_index);
-/* Launch what is pending and wait for the handle's stream.  Also the place where a failed frame hand-over inside a
- * pipelined launch is reported (PT_E_HIP; it cannot happen unless the device loses workgroups mid-launch). */
+/* Launch what is pending and wait for the handle's stream.  (A pipelined launch that abandoned a frame hand-over — see pt_render — has
+ * been repaired when this returns: the image is the one an undisturbed run leaves; no error is reported for it.) */
 PT_API int pt_synchronize(pt_handle h);
 
 /* ---- atmosphere environment (secondary kernel) ------------------------------------------------------------- */
