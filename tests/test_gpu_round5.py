@@ -79,3 +79,32 @@ def test_atmosphere_half_cube_by_symmetry_equals_the_oracle_texel_for_texel(pkg,
                 assert np.array_equal(want[face][:, 1:].view(np.uint32), want[face][:, :0:-1].view(np.uint32))
             assert np.array_equal(want[0][:, 1:].view(np.uint32), want[1][:, :0:-1].view(np.uint32))
     pt.Dispose()
+
+
+def test_sphere_grid_kernel_that_carries_the_pixel_is_bit_exact(pkg, native_lib):
+    """Tuning knob grid_carry = 1 (csrc/pt_tuning.hpp): the sphere-grid kernel carries the pixel with the path, at five workgroups per CU
+    (traffic 2.22 x -> 1.43 x on the 256-sphere scene, profiles/r05/c3_grid_carry.log).  Full-size launch (the carrying kernels need
+    >= 12,000 tiles), 256 spheres, 70 frames in two chained launches, against one plain launch per frame of the tile-per-wave kernel."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import __graft_entry__ as g
+import configs
+from test_gpu_abi_round2 import make_tracer
+pkg = g.load_package()
+w = configs.Workload("gridcarry", "stress256", 1920, 1080, 8, "sky_f32_32", frames=70)
+def render(variant, batch, knob):
+    pkg.native.debug_set('grid_carry', knob)
+    pt = make_tracer(pkg, w); pt.SetVariant(variant); pt.SetFrameBatch(batch)
+    for _ in range(w.frames): pt.Render()
+    img = pt.Result; pt.Dispose()
+    return img
+a = render(0, 64, 1); b = render(1, 1, 0)
+print(json.dumps({"same": bool((a.view(np.uint32) == b.view(np.uint32)).all())}))
+""" % (root, root)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    assert json.loads(p.stdout.strip().splitlines()[-1])["same"]

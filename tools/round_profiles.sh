@@ -12,7 +12,7 @@
 # (Round 4: replaces run_round_profiles.sh, run_round_profiles_reduced.sh, profile_extra_configs.sh, unchained_stats.sh and
 # collect_round_profiles.sh.)
 R=/root/repo
-MODE=${1:-run}; RND=${2:-r04}; QUICK=${3:-}
+MODE=${1:-run}; RND=${2:-r05}; QUICK=${3:-}
 cd $R
 # tag | workload key | bench args          (first block: all passes; second block: stats + FETCH/WRITE + SQ only, shorter)
 MAIN=("default|default_1920x1080_d8_spp1_atmosphere256_g1|"
@@ -27,7 +27,8 @@ EXTRA=("sky2048|default_1920x1080_d8_spp1_sky2048_g1|--env sky2048"
        "4k|default_3840x2160_d8_spp1_atmosphere256_g1_strong4k|--strong-4k"
        "variant14|default_1920x1080_d8_spp1_atmosphere256_g1_variant14|--variant 14"
        "C3nogrid|stress256_1920x1080_d8_spp1_atmosphere256_g1_nogrid|--config C3 --tune no_sphere_grid=1"
-       "nocarry|default_1920x1080_d8_spp1_atmosphere256_g1_nocarry|--tune carry_last=0")
+       "nocarry|default_1920x1080_d8_spp1_atmosphere256_g1_nocarry|--tune carry_last=0"
+       "C3gridcarry|stress256_1920x1080_d8_spp1_atmosphere256_g1_gridcarry|--config C3 --tune grid_carry=1")
 
 if [ "$MODE" = collect ]; then
   mkdir -p profiles/$RND
@@ -36,7 +37,8 @@ if [ "$MODE" = collect ]; then
   done
   for f in ${RND}_default_stats_unchained_timed.json pytest_gpu.log smoke.log bench_configs.jsonl driver_command_bench.json emulate_strong.json present_rate.json present_rate_group2.json \
            bench_2ranks_one_gpu.json bench_8ranks_one_gpu.json short_runs.log handover_stress.log fuzz.log profile_sections.log \
-           ${RND}_default_kernel_stats_unchained.csv ${RND}_default_stats_unchained.json; do
+           ${RND}_default_kernel_stats_unchained.csv ${RND}_default_stats_unchained.json handover_zero_budget.log atmosphere_profile.log \
+           atmosphere_pmc_1024.csv bench_default.json; do
     [ -f gpurun_out/$RND/$f ] && cp gpurun_out/$RND/$f profiles/$RND/$f
   done
   ls profiles/$RND
@@ -100,4 +102,17 @@ N=12000; NM=5000; F1=600; F2=400; F4=1000; if [ "$QUICK" = --quick ]; then N=300
 { echo "== general"; timeout 600 python tools/fuzz_parity.py $F1 301; echo "== FUZZ_FOCUS=pipelining"; FUZZ_FOCUS=pipelining timeout 600 python tools/fuzz_parity.py $F2 302;
   echo "== FUZZ_FOCUS=pipelining FUZZ_BIAS=group_spp under the audit build"; MI355PT_LIB=$R/opentk-pathtracer_amd/libmi355pt_audit.so FUZZ_FOCUS=pipelining FUZZ_BIAS=group_spp timeout 600 python tools/fuzz_parity.py $F2 303;
   echo "== FUZZ_FOCUS=grid"; FUZZ_FOCUS=grid timeout 600 python tools/fuzz_parity.py $F4 304; } 2>&1 | grep -v amdgpu.ids > gpurun_out/$RND/fuzz.log
-tail -3 gpurun_out/$RND/pytest_gpu.log; grep "handover_stress:\|==" gpurun_out/$RND/handover_stress.log; grep "cases,\|==" gpurun_out/$RND/fuzz.log; grep "ms per" gpurun_out/$RND/present_rate.log; tail -14 gpurun_out/$RND/bench_configs.log
+# round 5: the hand-over bound with a ZERO budget (every wait abandons its launch: the repair path as the common path) on the four builds + spp > 1
+{ for L in "" _audit _chaos _audit_chaos; do echo "== libmi355pt$L.so --tune handover_budget_ms=0"; timeout 900 tools/handover_stress.bin opentk-pathtracer_amd/libmi355pt$L.so $((N / 2)) $((800 + ${#L})) --tune handover_budget_ms=0 | grep -v "^\.\.\."; done
+  echo "== multisample, zero budget, batch-pass kernel forced onto tiny images"
+  timeout 600 tools/handover_stress.bin opentk-pathtracer_amd/libmi355pt_audit_chaos.so $NM 811 --multisample --tune batch_pass_min_tiles=0 --tune handover_budget_ms=0 | grep -v "^\.\.\."
+  echo "== multisample, zero budget, in-lane sample chain"
+  timeout 600 tools/handover_stress.bin opentk-pathtracer_amd/libmi355pt.so $NM 812 --multisample --tune handover_budget_ms=0 | grep -v "^\.\.\."
+  echo "== fresh handle per case, 1 ms budget"
+  timeout 600 tools/handover_stress.bin opentk-pathtracer_amd/libmi355pt.so 1000 813 --fresh --tune handover_budget_ms=1 --tune handover_check_us=50 | grep -v "^\.\.\."; } > gpurun_out/$RND/handover_zero_budget.log 2>&1
+# round 5: the atmosphere kernel on its own (library timer) + one PMC pass at 1024^2
+{ for sz in 256 1024 2048; do python tools/atmo_profile.py $sz $((sz > 1000 ? 3 : 16)); done
+  ( cd /tmp; rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU --output-format csv -d $R/gpurun_out/prof_${RND}_atmo -o pmc -- python $R/tools/atmo_profile.py 1024 2 > /dev/null 2>&1 )
+  grep atmo $R/gpurun_out/prof_${RND}_atmo/pmc_counter_collection.csv > gpurun_out/$RND/atmosphere_pmc_1024.csv; } 2>&1 | grep -v amdgpu.ids > gpurun_out/$RND/atmosphere_profile.log
+cp gpurun_out/$RND/${RND}_default_bench.json gpurun_out/$RND/bench_default.json 2>/dev/null
+tail -3 gpurun_out/$RND/pytest_gpu.log; grep "handover_stress:\|==\|hand-over bound" gpurun_out/$RND/handover_zero_budget.log; cat gpurun_out/$RND/atmosphere_profile.log; grep "handover_stress:\|==" gpurun_out/$RND/handover_stress.log; grep "cases,\|==" gpurun_out/$RND/fuzz.log; grep "ms per" gpurun_out/$RND/present_rate.log; tail -14 gpurun_out/$RND/bench_configs.log
