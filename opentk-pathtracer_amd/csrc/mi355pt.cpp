@@ -1128,7 +1128,10 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     // frames simply stay pending — the GPU has two launches' worth of work queued, nothing idles — and whichever call comes next
     // looks again.  Only a host that runs more than 16 launches ahead is held, for at most 2 ms per call, and then queues the batch
     // behind its predecessor.
-    if (ptimpl::launch_ready(h)) return ptimpl::flush_frames_bounded(h, 0, 1);
+    // (a small share — fewer than 12,000 tiles — never waited: its launches go behind each other unless the predecessor happens to be
+    // resident, which is what it measures best with: tools/emulate_strong.py)
+    const bool bigShare = (long long)((h->width + 7) / 8) * ((h->rows + 7) / 8) >= 12000;
+    if (!bigShare || ptimpl::launch_ready(h)) return ptimpl::flush_frames_bounded(h, 0, 1);
     if (h->pendingFrames >= 16 * limit) return ptimpl::flush_frames_bounded(h, pt::tuning().renderWaitUs, 1);
     return PT_OK;
 }
