@@ -203,6 +203,24 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                     const __attribute__((address_space(4))) unsigned long long *tm =
                         (const __attribute__((address_space(4))) unsigned long long *)ca->tileMasks + (size_t)tile * kTileMaskWords;
                     masks[0] = tm[0]; masks[1] = tm[1]; masks[2] = tm[2]; masks[3] = tm[3]; masks[4] = tm[4];
+                } else if (fromQueue && ca->tileMasks != nullptr) {
+                    // Continuations of a few tiles (round 5): a tile's cached masks hold every primary ray the tile can EVER cast — any sample's
+                    // jitter and lens point — so the union of the masks of the tiles present in this bundle bounds the bundle: spheres AND
+                    // cuboids culled (the cone fitted to the rays themselves culls no cuboids and is wide for a mixed bundle), for a
+                    // handful of scalar loads per distinct tile.  More than 8 distinct tiles: the cone, as before.
+                    masks[0] = masks[1] = masks[2] = masks[3] = masks[4] = 0ull;
+                    const int myTile = ((tpix >> 16) >> 3) * ca->tilesX + ((tpix & 0xffff) >> 3);
+                    unsigned long long rem = __ballot(valid);
+                    int distinct = 0;
+                    while (rem != 0ull && distinct < 8) {
+                        const int t = __builtin_amdgcn_readlane(myTile, (int)__builtin_ctzll(rem));
+                        const __attribute__((address_space(4))) unsigned long long *tm =
+                            (const __attribute__((address_space(4))) unsigned long long *)ca->tileMasks + (size_t)t * kTileMaskWords;
+                        masks[0] |= tm[0]; masks[1] |= tm[1]; masks[2] |= tm[2]; masks[3] |= tm[3]; masks[4] |= tm[4];
+                        rem &= ~__ballot(valid && myTile == t);
+                        distinct++;
+                    }
+                    if (rem != 0ull) cull_spheres(sc, a.numSpheres, valid, to, td, masks);
                 } else {
                     cull_spheres(sc, a.numSpheres, valid, to, td, masks); // (continuations of several tiles: bounded from the rays themselves)
                 }
