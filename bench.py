@@ -524,7 +524,10 @@ def main():
                    "devices_used": devices_used, "steady": steady, "per_frame": per_frame, "displayed": displayed, "group": group,
                    "checks": {"finite": bool(torch.isfinite(full).all().item()), "alpha_one": bool((full[..., 3] == 1).all().item()),
                               "mean_radiance": round(float(full[..., :3].mean().item()), 5)},
-                   "basic": basic, "env_cpu": (pt.ReadEnvironment() if env_name != "sky2048" else None)}
+                   "basic": basic, "env_cpu": (pt.ReadEnvironment() if env_name != "sky2048" else None),
+                   # hand-over bound (csrc/pt_kernel_common.hpp): what the repair passes of THIS rank's handle did during the whole run —
+                   # all zero unless a launch was abandoned (a contended device)
+                   "handover": pkg.native.debug_handover_stats(pt._h)}
         del full
         pt.Dispose()
         return res
@@ -611,6 +614,7 @@ def main():
             "displayed_frame": m["displayed"],
             "clock_warmup_ms": args.clock_warmup_ms,
             "checks": m["checks"],
+            "handover_bound": m["handover"],
         }
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note

@@ -26,7 +26,7 @@ struct Tuning {
     int shortWorkgroupsPerCU = 5;  // workgroups per CU of launches of fewer than 8 frames
     long chainWaitUs = 60000;      // back-pressure: how long a launch issued by a BLOCKING entry point waits for its predecessor to become resident
     long renderWaitUs = 2000;      // ... and the most pt_render itself ever waits (only when the host is 16 launches ahead)
-    long handoverBudgetMs = 2000;  // hand-over bound: a result that has waited this long (wall clock) for its pixel's previous frame abandons its launch
+    long handoverBudgetMs = 500;   // hand-over bound: a result that has waited this long (wall clock) for its pixel's previous frame abandons its launch
     long handoverCheckUs = 1000;   // ... and how often a waiting wavefront looks at the abandon word and at its own waits
     // kernel selection (pt_integrate_persistent.hip: launch_integrate)
     int parkedMax = -1;            // >= 0: parked resolves per wavefront

@@ -44,7 +44,7 @@ def _stress(pkg, lib, cases, seed, *extra, timeout=900):
 
 
 def test_undisturbed_runs_never_repair(pkg, native_lib):
-    """The default budget (2 s): on a GPU of its own no launch is ever abandoned — the repair passes behind the joins are no-ops."""
+    """The default budget (0.5 s): on a GPU of its own no launch is ever abandoned — the repair passes behind the joins are no-ops."""
     pairs, joins, seen = _stress(pkg, pkg.native.LIB_PATH, 400, 511)
     assert (pairs, joins, seen) == (0, 0, 0)
 
@@ -194,6 +194,6 @@ a, sa = render(0, None)
 b, sb = render(0, 7)
 want, _ = render(1, 1)
 print(json.dumps({"auto": bool((a.view(np.uint32) == want.view(np.uint32)).all()), "reset": bool((b.view(np.uint32) == want.view(np.uint32)).all()), "stats": [sa, sb]}))
-""", budget=2000)
+""", budget=500)
     assert out["auto"] and out["reset"], out
     assert all(s["pairs_repaired"] == 0 and s["inconsistent"] == 0 for s in out["stats"]), out
