@@ -39,7 +39,7 @@ def test_render_returns_promptly_while_the_gpu_is_launches_behind(pkg, native_li
     print(f"pt_render: max {1e3 * times.max():.3f} ms, 99.9th percentile {1e3 * np.quantile(times, 0.999):.3f} ms, median {1e6 * np.median(times):.1f} us; "
           f"pt_synchronize afterwards {1e3 * t_sync:.1f} ms")
     assert times.max() < 6e-3, f"a pt_render call took {1e3 * times.max():.2f} ms"
-    assert np.quantile(times, 0.99) < 1e-3
+    assert np.quantile(times, 0.95) < 1e-3  # (once the host is 16 launches ahead one call in 64 waits its bounded 2 ms)
     assert np.isfinite(img).all() and (img[..., 3] == 1).all()
 
 
