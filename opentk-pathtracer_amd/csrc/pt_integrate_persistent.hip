@@ -1036,7 +1036,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
             if (nwg > numChunks) nwg = numChunks;
             if (nwg < 1) nwg = 1;
         }
-        bool carry = spp1 && (!useGrid || gridCarry) && !perWaveTimeline && tiles >= tune.carryMinTiles && tune.carryLast != 0 && a.drainCompaction == 0;
+        bool carry = spp1 && (!useGrid || gridCarry) && !perWaveTimeline && tiles >= 12000 && tune.carryLast != 0 && a.drainCompaction == 0;
         auto queue_bytes = [&](bool c) -> size_t {
             if (useBatchPass) return (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry));
             return (spp1 ? frame_weight_bytes(a.batchFrames) : 0) +

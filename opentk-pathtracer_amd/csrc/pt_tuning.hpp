@@ -39,7 +39,6 @@ struct Tuning {
     int tileMasks = 1;             // 0: the tile pass always culls the spheres against its own 64 rays (no cached per-tile masks)
     int logLaunch = 0;             // n > 0: the next n persistent launches print their kernel choice and LDS budget to stderr
     int carryLast = 1;             // 0: the pixel never travels with its path (every resolve loads it; the kernel of rounds 1-3)
-    int carryMinTiles = 12000;     // tiles per frame from which a launch carries the pixel with the path (smaller shares park waiting results instead)
     int gridCarry = 0;             // 1: sphere-grid scenes carry the pixel too, at five workgroups per CU (round 5 experiment)
     // sphere grid build (pt_sphere_grid.hpp)
     int gridMinSpheres = 64;       // scenes with fewer spheres get no grid
@@ -84,7 +83,6 @@ inline bool tuning_set(const char *key, long long v)
     PT_KNOB("force_lean_lds", forceLeanLds)
     PT_KNOB("carry_last", carryLast)
     PT_KNOB("grid_carry", gridCarry)
-    PT_KNOB("carry_min_tiles", carryMinTiles)
     PT_KNOB("log_launch", logLaunch)
     PT_KNOB("tile_masks", tileMasks)
     PT_KNOB("grid_min_spheres", gridMinSpheres)
