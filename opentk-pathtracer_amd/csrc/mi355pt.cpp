@@ -1132,7 +1132,20 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     // resident, which is what it measures best with: tools/emulate_strong.py)
     const bool bigShare = (long long)((h->width + 7) / 8) * ((h->rows + 7) / 8) >= 12000;
     if (!bigShare || ptimpl::launch_ready(h)) return ptimpl::flush_frames_bounded(h, 0, 1);
-    if (h->pendingFrames >= 16 * limit) return ptimpl::flush_frames_bounded(h, pt::tuning().renderWaitUs, 1);
+    if (h->pendingFrames >= 16 * limit) {
+        // a host that runs this far ahead is paced: the call waits (at most render_wait_us = 2 ms) for the moment the batch can start beside
+        // its predecessor and launches it then; if that moment does not come in time the frames simply stay pending — never a launch BEHIND
+        // the predecessor from here (that order costs a drain + ramp per launch: 1.4 % at 1080p; measured as a 2.4 % lower steady rate
+        // when this path still did it)
+        const long limitUs = pt::tuning().renderWaitUs;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            if (ptimpl::launch_ready(h)) return ptimpl::flush_frames_bounded(h, 0, 1);
+            const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (waited >= limitUs) break;
+            std::this_thread::sleep_for(std::chrono::microseconds(waited > 200 ? 50 : 5));
+        }
+    }
     return PT_OK;
 }
 

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
     // what is timed is "this wavefront has done nothing but wait since" (0: some lane traced in the last iteration)
     HandoverBound bound;
     bound.init();
-    unsigned int stallSince = 0u, noLaneWait = 0u;
+    unsigned int stallSince = 0u;
     auto qslot = [&](int i) -> int { // slot of the i-th parked continuation
         int sl = qhead + i;
         return sl >= parkCapacity ? sl - parkCapacity : sl;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         bool active = pix >= 0;
         if (__ballot(active) == 0ull) {
             if (exhausted && avail == 0 && parked == 0) break;
-            (void)bound.tick(false, noLaneWait, stallSince, true); // (only waiting records left in the queue: they are retried — or, abandoned, dropped — by the batch passes above)
+            if (bound.tick(0ull, stallSince, true)) stop_queue(&queue); // (only waiting records left in the queue: they are retried — or, abandoned, dropped — by the batch passes above)
             if (parked > 0 && avail == 0) __builtin_amdgcn_s_sleep(8);
             continue;
         }
@@ -333,8 +333,12 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         }
         // (a wavefront that has done nothing but wait for FrameArgs::waitBudget abandons the launch: waiting records move between lanes,
         // ring and queue, so the bound is kept per wavefront, not per lane)
+        // ... and a result that sits in a lane is timed like the spp = 1 kernel's: the same lanes waiting for the whole budget.  (Any waiting
+        // lane also makes the wavefront look at the abandon word now and then: an abandoned launch stops drawing tickets.)
         const bool nothingTraced = __ballot(pix >= 0 && !pending) == 0ull;
-        if (nothingTraced || stallSince != 0u) (void)bound.tick(false, noLaneWait, stallSince, nothingTraced);
+        const unsigned long long laneWaits = __ballot(pix >= 0 && pending && !needRay);
+        if (nothingTraced || stallSince != 0u || laneWaits != 0ull)
+            if (bound.tick(laneWaits, stallSince, nothingTraced)) stop_queue(&queue);
         if (active && needRay) { // fallback (queue was full): the next sample's primary ray, generated in the lane
             const int pxy = pixel_xy(pix);
             primary_ray(a, pxy & 0xffff, pxy >> 16, seed, ro, rd);

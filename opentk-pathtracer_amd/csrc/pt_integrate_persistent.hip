@@ -375,10 +375,9 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     // GRID kernels: the parameter from which the grid walk of the current bounce continues (>= 0 while it is unfinished, else -1:
     // pt_device.hpp, WALK SLICES); dead in the other kernels
     float walkFrom = -1.0f, walkFresh = -1.0f;
-    // wait_clock() | 1 at the lane's first failed resolve (0: not waiting); every site that loads a path into the lane goes through
-    // begin_path(), which resets both
-    unsigned int waitSince = 0u;
-    auto begin_path = [&]() -> void { pending = false; walkFrom = -1.0f; waitSince = 0u; };
+    // every site that loads a path into the lane goes through begin_path() (the wait of a finished path for its pixel's previous frame is
+    // timed per wavefront: HandoverBound)
+    auto begin_path = [&]() -> void { pending = false; walkFrom = -1.0f; };
     // (CARRY: bit 14 of fj = the lane's slot of laneLast holds the pixel's accumulation value as the tile pass read it)
 
     // compute.glsl:125-129 for one finished path of frame `rfj` of the batch.  False = the pixel still holds an older
@@ -621,7 +620,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         if (e.bounce & PATH_HAS_LAST) fj |= 0x4000;
                         laneLast[0] = e.last[0]; laneLast[64] = e.last[1]; laneLast[128] = e.last[2];
                     }
-                    begin_path();
+                    pending = false;   // (= begin_path(), written out: through the lambda the compiler copies the 16 registers of path state
+                    walkFrom = -1.0f;  //  twice per pop-loop round — 2.4 M of 110 M vector instructions per 1080p frame)
                     seed = e.seed;
                     ro = V(e.ro[0], e.ro[1], e.ro[2]);
                     rd = V(e.rd[0], e.rd[1], e.rd[2]);
@@ -708,8 +708,10 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             if (parking && nparked > 0) { // nothing to trace: look after the parked resolves (they must be gone before leaving)
                 service_parked();
                 if (nparked > 0) {
-                    unsigned int none = 0u;
-                    if (bound.tick(false, none, parkSince, !parkProgress)) nparked = 0; // (abandoned launch: the host's repair pass renders them)
+                    if (bound.tick(0ull, parkSince, !parkProgress)) { // (abandoned launch: the host's repair pass renders them)
+                        nparked = 0;
+                        stop_queue(&queue);
+                    }
                 }
                 if (nparked > 0 && exhausted && avail == 0) __builtin_amdgcn_s_sleep(8);
             }
@@ -827,12 +829,13 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
             const bool waits = pix >= 0 && pending;
             const unsigned long long waitMask = __ballot(waits);
             if (waitMask != 0ull || nparked > 0) {
-                if (bound.tick(waits, waitSince, parkSince, nparked > 0 && !parkProgress)) {
+                if (bound.tick(waitMask, parkSince, nparked > 0 && !parkProgress)) {
                     if (waits) {
                         pix = -1;
                         pending = false;
                     }
                     nparked = 0;
+                    stop_queue(&queue);
                 } else if (__ballot(pix >= 0 && !pending) == 0ull && avail == 0) {
                     __builtin_amdgcn_s_sleep(8); // nothing but waiting paths left in this wavefront: do not hammer the pixel
                 }
@@ -871,13 +874,15 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         }
         {
             const bool waits = pix >= 0 && pending;
-            if (__ballot(waits) != 0ull) {
+            const unsigned long long waitMask = __ballot(waits);
+            if (waitMask != 0ull) {
                 unsigned int noList = 0u;
-                if (bound.tick(waits, waitSince, noList, false)) { // (abandoned launch: waiting results are dropped, the host's repair pass renders them)
+                if (bound.tick(waitMask, noList, false)) { // (abandoned launch: waiting results are dropped, the host's repair pass renders them)
                     if (waits) {
                         pix = -1;
                         pending = false;
                     }
+                    stop_queue(&queue);
                 } else if (__ballot(pix >= 0 && !pending) == 0ull) {
                     __builtin_amdgcn_s_sleep(8);
                 }

@@ -129,25 +129,40 @@ PT_DEV void abandon_launch()
         __hip_atomic_fetch_or((unsigned int *)ca->errorWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-// Wave-uniform state of the bound.  tick() is called once per iteration in which something of the wavefront waits (lanes: `waits`, with
-// the lane's waitSince; lists: listSince = 0 when the list is empty or made progress); returns true when waiting results must be DROPPED.
+// Wave-uniform state of the bound.  tick() is called once per iteration in which something of the wavefront waits: waitMask = the lanes
+// whose result waits in the lane (timed per WAVEFRONT: "the same lanes have been waiting since" — a set of waiting lanes that changes is
+// progress; a lane that can never be served belongs to an abandoned chain, which the periodic look at the abandon word finds);
+// listSince / listStuck = a parked list (0 / false when it is empty or made progress).  Returns true when waiting results must be DROPPED.
+// Only every 64th call reads the clock (s_memrealtime is a scalar memory instruction: the wavefront would wait for it in every
+// iteration in which one lane waits — measured: +35 % in the resolve section of the default kernel); the calls between cost a few scalar
+// instructions.  An iteration takes 1 us (a wavefront that only waits) to 20 us: the clock is looked at every 0.1 - 1 ms.
 struct HandoverBound {
     unsigned int nextCheck; // wait_clock() value from which the abandon word is looked at again
+    unsigned int laneSince; // wait_clock() | 1 of the first clock reading since which the set of waiting lanes looked the same (0: nobody waited)
+    unsigned int lastLanes; // ... that set at the last clock reading, folded to 32 bits
+    unsigned int calls;     // tick() calls (only every 64th reads the clock)
+    bool listMoved;         // the parked list made progress (or was empty) in some call since the last clock reading
     bool abandoned;         // latched
-    PT_DEV void init() { nextCheck = wait_clock(); abandoned = false; }
-    PT_DEV bool tick(bool waits, unsigned int &waitSince, unsigned int &listSince, bool listStuck)
+    PT_DEV void init() { nextCheck = wait_clock(); laneSince = 0u; lastLanes = 0u; calls = 0u; listMoved = false; abandoned = false; }
+    PT_DEV bool tick(unsigned long long waitMask, unsigned int &listSince, bool listStuck)
     {
+        if (abandoned) return true;
+        listMoved = listMoved || !listStuck;
+        if ((++calls & 63u) != 0u) return false;
+        // ---- every 64th call: read the clock, compare what waits now with what waited at the last reading
         const unsigned int now = wait_clock();
-        if (waits && waitSince == 0u) waitSince = now | 1u;
-        if (!listStuck) listSince = 0u;
+        const unsigned int lanes = (unsigned int)waitMask ^ (unsigned int)(waitMask >> 32) ^ (waitMask != 0ull ? 0x80000000u : 0u);
+        if (lanes != lastLanes || waitMask == 0ull) laneSince = waitMask != 0ull ? (now | 1u) : 0u; // (changed: progress; the clock starts again)
+        lastLanes = lanes;
+        if (listMoved) listSince = 0u;
         else if (listSince == 0u) listSince = now | 1u;
-        if (!abandoned && (int)(now - nextCheck) >= 0) { // (wave-uniform, taken once per waitCheckInterval)
+        listMoved = false;
+        if ((int)(now - nextCheck) >= 0) { // (taken once per waitCheckInterval)
             ColdArgs ca = cold_args();
             nextCheck = now + ca->waitCheckInterval;
             // (signed differences: a start time is stored with its lowest bit set — 0 means "not waiting" — and may lie one unit ahead)
             const int budget = (int)ca->waitBudget;
-            const bool expired = (waits && (int)(now - waitSince) > budget) || (listSince != 0u && (int)(now - listSince) > budget);
-            if (__ballot(expired) != 0ull) {
+            if ((laneSince != 0u && (int)(now - laneSince) > budget) || (listSince != 0u && (int)(now - listSince) > budget)) {
                 abandon_launch();
                 abandoned = true;
             } else {
@@ -223,6 +238,12 @@ struct BlockQueue {            // one per workgroup, in static LDS
 PT_DEV unsigned int lds_load(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PT_DEV unsigned long long lds_load64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PT_DEV void lds_store(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// an abandoned launch hands out no more work: a wavefront that notices closes its workgroup's queue (the tiles of the chunk it holds are
+// still rendered; what the launch leaves undone is re-rendered by the host's repair pass, which also resets the ticket counters)
+PT_DEV void stop_queue(BlockQueue *q)
+{
+    if ((threadIdx.x & 63) == 0) lds_store(&q->done, 1u);
+}
 
 // n / d and n % d for wave-uniform n < 2^31 with the host's magic = floor(2^32 / d) (d = 1: 2^32 - 1): the estimate mul_hi(n, magic) is the
 // quotient or one less, so ONE correction step makes it exact — 6 scalar instructions where the compiler's division expands to 25.
@@ -263,9 +284,9 @@ PT_DEV int queue_pop_tile(BlockQueue *q)
                 ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
                 const long long first = ((ca->tagged ? 0ll : (long long)gridDim.x) + ticket) * chunk; // tagged launches have no static chunks
                 const long long last = first + chunk < numTiles ? first + chunk : numTiles;
-                // (an abandoned launch hands out no more work: what it leaves undone is re-rendered by the host's repair pass — the ticket
-                // just drawn is simply not used, the host resets the counters after a repair)
-                if (first >= numTiles || (ca->tagged && launch_abandoned())) {
+                // (an abandoned launch: the wavefronts that notice — every one that waits — close their workgroup's queue themselves,
+                // stop_queue() below; the refill path stays as it was)
+                if (first >= numTiles) {
                     if (leader) lds_store(&q->done, 1u);
                 } else {
                     if (leader) atomicExch(&q->pair, ((unsigned long long)last << 32) | (unsigned long long)first);

@@ -240,6 +240,8 @@ def debug_handover_stats(handle) -> dict:
     """Counters of the hand-over bound (csrc/pt_kernel_common.hpp) through pt_debug_handover_stats — exported, not in the public header.
     Drains the handle.  `inconsistent` must stay 0."""
     L = load()
+    if not hasattr(L, "pt_debug_handover_stats"):  # (an A/B library of an earlier round, MI355PT_LIB)
+        return {"pairs_repaired": None, "inconsistent": None, "joins_with_repairs": None, "flag_seen": None}
     L.pt_debug_handover_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
     L.pt_debug_handover_stats.restype = C.c_int
     out = (C.c_uint * 4)()
