@@ -6,8 +6,9 @@ raised error -5): the launch is ABANDONED, drops what still waits, and the host 
 behind the next join of the handle's streams (pt_repair_kernel) — so `PathTracer.Render()` cannot fail
 (reference: src/Render/PathTracer.cs:114-123) and every image is the one an undisturbed launch leaves.
 
-The tests force the rare path to be the common one: tuning knob handover_budget_ms = 0 makes every result that has to wait at all
-abandon its launch, so every mechanism behind it (ticket stop, dropped results, repair passes in launch order, tile flags, counter
+The tests force the rare path to be the common one: tuning knob handover_budget_ms = 0 makes a wavefront abandon its launch as soon as
+two consecutive clock readings (64 waiting iterations apart) find the same lanes waiting or a parked list that resolved nothing in
+between, so every mechanism behind it (ticket stop, dropped results, repair passes in launch order, tile flags, counter
 reset, snapshot presents tone-mapped again) runs thousands of times and must still deliver the reference kernel's bits.
 Run with `pytest -m gpu` on an MI355X.  Nothing here reads /root/reference.
 """
@@ -50,7 +51,7 @@ def test_undisturbed_runs_never_repair(pkg, native_lib):
 
 
 def test_zero_budget_every_wait_abandons_and_the_images_stay_exact(pkg, native_lib):
-    """handover_budget_ms = 0: a result that waits at all abandons its launch.  1,200 random call sequences (pipelined launches of up to
+    """handover_budget_ms = 0: a wait that outlasts two clock readings abandons its launch.  1,200 random call sequences (pipelined launches of up to
     200 frames on tiny images — where consecutive frames of a tile are in flight together all the time — group handles, reads,
     blocking and snapshot presents, uploads, resets, batch changes): every observed image equals the unpipelined tile-per-wave render,
     and the repair passes really ran."""
@@ -123,7 +124,10 @@ want, st1 = render(1, 1)
 print(json.dumps({"same": bool((got.view(np.uint32) == want.view(np.uint32)).all()), "stats": st, "plain": st1}))
 """)
     assert out["same"], out
-    assert out["stats"]["pairs_repaired"] > 0 and out["stats"]["inconsistent"] == 0, out
+    # (whether a launch is abandoned here depends on timing: a share this size parks its waiting results and the lists keep moving; the
+    # stress tests above are the ones that must see repairs.  What must hold either way: bit-identical, no inconsistent pixel.)
+    print("1/8 share, zero budget:", out["stats"])
+    assert out["stats"]["inconsistent"] == 0, out
     assert out["plain"]["pairs_repaired"] == 0, out
 
 

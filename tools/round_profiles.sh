@@ -102,7 +102,7 @@ N=12000; NM=5000; F1=600; F2=400; F4=1000; if [ "$QUICK" = --quick ]; then N=300
 { echo "== general"; timeout 600 python tools/fuzz_parity.py $F1 301; echo "== FUZZ_FOCUS=pipelining"; FUZZ_FOCUS=pipelining timeout 600 python tools/fuzz_parity.py $F2 302;
   echo "== FUZZ_FOCUS=pipelining FUZZ_BIAS=group_spp under the audit build"; MI355PT_LIB=$R/opentk-pathtracer_amd/libmi355pt_audit.so FUZZ_FOCUS=pipelining FUZZ_BIAS=group_spp timeout 600 python tools/fuzz_parity.py $F2 303;
   echo "== FUZZ_FOCUS=grid"; FUZZ_FOCUS=grid timeout 600 python tools/fuzz_parity.py $F4 304; } 2>&1 | grep -v amdgpu.ids > gpurun_out/$RND/fuzz.log
-# round 5: the hand-over bound with a ZERO budget (every wait abandons its launch: the repair path as the common path) on the four builds + spp > 1
+# round 5: the hand-over bound with a ZERO budget (a wait that outlasts two clock readings abandons its launch: the repair path as a common path) on the four builds + spp > 1
 { for L in "" _audit _chaos _audit_chaos; do echo "== libmi355pt$L.so --tune handover_budget_ms=0"; timeout 900 tools/handover_stress.bin opentk-pathtracer_amd/libmi355pt$L.so $((N / 2)) $((800 + ${#L})) --tune handover_budget_ms=0 | grep -v "^\.\.\."; done
   echo "== multisample, zero budget, batch-pass kernel forced onto tiny images"
   timeout 600 tools/handover_stress.bin opentk-pathtracer_amd/libmi355pt_audit_chaos.so $NM 811 --multisample --tune batch_pass_min_tiles=0 --tune handover_budget_ms=0 | grep -v "^\.\.\."
