@@ -21,7 +21,7 @@ Workload = BASELINE.json's metric ("@1080p 8-bounce default scene, 1/2/4/8 GPU")
   N = 1  BASELINE configs[1] (--config C2): default scene (48 spheres + 7 cuboids), 1920x1080, 8 bounces, 1 spp, the
          reference's default environment (256^2 RGBA32F atmosphere cube, computed by the atmosphere kernel).
   N > 1  the SAME 1920x1080 image row-tiled over the N GPUs (STRONG scaling, "scaling": "strong"): one process per GPU,
-         block-cyclic 16-row bands (floor rows cost ~2x sky rows), no data-path collective; the RCCL gather happens only at
+         block-cyclic 8-row bands (one tile row each) (floor rows cost ~2x sky rows), no data-path collective; the RCCL gather happens only at
          present time and is timed separately (`present_ms`).  value = all pixels x spp x steps / max-over-ranks wall time.
          The same run then measures BASELINE configs[3] — ONE 3840x2160 image over the N GPUs — and reports it inside the
          same JSON line as "configs3_4k" (the driver's contract is one line).
@@ -60,7 +60,8 @@ ALGO_BYTES_PER_PIXEL_FRAME = 32  # SURVEY.md section 8d / BASELINE.md section 4
 WEAK_SIZES = {1: (1920, 1080), 2: (2720, 1530), 4: (3840, 2160), 8: (5440, 3060)}
 # BASELINE.json configs by name: (scene, depth, env, BASELINE index)
 CONFIGS = {"C2": ("default", 8, "atmosphere256", 1), "C3": ("stress256", 8, "atmosphere256", 2), "C5": ("glass", 32, "atmosphere256", 4)}
-BAND = 16  # block-cyclic 16-row bands across ranks: row cost varies ~2x between sky and floor rows
+BAND = 8   # block-cyclic bands of ONE tile row (8 image rows) across ranks: row cost varies ~2x between sky and floor rows, and 1080 rows are
+           # 135 tile rows — 8 GPUs own 16 or 17 of them (136 rows at most; 16-row bands gave the largest share 144 rows: 6.7 % over the mean)
 
 
 def weak_image_size(n_gpus: int) -> tuple[int, int]:

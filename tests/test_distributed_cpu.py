@@ -71,7 +71,7 @@ def _worker(rank, world, port, height, out_path, band=0):
 
 # (8, 2160, 16): the row partition of BASELINE configs[3] — 3840x2160 over 8 GPUs in 16-row bands (135 bands: seven ranks own 17, one
 # owns 16) — at the full height and a narrow width (the partition only concerns rows), RGBA32F and RGBA8 gathers included
-@pytest.mark.parametrize("world,height,band", [(2, 36, 0), (3, 37, 0), (2, 43, 8), (8, 2160, 16), (8, 1080, 16)])
+@pytest.mark.parametrize("world,height,band", [(2, 36, 0), (3, 37, 0), (2, 43, 8), (8, 2160, 16), (8, 1080, 16), (8, 1080, 8)])
 def test_tiled_present_over_gloo(tmp_path, oracle, world, height, band):
     out = str(tmp_path / "full.npy")
     port = _free_port()

@@ -6,7 +6,8 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
-out = {"csrc_hash": pkg.native.csrc_hash(), "band_rows": 16, "results": {}}
+BAND = int(os.environ.get("EMULATE_BAND", "8"))  # rows per band of the block-cyclic split (bench.py: BAND)
+out = {"csrc_hash": pkg.native.csrc_hash(), "band_rows": BAND, "results": {}}
 sc, cam = pkg.scene.default_scene(), pkg.camera.Camera()
 only = os.environ.get("EMULATE_ONLY")  # e.g. "1920x1080:8" (tuning runs)
 for kv in filter(None, os.environ.get("EMULATE_TUNE", "").split(",")):  # e.g. "parked_max=16,batch_wg=5" (tuning runs)
@@ -23,7 +24,7 @@ for (W, H) in ((1920, 1080), (3840, 2160)):
             pt.EnvironmentMap = pkg.AtmosphericScatterer(256, pkg.camera.atmospheric_data_ubo(), pkg.camera.atmosphere_light_pos(0.5), pt)
             pt.UploadScene(sc); pt.UploadBasicData(pkg.camera.basic_data_ubo(cam, W, H))
             if world > 1:
-                pt.SetInterleavedTile(rank, world, 16)
+                pt.SetInterleavedTile(rank, world, BAND)
             t = time.perf_counter()
             fixed = int(os.environ.get("EMULATE_FIXED_WARMUP", "0"))  # counter runs: a known number of frames (n rounds of 64) instead of 80 ms
             for _ in range(fixed):
