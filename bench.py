@@ -324,6 +324,11 @@ def main():
         frames = warmup + steps
         devs = [0] * world if args.share_gpu else list(range(world))  # (--share-gpu: the same code on one device)
         gp = pkg.PathTracer(None, W, H, depth, args.spp, 20.0, 0.14, devices=devs)
+        direct = gp.GatherIsDirect
+        if not direct and not args.share_gpu:
+            gp.Dispose()
+            raise RuntimeError("pt_create_multi: no peer access between the devices (hipDeviceCanAccessPeer = 0) — the gather would be staged "
+                               "through the host; refusing to measure it (pt_multi_gather_is_direct)")
         gp.SetVariant(args.variant)
         gp.SetFrameBatch(args.frame_batch)
         if env_name == "atmosphere256":
@@ -350,7 +355,7 @@ def main():
         same = bool(np.array_equal(gimg.view(np.uint32), full.cpu().numpy().view(np.uint32))) if full is not None else None
         group = {"devices": devs, "frames": frames, "value": round(W * H * args.spp * steps / g_el / 1e6, 2), "unit": "Msamples/s",
                  "ms_per_step": round(g_el * 1e3 / steps, 5), "kernel_ms_slowest_device": round(gk / steps, 5),
-                 "read_result_ms": round(g_read, 3), "equals_rccl_gather_bit_for_bit": same,
+                 "read_result_ms": round(g_read, 3), "equals_rccl_gather_bit_for_bit": same, "gather_is_direct": direct,
                  "note": "ONE process, one pt_create_multi handle over all devices, run after the ranks' measurement while they idle"}
         gp.Dispose()
         return group
@@ -505,6 +510,84 @@ def main():
                          "unit": "Msamples/s",
                          "note": "Render(); pt_present_rgba8_async into a bound device image, two slots (a slot is waited for before it is "
                                  "reused): ACES + gamma -> RGBA8 per frame, no host copy"}
+            # (c) the reference's REAL frame loop: OnUpdateFrame re-uploads InvView and ViewPos on every focused update, moved or not
+            # (MainWindow.cs:131-132: two SubData calls), then OnRenderFrame renders and shows the frame (MainWindow.cs:40-69).  The bytes are
+            # unchanged here (a camera at rest, the progressive-accumulation case the metric is about): the library must treat them as no
+            # input change — same pipelining, same cached tile masks as (b).  Called through ctypes with prebuilt pointers: the C# host's
+            # DllImport costs less than Python's argument marshalling, which is the only thing this leg adds to (b) on the host.
+            import ctypes as C_
+            cam_blob = (C_.c_ubyte * 144).from_buffer_copy(bytes(basic))
+            p_view, p_pos = C_.c_void_p(C_.addressof(cam_blob) + 64), C_.c_void_p(C_.addressof(cam_blob) + 128)
+            up = pt._lib.pt_upload_basic_data
+
+            def show_ref(i):
+                if up(pt._h, 64, 64, p_view) or up(pt._h, 128, 16, p_pos):
+                    raise RuntimeError("pt_upload_basic_data failed")
+                show(i)
+            for s_, b_ in enumerate(bufs):
+                pt.BindPresentImage(s_, b_.data_ptr(), b_.numel())
+            seen[0] = seen[1] = False
+            for i in range(16):
+                show_ref(i)
+            pt.Synchronize()
+            t_r = time.perf_counter()
+            for i in range(n2):
+                show_ref(i)
+            for s_ in range(2):
+                pt.PresentWait(s_)
+            sync_local()
+            el_r = time.perf_counter() - t_r
+            for s_ in range(2):
+                pt.BindPresentImage(s_, None)
+            # ... and the same loop without a present (Render() only, uploads in between) under the library's automatic batching: the
+            # uploads must not break the pipelining (launches_per_step stays 1 / frames_per_launch)
+            pt.SetFrameBatch(args.frame_batch)
+            for _ in range(128):
+                up(pt._h, 64, 64, p_view); up(pt._h, 128, 16, p_pos); pt.Render()
+            pt.Synchronize()
+            n3, t_u = 960, time.perf_counter()
+            for _ in range(n3):
+                up(pt._h, 64, 64, p_view); up(pt._h, 128, 16, p_pos); pt.Render()
+            sync_local()
+            el_u = time.perf_counter() - t_u
+            # (d) a MOVING camera (MainWindow.cs:127-132: ProcessInputs moved the camera -> ResetRenderer(); the two uploads now carry new
+            # bytes): every frame is frame 0 of a new accumulation, the upload flushes, the cached masks never become valid (the tile pass
+            # culls against its own rays)
+            cam2 = pkg.camera.Camera(position=(-17.0, 3.6, -8.5), look_x=-31.0, look_y=0.5)
+            blob2 = (C_.c_ubyte * 144).from_buffer_copy(bytes(pkg.camera.basic_data_ubo(cam2, W, H)))
+            views = [(p_view, p_pos), (C_.c_void_p(C_.addressof(blob2) + 64), C_.c_void_p(C_.addressof(blob2) + 128))]
+            for s_, b_ in enumerate(bufs):
+                pt.BindPresentImage(s_, b_.data_ptr(), b_.numel())
+            seen[0] = seen[1] = False
+
+            def show_moving(i):
+                v_, p_ = views[i & 1]
+                up(pt._h, 64, 64, v_); up(pt._h, 128, 16, p_)
+                pt.ResetRenderer()
+                show(i)
+            for i in range(16):
+                show_moving(i)
+            pt.Synchronize()
+            n4, t_m = 200, time.perf_counter()
+            for i in range(n4):
+                show_moving(i)
+            for s_ in range(2):
+                pt.PresentWait(s_)
+            sync_local()
+            el_m = time.perf_counter() - t_m
+            for s_ in range(2):
+                pt.BindPresentImage(s_, None)
+            up(pt._h, 64, 64, p_view); up(pt._h, 128, 16, p_pos)
+            pt.ResetRenderer()
+            reference_loop = {"frames": n2, "ms_per_displayed_frame": round(el_r * 1e3 / n2, 5), "value": round(W * H * args.spp * n2 / el_r / 1e6, 2),
+                              "unit": "Msamples/s", "vs_displayed_frame": round(el_r / el, 4),
+                              "render_only": {"steps": n3, "ms_per_step": round(el_u * 1e3 / n3, 5), "value": round(W * H * args.spp * n3 / el_u / 1e6, 2)},
+                              "moving_camera": {"frames": n4, "ms_per_displayed_frame": round(el_m * 1e3 / n4, 5),
+                                                "note": "every frame: NEW InvView / ViewPos bytes, ResetRenderer(), Render(), present (MainWindow.cs:127-132)"},
+                              "note": "per frame: pt_upload_basic_data(64, 64) + pt_upload_basic_data(128, 16) with UNCHANGED bytes, Render(), "
+                                      "pt_present_rgba8_async into a bound device image = MainWindow.cs:131-132 + :40-69; `render_only` = the same "
+                                      "uploads between pipelined Render() calls (no present)"}
+            displayed["reference_loop"] = reference_loop
             pt.SetFrameBatch(args.frame_batch)
 
         # ---- N > 1: the same frames through ONE in-process group handle over the N devices (pt_create_multi: what the reference's
@@ -613,6 +696,7 @@ def main():
             "steady": m["steady"],
             "per_frame_launch": m["per_frame"],
             "displayed_frame": m["displayed"],
+            "reference_loop": (m["displayed"] or {}).pop("reference_loop", None),
             "clock_warmup_ms": args.clock_warmup_ms,
             "checks": m["checks"],
             "handover_bound": m["handover"],

@@ -76,7 +76,7 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out);
 PT_API int pt_destroy(pt_handle h);
 
 /* The same renderer on n_devices GPUs of this process (no reference counterpart, the reference
- * owns one GL context): the image is tiled across device_ids[0..n) in block-cyclic bands of 16 rows (balanced: rows
+ * owns one GL context): the image is tiled across device_ids[0..n) in block-cyclic bands of 8 rows = single tile rows (balanced: rows
  * near the floor cost ~2x sky rows; pt_multi_set_partition changes the band height or selects contiguous row
  * blocks), every device keeps its rows resident and renders them with global pixel coordinates, so the image is
  * bit-identical to the single-GPU one.  Nothing is exchanged per frame.  Every entry point accepts the group handle:
@@ -85,10 +85,17 @@ PT_API int pt_destroy(pt_handle h);
  * xGMI (hipMemcpyPeerAsync; each peer has its own link to the root) before the single device-to-host copy.
  * device_ids may name the same device more than once (used to test the group path on a one-GPU box).
  * Not available on a group handle (PT_E_BAD_ARGUMENT): pt_set_tile, pt_set_interleaved_tile, pt_bind_result_buffer,
- * pt_set_stream, pt_postprocess_device. */
+ * pt_set_stream, pt_postprocess_device.
+ * Peer access: the gather wants hipDeviceCanAccessPeer == 1 in both directions between device_ids[0] and every other
+ * device.  Where it is 0 (no xGMI / P2P disabled) the group is still created and renders the same bits, but its gather
+ * is staged through host memory by the HIP runtime; pt_multi_gather_is_direct reports which one the handle got, and a
+ * scaling measurement must refuse a staged group (bench.py and tools/multi_gpu_check.sh do). */
 PT_API int pt_create_multi(const int *device_ids, int n_devices, int width, int height, pt_handle *out);
+/* *out_direct = 1 when every gather copy of this handle goes over a direct peer link (always 1 for a one-GPU handle), 0 when the
+ * runtime stages it through the host (see pt_create_multi). */
+PT_API int pt_multi_gather_is_direct(pt_handle h, int *out_direct);
 /* band_rows = 0: contiguous row blocks (device g owns rows [g*H/G, (g+1)*H/G)); else a multiple of 8: block-cyclic
- * bands of that many rows (default 16).  Resets the frame counter and zeroes, like pt_set_tile. */
+ * bands of that many rows (default 8).  Resets the frame counter and zeroes, like pt_set_tile. */
 PT_API int pt_multi_set_partition(pt_handle h, int band_rows);
 /* Number of devices behind the handle (1 for pt_create handles). */
 PT_API int pt_device_count_of(pt_handle h, int *out_n_devices);

@@ -73,8 +73,17 @@ hipEvent_t next_launch_event(pt_handle h)
 
 // Hand-over repair: the launches since the last join, in launch order, behind the joined streams (call with the helper streams joined
 // into h->stream).  On the device each pass is a single load unless a launch was abandoned (pt_repair_kernel).
-static int enqueue_repairs(pt_handle h)
+static int enqueue_repairs(pt_handle h, bool flagWasDown)
 {
+    // flagWasDown (the caller has NOT just found and cleared the abandon flag): launches seen COMPLETE with the flag DOWN — read in that
+    // order: an abandoning launch raises the flag before it ends — ran to their end and need no pass: a host that joins often (a blocking
+    // present per frame) enqueues nothing at all on the usual path.  (After note_abandonment the flag is down because the HOST cleared it:
+    // then every remembered launch gets its pass.)
+    if (flagWasDown) {
+        auto flag_down = [&]() -> bool { return !(h->hostErrWord && *(volatile unsigned int *)h->hostErrWord); };
+        while (!h->unverified.empty() && hipEventQuery(h->unverified.front().done) == hipSuccess && flag_down()) h->unverified.pop_front();
+        (void)hipGetLastError(); // (hipErrorNotReady of the query is not an error)
+    }
     if (h->unverified.empty()) return PT_OK;
     for (const pt_renderer::LaunchRecord &r : h->unverified) PT_HIP(h, pt::launch_repair(r.a, h->dRepairCtl, h->stream));
     PT_HIP(h, pt::launch_repair_done(h->dAbandon, h->dQueue, h->stripeQueueBase[0], h->dQueue + kChainQueueWord, h->chainQueueBase,
@@ -90,6 +99,8 @@ static void note_abandonment(pt_handle h)
     *(volatile unsigned int *)h->hostErrWord = 0;
     h->abandonEpoch++;
     h->overlapHoldoff = 256;
+    h->repairPendingAll = true; // (the flag is down again because the host cleared it: the launches remembered now all get their repair pass)
+    h->repairCheckDue = true; // the next blocking call looks at what the repair passes found (settle_handover)
 }
 
 int join_stripes(pt_handle h, bool repairNow)
@@ -119,8 +130,10 @@ int join_stripes(pt_handle h, bool repairNow)
     // h->stream next and then calls settle_handover() leaves it to that — unless the image still carries tags: the alpha pass that
     // follows such a join would wipe out what the repair reads.
     if (!h->unverified.empty() && (repairNow || h->tagsLive)) {
-        if (h->hostErrWord && *(volatile unsigned int *)h->hostErrWord) note_abandonment(h);
-        if (int rc = enqueue_repairs(h)) return rc;
+        const bool raised = h->hostErrWord && *(volatile unsigned int *)h->hostErrWord;
+        if (raised) note_abandonment(h);
+        if (int rc = enqueue_repairs(h, !raised && !h->repairPendingAll)) return rc;
+        h->repairPendingAll = false;
     }
     return PT_OK;
 }
@@ -133,11 +146,23 @@ int settle_handover(pt_handle h)
         note_abandonment(h);
         // (the launches the flag belongs to may already have been repaired by an earlier join; then nothing is left to do here)
         if (!h->unverified.empty()) {
-            if (int rc = enqueue_repairs(h)) return rc;
+            if (int rc = enqueue_repairs(h, false)) return rc;
+            h->repairPendingAll = false;
             PT_HIP(h, hipStreamSynchronize(h->stream));
         }
     }
     h->unverified.clear();
+    if (h->repairCheckDue) {
+        // Repair passes ran since the last look (rare: a contended device).  A pixel whose tag fits nothing the launch sequence can have
+        // left means the image cannot be trusted: that is an error of the call that observes it, not a debug counter.
+        h->repairCheckDue = false;
+        unsigned int ctl[4] = {0, 0, 0, 0};
+        PT_HIP(h, hipMemcpy(ctl, h->dRepairCtl, sizeof ctl, hipMemcpyDeviceToHost));
+        if (ctl[1] != h->inconsistentSeen) {
+            h->inconsistentSeen = ctl[1];
+            return fail(h, PT_E_HIP, "hand-over repair: a pixel's frame tag fits no launch of this handle (image inconsistent; pt_reset / pt_set_size start over)");
+        }
+    }
     return PT_OK;
 }
 
@@ -500,13 +525,18 @@ PT_API int pt_set_params(pt_handle h, int num_spheres, int num_cuboids, int ray_
 {
     PT_CHECK_HANDLE(h);
     PT_FAN_OUT(h, pt_set_params(part, num_spheres, num_cuboids, ray_depth, spp, focal_length, aperture_diameter));
-    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
+    // The reference's setters run whenever the GUI touches a slider, changed or not (PathTracer.cs:11-83): values the renderer already
+    // has are not an input change — nothing is flushed, nothing invalidated (bitwise compare: -0.0f / NaN count as changes).
+    if (num_spheres == h->numSpheres && num_cuboids == h->numCuboids && ray_depth == h->rayDepth && spp == h->spp &&
+        std::memcmp(&focal_length, &h->focalLength, sizeof(float)) == 0 && std::memcmp(&aperture_diameter, &h->apertureDiameter, sizeof(float)) == 0)
+        return PT_OK;
     if (num_spheres < 0 || num_spheres > PT_MAX_SPHERES || num_cuboids < 0 || num_cuboids > PT_MAX_CUBOIDS)
         return fail(h, PT_E_OUT_OF_RANGE, "object counts exceed the GameObjectsUBO arrays (256 spheres / 64 cuboids)");
     if (ray_depth < 0 || spp < 1) return fail(h, PT_E_BAD_ARGUMENT, "ray_depth must be >= 0 and spp >= 1");
     // the kernels carry bounce / sample counters in 12-bit fields of their path records
     if (ray_depth > PT_MAX_RAY_DEPTH || spp > PT_MAX_SPP)
         return fail(h, PT_E_OUT_OF_RANGE, "ray_depth / spp exceed PT_MAX_RAY_DEPTH / PT_MAX_SPP (4095)");
+    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (num_spheres != h->numSpheres) h->gridDirty = true;
     if (num_spheres != h->numSpheres || num_cuboids != h->numCuboids || focal_length != h->focalLength || aperture_diameter != h->apertureDiameter) {
         h->tileMasksValid = false; // (the cached masks cull spheres AND cuboids against the lens' cone)
@@ -525,10 +555,15 @@ PT_API int pt_upload_basic_data(pt_handle h, int byte_offset, int size, const vo
 {
     PT_CHECK_HANDLE(h);
     PT_FAN_OUT(h, pt_upload_basic_data(part, byte_offset, size, src));
-    if (int rc = flush_frames(h)) return rc; // pending frames were rendered with the inputs as they were
     if (!src) return fail(h, PT_E_BAD_ARGUMENT, "src == NULL");
     if (byte_offset < 0 || size < 0 || (long long)byte_offset + size > PT_BASIC_DATA_UBO_SIZE)
         return fail(h, PT_E_OUT_OF_RANGE, "BasicDataUBO range outside [0,144)");
+    // The reference re-uploads InvView and ViewPos on EVERY focused update, moved or not (MainWindow.cs:131-132): two SubData calls between
+    // every pair of Render() calls.  Bytes the renderer already holds are not an input change: no flush (the frames keep pipelining), no
+    // invalidation (the cached tile masks stay valid).  A changed byte flushes first — pending frames were rendered with the camera as it was.
+    if (std::memcmp(h->basic + byte_offset, src, (size_t)size) == 0) return PT_OK;
+    h->statFlushes++;
+    if (int rc = flush_frames(h)) return rc;
     std::memcpy(h->basic + byte_offset, src, (size_t)size);
     h->tileMasksValid = false; h->launchesSinceInputChange = 0;
     return PT_OK;
@@ -542,6 +577,10 @@ PT_API int pt_upload_game_objects(pt_handle h, int byte_offset, int size, const 
     if (byte_offset < 0 || size < 0 || (long long)byte_offset + size > PT_GAME_OBJECTS_UBO_SIZE)
         return fail(h, PT_E_OUT_OF_RANGE, "GameObjectsUBO range outside [0,26624)");
     if (size == 0) return PT_OK;
+    // (an object the GUI re-uploads unchanged, Gui.cs:212-216, or a scene reload with the same bytes, MainWindow.cs:119-123: see
+    // pt_upload_basic_data — nothing is joined, copied or invalidated)
+    if (std::memcmp(h->objectsShadow + byte_offset, src, (size_t)size) == 0) return PT_OK;
+    h->statFlushes++;
     if (int rc = bind_device(h)) return rc;
     if (int rc = join_stripes(h)) return rc;
     // pageable source: HIP stages the bytes before returning, so the caller may reuse `src` immediately
@@ -594,6 +633,7 @@ bool gpu_busy(pt_handle h);
 int launch_frames(pt_handle h, int firstFrame, int n, long waitUs, bool lastOfFlush)
 {
     if (int rc = bind_device(h)) return rc;
+    h->statLaunches++;
     if (!h->snapshotTarget) h->snapFrame = -1; // frames rendered without a present snapshot: an older snapshot no longer shows the image
     pt::FrameArgs a;
     std::memcpy(a.invProj, h->basic, 64);
@@ -712,7 +752,8 @@ int launch_frames(pt_handle h, int firstFrame, int n, long waitUs, bool lastOfFl
         auto flag_down = [&]() -> bool { return !(h->hostErrWord && *(volatile unsigned int *)h->hostErrWord); };
         while (h->unverified.size() > 2 && hipEventQuery(h->unverified.front().done) == hipSuccess && flag_down()) h->unverified.pop_front();
         (void)hipGetLastError(); // (hipErrorNotReady of the query is not an error)
-        if (h->unverified.size() >= (size_t)pt_renderer::kLaunchEvents / 2) { // (the event ring must not lap a remembered launch)
+        static_assert(pt_renderer::kLaunchEvents / 2 <= pt::kMaxUnverifiedLaunches, "frame-tag window (pt_kernels.hpp)");
+        if (h->unverified.size() >= (size_t)pt_renderer::kLaunchEvents / 2) { // (the event ring must not lap a remembered launch; also the frame-tag window's bound)
             (void)hipEventSynchronize(h->unverified.front().done);
             if (flag_down()) h->unverified.pop_front();
         }
@@ -747,6 +788,7 @@ int launch_frames(pt_handle h, int firstFrame, int n, long waitUs, bool lastOfFl
                 if ((size_t)a.tilesX * a.tilesY <= h->tileMaskTiles) {
                     PT_HIP(h, pt::launch_tile_masks(a, h->dTileMasks, h->stream));
                     h->tileMasksValid = true;
+                    h->statMaskBuilds++;
                 }
             }
             if (h->tileMasksValid) a.tileMasks = h->dTileMasks;
@@ -828,7 +870,7 @@ int launch_frames(pt_handle h, int firstFrame, int n, long waitUs, bool lastOfFl
         h->chainBroken = false; // (join_stripes above set it; this launch re-opens the chain)
         h->mainDirty = true;    // a striped frame that follows must order its helper stripe behind this launch
         h->tagsLive = a.keepTags != 0;
-        h->lastTag = 2.0f + (float)((firstFrame + n - 1) & 1023); // pt::frame_tag of the launch's last frame
+        h->lastTag = 2.0f + (float)((firstFrame + n - 1) & pt::kFrameTagMask); // pt::frame_tag of the launch's last frame
     } else if (stripes == 1) {
         if (int rc = join_stripes(h)) return rc;
         h->tagsLive = false; // (the plain path stores alpha = 1 for every pixel; a tagged launch of an A/B variant stores 1 last)
@@ -1131,7 +1173,8 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     // (a small share — fewer than 12,000 tiles — never waited: its launches go behind each other unless the predecessor happens to be
     // resident, which is what it measures best with: tools/emulate_strong.py)
     const bool bigShare = (long long)((h->width + 7) / 8) * ((h->rows + 7) / 8) >= 12000;
-    if (!bigShare || ptimpl::launch_ready(h)) return ptimpl::flush_frames_bounded(h, 0, 1);
+    // (a limit the host set itself bounds latency AND deferral: such a batch is launched at the limit, behind its predecessor if need be)
+    if (!bigShare || h->maxBatchExplicit || ptimpl::launch_ready(h)) return ptimpl::flush_frames_bounded(h, 0, 1);
     if (h->pendingFrames >= 16 * limit) {
         // a host that runs this far ahead is paced: the call waits (at most render_wait_us = 2 ms) for the moment the batch can start beside
         // its predecessor and launches it then; if that moment does not come in time the frames simply stay pending — never a launch BEHIND
@@ -1576,6 +1619,23 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_handover_stats(pt
         out[2] += ctl[2];
         out[3] += p->abandonEpoch;
     }
+    return PT_OK;
+}
+
+// Test aid (not declared in the public header): how the handle has been launching.  out[0] = pt_render-driven launch_frames calls (a striped
+// frame counts once), [1] = 1 while the cached tile masks are valid, [2] = frames accepted by pt_render and not launched yet, [3] = tile-mask
+// rebuilds, [4] = frame counter, [5] = flushes forced by an input change (upload / set_params with different values).  Does not flush or join.
+extern "C" __attribute__((visibility("default"))) int pt_debug_launch_stats(pt_handle h, unsigned long long out[6])
+{
+    PT_CHECK_HANDLE(h);
+    if (!out) return fail(h, PT_E_BAD_ARGUMENT, "out == NULL");
+    pt_handle r = h->isGroup() ? h->parts[0] : h;
+    out[0] = r->statLaunches;
+    out[1] = r->tileMasksValid ? 1 : 0;
+    out[2] = (unsigned long long)r->pendingFrames;
+    out[3] = r->statMaskBuilds;
+    out[4] = (unsigned long long)r->frame;
+    out[5] = r->statFlushes;
     return PT_OK;
 }
 

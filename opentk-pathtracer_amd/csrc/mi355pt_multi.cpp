@@ -341,20 +341,24 @@ PT_API int pt_create_multi(const int *device_ids, int n_devices, int width, int 
     g->stream = g->ownStream;
     PT_GROUP_HIP(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
 #undef PT_GROUP_HIP
-    // direct xGMI copies between the root and every peer.  Without peer access hipMemcpyPeerAsync would silently stage every gather through
-    // host memory: a group that cannot reach a device directly is refused (tuning knob allow_staged_gather = 1 accepts it, for a box
-    // whose topology really has no link), loudly — SCALE numbers must never come from a host-staged gather by accident.
+    // Direct xGMI copies between the root and every peer.  Without peer access hipMemcpyPeerAsync stages the gather through host memory:
+    // the group still WORKS (a CI box or a workstation without P2P renders the same bits), but it is not what a SCALE number may come
+    // from — the handle remembers it (pt_multi_gather_is_direct) and bench.py / tools/multi_gpu_check.sh refuse a staged group.  Tuning
+    // knob allow_staged_gather = 0 turns the fallback into the hard error it was in round 5.
     for (int i = 1; i < n_devices; i++) {
         const int d = device_ids[i];
         if (d == g->device) continue;
         int canRootToPeer = 0, canPeerToRoot = 0;
         const hipError_t e1 = hipDeviceCanAccessPeer(&canRootToPeer, g->device, d), e2 = hipDeviceCanAccessPeer(&canPeerToRoot, d, g->device);
-        if ((e1 != hipSuccess || e2 != hipSuccess || !canRootToPeer || !canPeerToRoot) && pt::tuning().allowStagedGather == 0) {
+        if (e1 != hipSuccess || e2 != hipSuccess || !canRootToPeer || !canPeerToRoot) {
             (void)hipGetLastError();
-            const std::string msg = "pt_create_multi: no peer access between device " + std::to_string(g->device) + " and device " + std::to_string(d) +
-                                    " (hipDeviceCanAccessPeer = 0): the gather would be staged through the host";
-            ptimpl::group_destroy(g);
-            return fail(nullptr, PT_E_HIP, msg);
+            g->gatherDirect = false;
+            if (pt::tuning().allowStagedGather == 0) {
+                const std::string msg = "pt_create_multi: no peer access between device " + std::to_string(g->device) + " and device " + std::to_string(d) +
+                                        " (hipDeviceCanAccessPeer = 0): the gather would be staged through the host";
+                ptimpl::group_destroy(g);
+                return fail(nullptr, PT_E_HIP, msg);
+            }
         }
         if (canRootToPeer) {
             (void)hipSetDevice(g->device);
@@ -374,6 +378,14 @@ PT_API int pt_create_multi(const int *device_ids, int n_devices, int width, int 
         return fail(nullptr, rc, msg);
     }
     *out = g;
+    return PT_OK;
+}
+
+PT_API int pt_multi_gather_is_direct(pt_handle h, int *out_direct)
+{
+    PT_CHECK_HANDLE(h);
+    if (!out_direct) return fail(h, PT_E_BAD_ARGUMENT, "out == NULL");
+    *out_direct = (!h->isGroup() || h->gatherDirect) ? 1 : 0;
     return PT_OK;
 }
 

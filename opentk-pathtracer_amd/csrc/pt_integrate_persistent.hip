@@ -78,9 +78,9 @@ __global__ __launch_bounds__(256) void pt_repair_kernel(const FrameArgs a, unsig
         float4 last = a.accum[idx];
         int done = 0, odd = 0;
         if (last.w >= FRAME_TAG) {
-            const int rel = ((int)last.w - (int)FRAME_TAG - a.frame) & 1023;
+            const int rel = ((int)last.w - (int)FRAME_TAG - a.frame) & kFrameTagMask;
             if (rel < n) done = rel + 1;
-            else if (rel < 512) done = n;           // a later launch got this far: every frame of this one is in
+            else if (rel <= kFrameTagMask / 2) done = n; // a later launch got this far: every frame of this one is in (window: pt_kernels.hpp)
             else if (last.w != a.chainTag) odd = 1; // older than the predecessor's last frame: the launches before were not complete
         } else if (last.w == 1.0f) {
             // 1 is what the last frame of a launch that does not keep its tags stores — this launch's, or a later one's of the same chain —

@@ -99,7 +99,7 @@ constexpr float FRAME_TAG = 2.0f;
 // may CHAIN: the first frame of a tagged launch waits for the tag of the previous launch's last frame (FrameArgs::chainTag), so
 // two launches on different streams overlap like the frames inside one launch do (the second fills the wavefront slots the
 // first one's drain frees) — the host restores alpha = 1 before anything can observe the image (pt_set_alpha_kernel).
-PT_DEV float frame_tag(int absFrame) { return FRAME_TAG + (float)(absFrame & 1023); }
+PT_DEV float frame_tag(int absFrame) { return FRAME_TAG + (float)(absFrame & kFrameTagMask); }
 
 // ---- hand-over bound (round 5): wall clock, and giving up means ABANDONING the launch — never a fold onto a stale pixel.
 // Time is the constant-rate counter (s_memrealtime, 100 MHz) >> 10: one unit = 10.24 us, 32 bits wrap after 12 hours (differences are
@@ -172,7 +172,7 @@ struct HandoverBound {
         return abandoned;
     }
 };
-constexpr int MAX_BATCH_FRAMES = 256; // (one workgroup fills the weight table: <= its 256 threads; tags cover 1,024 frames)
+constexpr int MAX_BATCH_FRAMES = kMaxBatchFrames; // (one workgroup fills the weight table: <= its 256 threads; tags: pt_kernels.hpp kFrameTagMask)
 
 PT_DEV float4 load_pixel_sc1(const float4 *p)
 {

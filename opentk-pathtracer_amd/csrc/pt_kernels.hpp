@@ -98,6 +98,16 @@ struct FrameArgs {
     unsigned int *auditLog;
     int auditSabotage;      // audit build, tuning knob audit_sabotage = n: every n-th (pixel, frame) folds into a perturbed colour, as a stale or torn read would — proves that the audit sees it
 };
+// Frame tags (alpha channel inside tagged launches, pt_kernel_common.hpp): tag(f) = 2 + (f & kFrameTagMask), exact in binary32 (< 2^24).
+// Two frames that can be in the image together must have different tags, and the repair pass tells "a later launch's tag" from "an
+// older one" by the half window: every frame the host can have issued since the oldest launch it still remembers must lie within
+// kFrameTagMask / 2 of it.  The host remembers at most kMaxUnverifiedLaunches launches of at most kMaxBatchFrames frames (the bound is
+// enforced where launches are remembered, mi355pt.cpp): 128 x 256 = 32,768 frames, a sixteenth of the half window of 524,288.
+// (Rounds 2 - 5 used a 1,024-frame window, which 256-frame launches of a small share could outrun: round-5 advisor finding.)
+constexpr int kFrameTagMask = 0xFFFFF;
+constexpr int kMaxBatchFrames = 256, kMaxUnverifiedLaunches = 128;
+static_assert((long long)kMaxBatchFrames * (kMaxUnverifiedLaunches + 2) * 8 <= (kFrameTagMask + 1) / 2, "frame tags would alias within the repair window");
+static_assert(kFrameTagMask + 2 < (1 << 24), "frame tags must be exact in binary32");
 constexpr int kAuditLogRecords = 1024, kAuditRecordWords = 12;
 constexpr int kTileMaskWords = 8; // 64 bytes per tile (FrameArgs::tileMasks)
 constexpr int kStartedWords = 4096; // capacity of FrameArgs::startedFlags (a launch with more workgroups does not report in)

@@ -79,6 +79,7 @@ struct pt_renderer {
     size_t tileMaskTiles = 0;        // capacity in tiles
     bool tileMasksValid = false;
     int launchesSinceInputChange = 0;
+    unsigned long long statLaunches = 0, statMaskBuilds = 0, statFlushes = 0; // pt_debug_launch_stats: integrator launches, mask rebuilds, input-change flushes
     unsigned char *dGrid = nullptr; // (kMaxCells + 1) * 2 + kMaxRefs bytes
     float *dLut = nullptr;          // 256-entry sRGB table
     unsigned int *dQueue = nullptr; // global chunk-ticket counter of the persistent kernel (never reset: epoch scheme)
@@ -99,6 +100,9 @@ struct pt_renderer {
     static constexpr int kLaunchEvents = 256; // ring of "launch done" events (mainDone / chainDone alias the latest ones)
     hipEvent_t launchEvents[kLaunchEvents] = {};
     unsigned int launchEventNext = 0;
+    bool repairPendingAll = false;        // the host cleared a raised abandon flag and has not yet enqueued the repair passes of the launches remembered
+    bool repairCheckDue = false;          // repair passes may have run since dRepairCtl was last read (checked by the next blocking call)
+    unsigned int inconsistentSeen = 0;    // dRepairCtl[1] at that reading
     unsigned int abandonEpoch = 0;        // bumped whenever the host finds hostErrWord raised (present slots remember it)
     int overlapHoldoff = 0;               // launches that still run BEHIND their predecessor after an abandonment (a contended device)
     unsigned int waitBudgetUnits = 0, waitCheckUnits = 0; // FrameArgs::waitBudget / waitCheckInterval for this device's wall clock
@@ -191,7 +195,8 @@ struct pt_renderer {
     // group handle (pt_create_multi): parts[i] renders its share on device_ids[i]; this struct then only carries the root
     // device's streams, the gather buffers and the present slots
     std::vector<pt_renderer *> parts;
-    int groupBand = 16;             // 0 = contiguous row blocks
+    int groupBand = 8;              // 0 = contiguous row blocks; 8 = single tile rows (1080p over 8 devices: largest share 136 rows; 16-row bands: 144)
+    bool gatherDirect = true;       // (group) every peer copies to the root over a direct link (hipDeviceCanAccessPeer both ways); pt_multi_gather_is_direct
     hipEvent_t gatherReady = nullptr; // (parts) recorded on the part's stream when its rows may be copied
     void *dGatherFull = nullptr;      // (group) assembled image on the root device (RGBA32F or RGBA8)
     size_t gatherFullBytes = 0;

@@ -19,7 +19,7 @@ struct Tuning {
     int frameBatch = 0;            // 1..64: initial pt_set_frame_batch
     int queueChunk = 0;            // 1..1024: tiles per global ticket (0 = automatic)
     int groupBand = -1;            // group handles: band height (0 = contiguous row blocks; else a multiple of 8)
-    int allowStagedGather = 0;     // group handles: 1 = accept devices without peer access (their gather is staged through the host)
+    int allowStagedGather = 1;     // group handles: 1 = devices without peer access are accepted (gather staged through the host; pt_multi_gather_is_direct says so), 0 = pt_create_multi fails
     // launches (mi355pt.cpp: launch_frames)
     int auditSabotage = 0;         // -DPT_AUDIT builds only: every n-th (pixel, frame) folds into a perturbed colour
     int noSingleTagged = 0;        // 1: single frames never chain

@@ -508,4 +508,15 @@ inline void UploadCamera(PathTracer &pathTracer, const Camera &camera, int width
     ubo.SubData(Vector4::SizeInBytes * 8, Vector4::SizeInBytes, pos);
 }
 
+// OnUpdateFrame alone (MainWindow.cs:131-132): the reference writes InvView and ViewPos on EVERY focused update, moved or not.  The
+// library compares the bytes with what it holds: an unmoved camera costs two memcmp calls and changes nothing.
+inline void UploadCameraPerFrame(PathTracer &pathTracer, const Camera &camera)
+{
+    UniformBuffer ubo = pathTracer.BasicDataUBO();
+    Matrix4 invView = camera.View.Inverted();
+    ubo.SubData(Vector4::SizeInBytes * 4, Vector4::SizeInBytes * 4, invView.M);
+    float pos[4] = {camera.Position.X, camera.Position.Y, camera.Position.Z, 0.0f};
+    ubo.SubData(Vector4::SizeInBytes * 8, Vector4::SizeInBytes, pos);
+}
+
 } // namespace opentk_pathtracer

@@ -50,7 +50,10 @@ int main(int argc, char **argv)
             atmosphericScatterer.Render();
             LoadScene(pathTracer);
             UploadCamera(pathTracer, camera, W, H);
-            for (int i = 0; i < frames; i++) pathTracer.Render();
+            for (int i = 0; i < frames; i++) {
+                UploadCameraPerFrame(pathTracer, camera); // OnUpdateFrame, MainWindow.cs:131-132: every update, moved or not
+                pathTracer.Render();                      // OnRenderFrame, :49
+            }
             std::vector<float> img = pathTracer.Result();
             write_file(argv[5], img.data(), img.size() * sizeof(float));
             if (argc > 8) { // the environment the frames were rendered with, read back through the C ABI
@@ -78,6 +81,7 @@ int main(int argc, char **argv)
             const uint8_t *shown = nullptr;
             int shownFrame = 0, presented = 0;
             for (int f = 0; f < frames; f++) {
+                UploadCameraPerFrame(pathTracer, camera);  // OnUpdateFrame, MainWindow.cs:131-132
                 pathTracer.Render();                       // PathTracer.Render(), MainWindow.cs:49
                 pathTracer.PresentAsync(presented % 3);    // instead of PostProcesser.Render(PathTracer.Result), :51
                 if (++presented >= 3) shown = pathTracer.PresentWait(presented % 3, &shownFrame); // the frame of two calls ago: landed

@@ -200,6 +200,7 @@ def load() -> C.CDLL:
         "pt_device_count": [],
         "pt_create_multi": [ip, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
         "pt_multi_set_partition": [vp, C.c_int],
+        "pt_multi_gather_is_direct": [vp, ip],
         "pt_device_count_of": [vp, ip],
         "pt_present_rgba8_async": [vp, C.c_int],
         "pt_present_wait": [vp, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), ip],
@@ -234,6 +235,17 @@ def debug_set(key: str, value: int) -> None:
     if rc != PT_OK:
         raise NativeError(rc, f"pt_debug_set({key!r}): unknown knob")
 
+
+
+def debug_launch_stats(handle) -> dict:
+    """How the handle has been launching (pt_debug_launch_stats — exported, not in the public header; neither flushes nor joins)."""
+    L = load()
+    L.pt_debug_launch_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    L.pt_debug_launch_stats.restype = C.c_int
+    out = (C.c_ulonglong * 6)()
+    check(L.pt_debug_launch_stats(handle, out), handle)
+    return {"launches": int(out[0]), "tile_masks_valid": bool(out[1]), "pending_frames": int(out[2]), "mask_builds": int(out[3]),
+            "frame": int(out[4]), "input_change_flushes": int(out[5])}
 
 
 def debug_handover_stats(handle) -> dict:

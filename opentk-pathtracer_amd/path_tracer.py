@@ -221,6 +221,14 @@ class PathTracer:
         """Group handles: block-cyclic bands of `band_rows` image rows per device (0 = contiguous row blocks)."""
         check(self._lib.pt_multi_set_partition(self._h, band_rows), self._h)
 
+    @property
+    def GatherIsDirect(self) -> bool:
+        """Group handles: True when every gather copy goes over a direct peer link (pt_multi_gather_is_direct); a staged group must not
+        be the source of a scaling number."""
+        v = C.c_int()
+        check(self._lib.pt_multi_gather_is_direct(self._h, C.byref(v)), self._h)
+        return bool(v.value)
+
     def PostProcessDevice(self):
         p, n = C.c_void_p(), C.c_size_t()
         check(self._lib.pt_postprocess_device(self._h, C.byref(p), C.byref(n)), self._h)

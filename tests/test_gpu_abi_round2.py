@@ -38,7 +38,7 @@ def test_group_handle_equals_untiled_render(pkg, native_lib, oracle, devices, ba
     pt = make_tracer(pkg, w, devices=devices)
     n = C.c_int()
     assert native_lib.pt_device_count_of(pt._h, C.byref(n)) == 0 and n.value == len(devices)
-    if band != 16:
+    if band != 8:  # (8 = the default since round 6)
         pt.SetPartition(band)
     for _ in range(w.frames):
         total = pt.Render()

@@ -1,0 +1,177 @@
+"""GPU tests added in round 6.
+  * The reference's REAL frame loop: MainWindow.OnUpdateFrame re-uploads InvView and ViewPos on every focused update, moved or not
+    (/root/reference/OpenTK-PathTracer/src/MainWindow.cs:131-132), between every pair of PathTracer.Render() calls (:40-69).  Unchanged
+    bytes must be no input change for the library: frames keep pipelining (launches per step < 1), the cached tile masks become valid;
+    a changed byte still flushes, invalidates, and the image stays the oracle's bit for bit across a camera move mid-run.
+  * The same rule for pt_upload_game_objects (Gui.cs:212-216 re-uploads the picked object on every slider event) and pt_set_params
+    (PathTracer.cs:11-83: a setter per GUI touch).
+Run with `pytest -m gpu` on an MI355X.  Nothing here reads /root/reference.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import configs
+from test_gpu_abi_round2 import make_tracer
+from test_gpu_parity import assert_bit_exact
+
+pytestmark = pytest.mark.gpu
+
+
+def _reupload_camera(pt, basic):
+    """OnUpdateFrame's two SubData calls (MainWindow.cs:131-132)."""
+    pt.BasicDataUBO.SubData(64, 64, basic[64:128])
+    pt.BasicDataUBO.SubData(128, 16, basic[128:144])
+
+
+def test_reference_frame_loop_pipelines_and_gets_cached_masks(pkg, native_lib):
+    """1,000 iterations of {re-upload InvView + ViewPos (unchanged), Render()} at 1080p with the automatic batch size: the uploads must
+    neither flush nor invalidate — far fewer launches than frames, cached tile masks valid, no input-change flush counted."""
+    w = configs.Workload("refloop", "default", 1920, 1080, 8, "sky_f32_32")
+    _, basic, _, _, _ = configs.inputs(w)
+    pt = make_tracer(pkg, w)
+    pt.SetFrameBatch(0)
+    for _ in range(8):  # (an idle GPU launches its first frames at once)
+        _reupload_camera(pt, basic)
+        pt.Render()
+    pt.Synchronize()
+    s0 = pkg.native.debug_launch_stats(pt._h)
+    n = 1000
+    for _ in range(n):
+        _reupload_camera(pt, basic)
+        pt.Render()
+    pt.Synchronize()
+    s1 = pkg.native.debug_launch_stats(pt._h)
+    img = pt.Result
+    pt.Dispose()
+    launches = s1["launches"] - s0["launches"]
+    print(f"reference loop: {n} frames in {launches} launches ({launches / n:.4f} per step), masks valid {s1['tile_masks_valid']}, "
+          f"mask builds {s1['mask_builds']}, input-change flushes {s1['input_change_flushes'] - s0['input_change_flushes']}")
+    assert s1["input_change_flushes"] == s0["input_change_flushes"], "an unchanged upload was treated as an input change"
+    assert launches < n / 8, f"{launches} launches for {n} frames: the redundant uploads broke the pipelining"
+    assert s1["tile_masks_valid"] and s1["mask_builds"] >= 1
+    assert np.isfinite(img).all() and (img[..., 3] == 1).all()
+
+
+def test_camera_move_mid_run_flushes_and_stays_bit_exact(pkg, native_lib, oracle):
+    """Frames 0..4 with camera A (each preceded by the redundant re-upload), then camera B's bytes arrive between two Render() calls
+    WITHOUT a reset (legal over the C ABI: the running mean simply continues), frames 5..9 with camera B re-uploaded every frame.
+    The pending frames of camera A must have been rendered with camera A: image == oracle's two-stage accumulation, bit for bit."""
+    w = configs.Workload("cammove", "default", 200, 117, 8, "sky_f32_32")
+    sc, basic_a, objs, env, kw = configs.inputs(w)
+    cam_b = pkg.camera.Camera(position=(-15.0, 4.0, -7.5), look_x=-40.0, look_y=-3.0)
+    basic_b = pkg.camera.basic_data_ubo(cam_b, w.width, w.height)
+    assert bytes(basic_a) != bytes(basic_b)
+    pt = make_tracer(pkg, w)
+    for _ in range(5):
+        _reupload_camera(pt, basic_a)
+        pt.Render()
+    s0 = pkg.native.debug_launch_stats(pt._h)
+    for _ in range(5):
+        _reupload_camera(pt, basic_b)
+        pt.Render()
+    s1 = pkg.native.debug_launch_stats(pt._h)
+    got = pt.Result
+    pt.Dispose()
+    assert s1["input_change_flushes"] > s0["input_change_flushes"], "changed camera bytes did not count as an input change"
+    want = oracle.render(w.width, w.height, basic_a, objs, env, num_frames=5, **kw)
+    want = oracle.render(w.width, w.height, basic_b, objs, env, frame_start=5, num_frames=5, image=want, **kw)
+    assert_bit_exact(got, want, "camera moved between frames 4 and 5 (no reset)")
+
+
+def test_changed_camera_invalidates_cached_masks(pkg, native_lib, oracle):
+    """Masks cached for camera A must not survive camera B: after the move the image still equals the oracle (a stale mask would cull
+    objects camera B sees), and the masks are rebuilt once B has been left alone."""
+    w = configs.Workload("maskmove", "default", 1920, 1080, 4, "sky_f32_32")
+    sc, basic_a, objs, env, kw = configs.inputs(w)
+    cam_b = pkg.camera.Camera(position=(5.0, 2.0, 6.0), look_x=140.0, look_y=-5.0)
+    basic_b = pkg.camera.basic_data_ubo(cam_b, w.width, w.height)
+    pt = make_tracer(pkg, w)
+    pt.SetFrameBatch(4)
+    for _ in range(40):
+        _reupload_camera(pt, basic_a)
+        pt.Render()
+    pt.Synchronize()
+    assert pkg.native.debug_launch_stats(pt._h)["tile_masks_valid"]
+    pt.UploadBasicData(basic_b)
+    assert not pkg.native.debug_launch_stats(pt._h)["tile_masks_valid"]
+    pt.ResetRenderer()  # MainWindow.cs:128-129: a moved camera restarts the accumulation
+    for _ in range(2):
+        _reupload_camera(pt, basic_b)
+        pt.Render()
+    got = pt.Result
+    rows = slice(400, 432)  # (the oracle on 32 rows of the 1080p frame: seconds)
+    want = oracle.render(w.width, w.height, basic_b, objs, env, num_frames=2, y0=rows.start, rows=32, **kw)
+    assert_bit_exact(got[rows], want, "two frames after a camera move at 1080p (rows 400..431)")
+    for _ in range(40):
+        _reupload_camera(pt, basic_b)
+        pt.Render()
+    pt.Synchronize()
+    st = pkg.native.debug_launch_stats(pt._h)
+    pt.Dispose()
+    assert st["tile_masks_valid"] and st["mask_builds"] >= 2
+
+
+def test_unchanged_object_and_param_uploads_are_no_input_change(pkg, native_lib, oracle):
+    """Gui.cs:212-216 re-uploads the picked object on every slider event, PathTracer.cs:11-83 pushes a uniform per setter call: the same
+    bytes / values again neither join nor flush; different ones do, and the image follows the oracle."""
+    w = configs.Workload("objs", "default", 160, 96, 6, "sky_f32_32")
+    sc, basic, objs, env, kw = configs.inputs(w)
+    pt = make_tracer(pkg, w)
+    base = pkg.native.debug_launch_stats(pt._h)["input_change_flushes"]  # (the scene's first upload: every object is a change)
+    objs_np = np.frombuffer(bytes(objs), dtype=np.uint8)
+    for _ in range(4):
+        pt.GameObjectsUBO.SubData(80 * 3, 80, objs_np[80 * 3:80 * 4])          # sphere 3, unchanged
+        pt.GameObjectsUBO.SubData(20480 + 96 * 2, 96, objs_np[20480 + 96 * 2:20480 + 96 * 3])  # cuboid 2, unchanged
+        pt.RayDepth = w.ray_depth                                               # same value again
+        pt.Render()
+    s0 = pkg.native.debug_launch_stats(pt._h)
+    assert s0["input_change_flushes"] == base
+    # now really edit sphere 3 (albedo) between frames 3 and 4
+    edited = objs_np.copy()
+    edited[80 * 3 + 16:80 * 3 + 28].view(np.float32)[:] = (0.9, 0.1, 0.1)
+    pt.GameObjectsUBO.SubData(80 * 3, 80, edited[80 * 3:80 * 4])
+    for _ in range(3):
+        pt.Render()
+    s1 = pkg.native.debug_launch_stats(pt._h)
+    got = pt.Result
+    pt.Dispose()
+    assert s1["input_change_flushes"] == base + 1
+    want = oracle.render(w.width, w.height, basic, objs, env, num_frames=4, **kw)
+    want = oracle.render(w.width, w.height, basic, edited.tobytes(), env, frame_start=4, num_frames=3, image=want, **kw)
+    assert_bit_exact(got, want, "object edit between frames 3 and 4, redundant uploads around it")
+
+
+def test_multi_gpu_check_script_dry_run(pkg, native_lib, tmp_path):
+    """tools/multi_gpu_check.sh is the one-command acceptance run for an N-GPU box, and no such box has existed in any round: its JSON
+    checks are kept alive by running them on bench.py --gpus 2 --share-gpu (two gloo ranks on this GPU)."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "multi")
+    p = subprocess.run(["bash", os.path.join(root, "tools", "multi_gpu_check.sh"), "--dry-run", out], capture_output=True, text=True, timeout=1200)
+    print(p.stdout[-1500:], p.stderr[-1500:])
+    assert p.returncode == 0, "dry run of tools/multi_gpu_check.sh failed"
+    rep = json.load(open(os.path.join(out, "multi_gpu_check.json")))
+    assert rep["ok"] and rep["runs"] and rep["runs"][0]["gpus"] == 2 and not rep["runs"][0]["errors"]
+
+
+def test_group_handle_reports_its_gather_path_and_defaults_to_tile_row_bands(pkg, native_lib, oracle):
+    """pt_multi_gather_is_direct (a same-device group is always direct), and the default partition since round 6: 8-row bands — of 1080p's
+    135 tile rows 8 parts own 16 or 17 (136 image rows at most; 16-row bands left the largest share 144)."""
+    w = configs.Workload("g8", "default", 1920, 1080, 8, "sky_f32_32")
+    pt = make_tracer(pkg, w, devices=[0] * 8)
+    assert pt.GatherIsDirect
+    rows = []
+    for part in range(8):
+        from opentk_pathtracer_amd.distributed import interleaved_rows
+        rows.append(len(interleaved_rows(1080, part, 8, 8)))
+    assert max(rows) == 136 and sum(rows) == 1080
+    pt.Render()
+    got = pt.Result
+    pt.Dispose()
+    sc, basic, objs, env, kw = configs.inputs(w)
+    want = oracle.render(w.width, w.height, basic, objs, env, num_frames=1, y0=128, rows=24, **kw)
+    assert_bit_exact(got[128:152], want, "default-partition group handle, rows 128..151 of 1080p")
