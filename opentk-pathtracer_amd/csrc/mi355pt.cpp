@@ -20,6 +20,15 @@ thread_local std::string g_create_error;
 
 namespace ptimpl {
 
+#define FEED_LOG(...)                                                                                                                \
+    do {                                                                                                                             \
+        if (pt::tuning().feedLog) {                                                                                                  \
+            std::fprintf(stderr, "[feed %9.1f us] ", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - 1e6 * (long long)(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count())); \
+            std::fprintf(stderr, __VA_ARGS__);                                                                                       \
+            std::fprintf(stderr, "\n");                                                                                              \
+        }                                                                                                                            \
+    } while (0)
+
 int fail(pt_handle h, int code, const std::string &msg)
 {
     if (h) h->error = msg;
@@ -89,6 +98,16 @@ static int enqueue_repairs(pt_handle h, bool flagWasDown)
     PT_HIP(h, pt::launch_repair_done(h->dAbandon, h->dQueue, h->stripeQueueBase[0], h->dQueue + kChainQueueWord, h->chainQueueBase,
                                      h->dRepairCtl, h->stream));
     h->unverified.clear();
+    if (h->feedCountersStale && h->dFeedDone) {
+        // an abandoned frame-fed launch counted fewer pixels than the host's running totals say: the counters start again from zero —
+        // behind everything joined into h->stream, and behind the gates and tone maps still queued on the copy stream
+        if (!h->feedResetEvent) PT_HIP(h, hipEventCreateWithFlags(&h->feedResetEvent, hipEventDisableTiming));
+        PT_HIP(h, hipEventRecord(h->feedResetEvent, h->copyStream));
+        PT_HIP(h, hipStreamWaitEvent(h->stream, h->feedResetEvent, 0));
+        PT_HIP(h, hipMemsetAsync(h->dFeedDone, 0, (size_t)16 * pt::kFeedDoneStride * sizeof(unsigned long long), h->stream));
+        std::memset(h->feedDoneBase, 0, sizeof h->feedDoneBase);
+        h->feedCountersStale = false;
+    }
     return PT_OK;
 }
 
@@ -96,15 +115,80 @@ static int enqueue_repairs(pt_handle h, bool flagWasDown)
 // while), and present slots tone-mapped from a snapshot since the last epoch are tone-mapped again when they are waited for.
 static void note_abandonment(pt_handle h)
 {
+    const unsigned int why = *(volatile unsigned int *)h->hostErrWord;
     *(volatile unsigned int *)h->hostErrWord = 0;
     h->abandonEpoch++;
-    h->overlapHoldoff = 256;
+    // a hand-over that ran out of its budget = a contended device: launches stop overlapping for a while.  A frame-fed launch that ended
+    // itself because no frame came (reason "idle") says nothing about the device — only about the host's pace: a host whose fed launches
+    // end idle after a frame or two is too slow to feed a resident launch, and gets the classic launches for a (growing) while
+    if (why & pt::kAbandonContended) h->overlapHoldoff = 256;
+    if (why & pt::kAbandonIdle) {
+        h->statFeedIdle++;
+        if (h->feed.published <= 2) {
+            h->feedIdleStrikes++;
+            if (h->feedIdleStrikes >= 2) h->feedHoldoff = h->feedIdleStrikes >= 10 ? 4096 : (16 << (h->feedIdleStrikes - 2));
+        } else {
+            h->feedIdleStrikes = 0;
+        }
+    }
+    h->feedCountersStale = true; // (an abandoned fed launch counted fewer pixels than the host's running totals say)
     h->repairPendingAll = true; // (the flag is down again because the host cleared it: the launches remembered now all get their repair pass)
     h->repairCheckDue = true; // the next blocking call looks at what the repair passes found (settle_handover)
 }
 
+// The open frame-fed launch takes no more frames: the host word gets its final count (| kFeedClosed), and everything that depended on
+// that count is settled — the launch's repair record, the ticket counter of its stream, the running totals of the per-frame counters.
+unsigned int feed_word(const pt_renderer::FeedState &f, bool closed)
+{
+    return (closed ? pt::kFeedClosed : 0u) | ((unsigned int)f.published << 16) | (f.slots16 & 0xffffu);
+}
+
+void feed_close(pt_handle h)
+{
+    pt_renderer::FeedState &f = h->feed;
+    if (!f.open) return;
+    f.open = false;
+    __atomic_store_n(&h->hostFeed[f.hostWord], feed_word(f, true), __ATOMIC_RELEASE);
+    FEED_LOG("close word %d = %08x (first %d published %d pendingSlot %d)", f.hostWord, feed_word(f, true), f.firstFrame, f.published, f.pendingSlot);
+    for (pt_renderer::LaunchRecord &r : h->unverified)
+        if (r.a.launchSeq == f.seq) r.a.batchFrames = f.published;
+    const unsigned int tickets = (unsigned int)(((long long)f.published * f.tilesFrame + f.queueChunk - 1) / f.queueChunk); // (+ one failing ticket per workgroup: added at the launch)
+    (f.streamIdx == 1 ? h->chainQueueBase : h->stripeQueueBase[0]) += tickets;
+    for (int j = 0; j < f.published; j++) h->feedDoneBase[f.streamIdx][j & 7] += f.pixelsPerFrame;
+    if (f.published >= 8) h->feedIdleStrikes = 0; // (the host kept a launch fed: not a slow host)
+    // fused display: the newest frame was presented, and no later frame of this launch will come to tone-map it — the next join does
+    // (from the accumulation image, before anything else is rendered: whoever closes a launch joins, or launches through launch_frames)
+    if (f.pendingSlot >= 0) {
+        h->fusedOrphanSlot = f.pendingSlot;
+        f.pendingSlot = -1;
+    }
+}
+
+// A present into slot fusedOrphanSlot was left without a successor frame (see feed_close): with every launch joined into h->stream the
+// accumulation image IS the frame that was shown — tone-map it the classic way.  Call with the streams joined.
+static int resolve_fused_orphan(pt_handle h)
+{
+    if (h->fusedOrphanSlot < 0) return PT_OK;
+    FEED_LOG("orphan present of slot %d: tone map from the image", h->fusedOrphanSlot);
+    PresentSlot &s = h->slots[h->fusedOrphanSlot];
+    h->fusedOrphanSlot = -1;
+    if (!s.fusedWaiting) return PT_OK;
+    void *const image = s.boundDev ? s.boundDev : s.dRgba8;
+    const size_t pixels = (size_t)s.rows * s.width;
+    PT_HIP(h, pt::launch_postprocess(h->accum(), image, pixels, h->stream));
+    PT_HIP(h, hipEventRecord(s.toneMapped, h->stream));
+    PT_HIP(h, hipStreamWaitEvent(h->copyStream, s.toneMapped, 0));
+    if (!s.boundDev) PT_HIP(h, hipMemcpyAsync(s.host, s.dRgba8, pixels * 4, hipMemcpyDeviceToHost, h->copyStream));
+    PT_HIP(h, hipEventRecord(s.copied, h->copyStream));
+    s.fusedWaiting = false;
+    s.fedPresent = false; // (completed by the events above, like any present tone-mapped behind a join — the join put the repair passes in front)
+    s.snapSource = nullptr;
+    return PT_OK;
+}
+
 int join_stripes(pt_handle h, bool repairNow)
 {
+    feed_close(h);
     if (h->pendingFrames > 0) {
         // whatever follows a join is ordered by the streams again, so this launch need not leave its tags in the image: its
         // last frame stores the reference's alpha = 1 and the usual render-N-then-read sequence needs no alpha pass at all
@@ -135,7 +219,7 @@ int join_stripes(pt_handle h, bool repairNow)
         if (int rc = enqueue_repairs(h, !raised && !h->repairPendingAll)) return rc;
         h->repairPendingAll = false;
     }
-    return PT_OK;
+    return resolve_fused_orphan(h);
 }
 
 // h->stream has been synchronised behind join_stripes(h, false): every launch of the handle is complete.  Usually that is all there is
@@ -336,6 +420,7 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id) != hipSuccess || khz <= 0) khz = 100000;
         (void)hipGetLastError();
+        h->wallClockKhz = khz;
         const pt::Tuning &t = pt::tuning();
         const double unitsPerMs = (double)khz / 1024.0;
         double budget = (double)t.handoverBudgetMs * unitsPerMs, check = (double)t.handoverCheckUs * unitsPerMs / 1000.0;
@@ -344,6 +429,16 @@ PT_API int pt_create(int device_id, int width, int height, pt_handle *out)
         h->waitBudgetUnits = (unsigned int)budget;
         h->waitCheckUnits = (unsigned int)check;
     }
+    PT_CREATE_HIP(hipHostMalloc((void **)&h->hostFeed, pt_renderer::kFeedHostWords * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent));
+    for (int i = 0; i < pt_renderer::kFeedHostWords; i++) h->hostFeed[i] = pt::kFeedClosed;
+    PT_CREATE_HIP(hipHostMalloc((void **)&h->hostFeedDone, pt_renderer::kFeedHostWords * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(h->hostFeedDone, 0, pt_renderer::kFeedHostWords * sizeof(unsigned int));
+    PT_CREATE_HIP(hipHostGetDevicePointer((void **)&h->devFeedHostDone, h->hostFeedDone, 0));
+    PT_CREATE_HIP(hipHostGetDevicePointer((void **)&h->devFeedHost, h->hostFeed, 0));
+    PT_CREATE_HIP(hipMalloc((void **)&h->dFeedDev, (size_t)2 * pt::kFeedBcastSlots * pt::kFeedBcastStride * sizeof(unsigned int)));
+    PT_CREATE_HIP(hipMemsetAsync(h->dFeedDev, 0, (size_t)2 * pt::kFeedBcastSlots * pt::kFeedBcastStride * sizeof(unsigned int), h->stream));
+    PT_CREATE_HIP(hipMalloc((void **)&h->dFeedDone, (size_t)16 * pt::kFeedDoneStride * sizeof(unsigned long long)));
+    PT_CREATE_HIP(hipMemsetAsync(h->dFeedDone, 0, (size_t)16 * pt::kFeedDoneStride * sizeof(unsigned long long), h->stream));
     PT_CREATE_HIP(hipHostMalloc((void **)&h->hostStarted, ptimpl::kStartedWords * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(h->hostStarted, 0, ptimpl::kStartedWords * sizeof(unsigned int));
     PT_CREATE_HIP(hipHostGetDevicePointer((void **)&h->devStarted, h->hostStarted, 0));
@@ -382,6 +477,7 @@ PT_API int pt_destroy(pt_handle h)
     if (h->isGroup()) return ptimpl::group_destroy(h);
     h->pendingFrames = 0; // frames nobody can observe any more are not worth launching
     (void)hipSetDevice(h->device);
+    ptimpl::feed_close(h); // (a frame-fed launch still waiting for frames ends now)
     // (launches may still write present snapshots, tone maps read them: every stream of the handle is drained before they are freed)
     for (int j = 0; j < ptimpl::kMaxStripes; j++)
         if (h->stripeStream[j]) (void)hipStreamSynchronize(h->stripeStream[j]);
@@ -414,6 +510,13 @@ PT_API int pt_destroy(pt_handle h)
     if (h->dTileMasks) (void)hipFree(h->dTileMasks);
     if (h->hostErrWord) (void)hipHostFree(h->hostErrWord);
     if (h->hostStarted) (void)hipHostFree(h->hostStarted);
+    if (h->hostFeed) (void)hipHostFree(h->hostFeed);
+    if (h->hostFeedDone) (void)hipHostFree(h->hostFeedDone);
+    if (h->dFeedDev) (void)hipFree(h->dFeedDev);
+    if (h->dFeedDone) (void)hipFree(h->dFeedDone);
+    for (hipEvent_t e : h->feedWordBusy)
+        if (e) (void)hipEventDestroy(e);
+    if (h->feedResetEvent) (void)hipEventDestroy(h->feedResetEvent);
     if (h->hostAuditLog) (void)hipHostFree(h->hostAuditLog);
     if (h->dAudit) (void)hipFree(h->dAudit);
     if (h->dEnv) (void)hipFree(h->dEnv);
@@ -626,16 +729,24 @@ namespace {
 
 bool gpu_busy(pt_handle h);
 
-// Launch frames [firstFrame, firstFrame + n) with the handle's current inputs.  n == 1: the striped frame; n > 1: one
-// batch kernel on the main stream (pt_integrate_persistent.hip, frame pipelining).
-// waitUs: how long the call may wait for the predecessor launch to become resident (back-pressure of launch chaining, see below);
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Launching frames [firstFrame, firstFrame + n) with the handle's current inputs, in steps (round 6: what used to be one 326-line function):
+//   fill_frame_args      the inputs as the kernels take them (+ the sphere grid of a changed scene)
+//   choose_launch_mode   tagged or plain, stripes, kernel variant, workgroups per CU
+//   use_tile_masks       cached per-tile cull masks: use / rebuild
+//   wait_for_residency   launch chaining: may this launch run BESIDE its predecessor?
+//   arm_handover         sequence number + abandon word of a tagged launch; remember_launch: the record its repair pass needs
+//   launch_chained / launch_single_stream / launch_striped     the three ways a launch reaches the GPU
+// launch_frames() strings them together.  waitUs: how long the call may wait for the predecessor launch to become resident;
 // lastOfFlush: this launch holds the newest pending frame (only it may store alpha = 1 last / write a present snapshot).
-int launch_frames(pt_handle h, int firstFrame, int n, long waitUs, bool lastOfFlush)
+struct LaunchMode {
+    bool tagged = false, chainable = false;
+    int stripes = 1, kernelVariant = 0;
+};
+
+// ---- step 1: inputs -> FrameArgs (everything that does not depend on how the launch reaches the GPU)
+int fill_frame_args(pt_handle h, pt::FrameArgs &a, int firstFrame, int n)
 {
-    if (int rc = bind_device(h)) return rc;
-    h->statLaunches++;
-    if (!h->snapshotTarget) h->snapFrame = -1; // frames rendered without a present snapshot: an older snapshot no longer shows the image
-    pt::FrameArgs a;
     std::memcpy(a.invProj, h->basic, 64);
     std::memcpy(a.invView, h->basic + 64, 64);
     std::memcpy(a.viewPos, h->basic + 128, 12);
@@ -668,8 +779,8 @@ int launch_frames(pt_handle h, int firstFrame, int n, long waitUs, bool lastOfFl
     a.errorWord = h->devErrWord;
     a.startedFlags = nullptr;
     a.launchSeq = 0;
-    a.snapshot = nullptr; // (set next to every a.accum below when this launch feeds a present)
-    a.audit = nullptr; // (set next to every a.accum below)
+    a.snapshot = nullptr; // (set next to every a.accum when the launch feeds a present)
+    a.audit = nullptr;    // (set next to every a.accum)
     a.auditLog = h->devAuditLog;
     a.auditSabotage = 0;
 #ifdef PT_AUDIT
@@ -700,243 +811,448 @@ int launch_frames(pt_handle h, int firstFrame, int n, long waitUs, bool lastOfFl
     }
     a.gridReach2 = h->grid.reach2;
     std::memcpy(a.sphereRunStart, h->sphereRunStart, sizeof(a.sphereRunStart));
-    a.tileMasks = nullptr; // (set below, next to a.tilesY, for the launch modes that run the tile pass over the handle's whole tile)
-
-    // variant -> (kernel variant, stripes): 0 = default (2 stripes x 5 workgroups/CU); 20+k / 30+k / 40+k = 2 / 3 / 4
-    // stripes of the persistent kernel with k+1 workgroups per CU; everything else = one kernel on the main stream
-    int stripes = 1, kernelVariant = h->variant;
-    // Tagged launches (pixels handed over through alpha tags): every launch of more than one frame, and — once the host has
-    // pipelined frames on this handle — single frames too, so that they can overlap the launches around them (a host that
-    // presents every frame, or only ever renders one frame at a time, keeps the faster single-frame stripes).
-    // ... and single frames whenever the GPU still runs earlier frames of this handle: the frame then chains on the other stream and
-    // moves into the wavefront slots the previous launch's drain frees (0.154 ms per 1080p frame against 0.182 for the two row
-    // stripes); a host that lets the GPU run dry between its frames (blocking reads / presents) keeps the stripes, which are the
-    // faster way to render ONE frame on an idle machine.
-    const bool noSingleTagged = pt::tuning().noSingleTagged != 0; // A/B runs
-    const bool chainable = h->variant == 0 && !h->externalStream() && !ptimpl::timeline_blocks_pipelining(h);
-    // (also the first frame of a burst on an idle GPU once the host has pipelined frames before: the batch that follows then chains
-    // on it instead of waiting behind two joined stripes — the driver's `--steps 20` command: 15.4 instead of 14.8 Gsamples/s)
-    const bool tagged = h->variant == 0 && (n > 1 || (chainable && !noSingleTagged && (gpu_busy(h) || (h->sawBatch && h->presentCadence != 1))));
-    // (short launches — the interactive modes — take 5 workgroups per CU: 112 instead of 32 free VGPRs per SIMD leave the present's
-    // tone map and the runtime's copy kernel room BESIDE the resident persistent wavefronts; 6 per CU starve them until the drain,
-    // measured: 0.28 instead of 0.16 ms per displayed frame; a single frame also renders 2 % faster with 5)
-    const int shortWg = pt::tuning().shortWorkgroupsPerCU;
-    if (tagged) { stripes = 1; kernelVariant = 10 + (n < 8 ? shortWg : h->batchWorkgroupsPerCU) - 1; h->batchLaunched = true; if (n > 1) h->sawBatch = true; }
-    else if (h->variant == 0 && h->externalStream()) { stripes = 1; kernelVariant = 14; } // everything ON the caller's stream
-    else if (h->variant == 0) { stripes = 2; kernelVariant = 14; }
-    else if (h->variant >= 20 && h->variant < 50) { stripes = h->variant / 10; kernelVariant = 10 + h->variant % 10; }
-    if (h->rows < 16 * stripes) stripes = 1; // tiny tiles: not worth splitting
-    a.variant = kernelVariant;
-    // Drain compaction (a thin draining wavefront donates its paths to its workgroup's pool) shortens the tail of ONE
-    // launch.  With stripes the tail of one launch is covered by the other stripe's (or the next frame's) main phase, and
-    // the pool's LDS and the donor traffic only cost: auto = on for single-launch variants, off for striped frames.
-    a.drainCompaction = h->drainCompaction >= 0 ? h->drainCompaction : (stripes > 1 || tagged ? 0 : 32); // a batch drains once per n frames
-    a.tagged = tagged ? 1 : 0;
+    a.tileMasks = nullptr; // (use_tile_masks: only launches that run the tile pass over the handle's whole tile)
+    a.tagged = 0;
     a.keepTags = 0;
     a.chainTag = 0.0f;
     a.abandonWord = nullptr;
     a.tileFlags = nullptr;
     a.waitBudget = h->waitBudgetUnits;
     a.waitCheckInterval = h->waitCheckUnits;
-    // Hand-over bound (pt_renderer.hpp): a tagged launch gets a sequence number and the handle's abandon word, and is remembered — its
-    // kernel argument and an event behind it — until a join has put its repair pass behind it or it is seen complete with the flag down.
-    auto arm_handover = [&]() -> void { // (call with a.chainTag / a.keepTags set)
-        a.launchSeq = ++h->launchSeq;
-        if (a.launchSeq == 0 || a.launchSeq >= 0xfffffff0u) a.launchSeq = h->launchSeq = 1; // (0: a fresh roll call; ~0: "no launch abandoned")
-        a.abandonWord = h->dAbandon;
-        a.tileFlags = a.chainTag == 0.0f ? h->dTileFlags : nullptr; // (the first launch of a chain: alpha = 1 could mean "untouched" or "finished")
-    };
-    auto remember_launch = [&](hipEvent_t done) -> void {
-        // A launch seen COMPLETE with the flag DOWN — read in that order: an abandoning launch raises the flag before it ends — ran to its
-        // end and needs no repair pass.
-        auto flag_down = [&]() -> bool { return !(h->hostErrWord && *(volatile unsigned int *)h->hostErrWord); };
-        while (h->unverified.size() > 2 && hipEventQuery(h->unverified.front().done) == hipSuccess && flag_down()) h->unverified.pop_front();
-        (void)hipGetLastError(); // (hipErrorNotReady of the query is not an error)
-        static_assert(pt_renderer::kLaunchEvents / 2 <= pt::kMaxUnverifiedLaunches, "frame-tag window (pt_kernels.hpp)");
-        if (h->unverified.size() >= (size_t)pt_renderer::kLaunchEvents / 2) { // (the event ring must not lap a remembered launch; also the frame-tag window's bound)
-            (void)hipEventSynchronize(h->unverified.front().done);
-            if (flag_down()) h->unverified.pop_front();
+    return PT_OK;
+}
+
+// ---- step 2: how the frames reach the GPU
+// variant -> (kernel variant, stripes): 0 = default (2 stripes x 5 workgroups/CU); 20+k / 30+k / 40+k = 2 / 3 / 4
+// stripes of the persistent kernel with k+1 workgroups per CU; everything else = one kernel on the main stream.
+// Tagged launches (pixels handed over through alpha tags): every launch of more than one frame, and — once the host has
+// pipelined frames on this handle — single frames too, so that they can overlap the launches around them (a host that
+// presents every frame, or only ever renders one frame at a time, keeps the faster single-frame stripes) ... and single frames
+// whenever the GPU still runs earlier frames of this handle: the frame then chains on the other stream and moves into the wavefront
+// slots the previous launch's drain frees (0.154 ms per 1080p frame against 0.182 for the two row stripes); a host that lets the GPU
+// run dry between its frames (blocking reads / presents) keeps the stripes, which are the faster way to render ONE frame on an idle machine.
+LaunchMode choose_launch_mode(pt_handle h, pt::FrameArgs &a, int n)
+{
+    LaunchMode m;
+    m.kernelVariant = h->variant;
+    const bool noSingleTagged = pt::tuning().noSingleTagged != 0; // A/B runs
+    m.chainable = h->variant == 0 && !h->externalStream() && !ptimpl::timeline_blocks_pipelining(h);
+    // (also the first frame of a burst on an idle GPU once the host has pipelined frames before: the batch that follows then chains
+    // on it instead of waiting behind two joined stripes — the driver's `--steps 20` command: 15.4 instead of 14.8 Gsamples/s)
+    m.tagged = h->variant == 0 && (n > 1 || (m.chainable && !noSingleTagged && (gpu_busy(h) || (h->sawBatch && h->presentCadence != 1))));
+    // (short launches — the interactive modes — take 5 workgroups per CU: 112 instead of 32 free VGPRs per SIMD leave the present's
+    // tone map and the runtime's copy kernel room BESIDE the resident persistent wavefronts; 6 per CU starve them until the drain,
+    // measured: 0.28 instead of 0.16 ms per displayed frame; a single frame also renders 2 % faster with 5)
+    const int shortWg = pt::tuning().shortWorkgroupsPerCU;
+    if (m.tagged) { m.stripes = 1; m.kernelVariant = 10 + (n < 8 ? shortWg : h->batchWorkgroupsPerCU) - 1; h->batchLaunched = true; if (n > 1) h->sawBatch = true; }
+    else if (h->variant == 0 && h->externalStream()) { m.stripes = 1; m.kernelVariant = 14; } // everything ON the caller's stream
+    else if (h->variant == 0) { m.stripes = 2; m.kernelVariant = 14; }
+    else if (h->variant >= 20 && h->variant < 50) { m.stripes = h->variant / 10; m.kernelVariant = 10 + h->variant % 10; }
+    if (h->rows < 16 * m.stripes) m.stripes = 1; // tiny tiles: not worth splitting
+    a.variant = m.kernelVariant;
+    // Drain compaction (a thin draining wavefront donates its paths to its workgroup's pool) shortens the tail of ONE
+    // launch.  With stripes the tail of one launch is covered by the other stripe's (or the next frame's) main phase, and
+    // the pool's LDS and the donor traffic only cost: auto = on for single-launch variants, off for striped frames.
+    a.drainCompaction = h->drainCompaction >= 0 ? h->drainCompaction : (m.stripes > 1 || m.tagged ? 0 : 32); // a batch drains once per n frames
+    a.tagged = m.tagged ? 1 : 0;
+    return m;
+}
+
+// ---- step 3: cached tile masks (the tile pass of the spp = 1 kernels, the fresh-tile batch passes of the spp > 1 kernel): valid masks are
+// simply used; stale ones are rebuilt once the camera / lens / spheres / tiling have been left alone for two launches — the launches still
+// in flight read the old buffer, so the rebuild joins the two launch streams first (chainBroken: this launch then starts on the main
+// stream, behind the mask kernel).  Call with a.tilesX / a.tilesY / a.y0 / a.rows set.
+int use_tile_masks(pt_handle h, pt::FrameArgs &a)
+{
+    if (pt::tuning().tileMasks == 0) return PT_OK;
+    // (counted in FRAMES since round 6 — a frame-fed launch takes up to 64 frames: a host that moves the camera every frame still never
+    // gets here with more than one)
+    const bool settled = h->launchesSinceInputChange > 2;
+    h->launchesSinceInputChange += a.batchFrames;
+    if (!h->tileMasksValid && settled) {
+        if (int rc = join_stripes(h)) return rc;
+        // (the buffer is sized by ensure_accum with the image: nothing is allocated on the render path)
+        if ((size_t)a.tilesX * a.tilesY <= h->tileMaskTiles) {
+            PT_HIP(h, pt::launch_tile_masks(a, h->dTileMasks, h->stream));
+            h->tileMasksValid = true;
+            h->statMaskBuilds++;
         }
-        h->unverified.push_back({a, done});
-    };
-    if (tagged && h->hostErrWord && *(volatile unsigned int *)h->hostErrWord) {
+    }
+    if (h->tileMasksValid) a.tileMasks = h->dTileMasks;
+    return PT_OK;
+}
+
+// ---- step 4: residency.  A launch may run BESIDE its predecessor (on the other stream) only if that launch is fully resident — then it
+// can only ever get the slots the predecessor's workgroups give up when they are done; otherwise it goes behind it on the same stream (no
+// overlap, always safe).  After an abandonment the device is evidently contended: for a while launches run behind their predecessor.
+bool predecessor_resident(pt_handle h)
+{
+    for (int i = 0; i < h->lastWorkgroups; i++)
+        if (((volatile unsigned int *)h->hostStarted)[i] != h->launchSeq) return false;
+    return true;
+}
+bool wait_for_residency(pt_handle h, const pt::FrameArgs &a, long waitUs)
+{
+    if (pt::tuning().serialLaunches != 0) return false; // (A/B and profile runs: strictly one launch after the other)
+    if (h->overlapHoldoff > 0) h->overlapHoldoff--;
+    const bool mayChain = !h->chainBroken && h->lastWorkgroups > 0 && h->lastWorkgroups <= ptimpl::kStartedWords && h->overlapHoldoff == 0;
+    bool resident = mayChain && predecessor_resident(h);
+    // (small shares — a 1/8 share of 1080p has 4,050 tiles per frame — lose 4 % when two launches overlap: the second launch's first
+    // frames all wait for the first one's last; measured, tools/emulate_strong.py)
+    const bool bigShare = (long long)a.tilesX * a.tilesY >= 12000;
+    if (mayChain && !resident && (bigShare || h->flushFinal)) {
+        // Back-pressure (round 3): the host is more than one launch ahead of the GPU — the predecessor still queues behind ITS
+        // predecessor.  Launching behind it on the same stream would expose a full drain + ramp per launch (0.096 ms at 1080p);
+        // instead the call waits until the predecessor is resident (i.e. until the launch before it has left the machine) and
+        // then chains.  Bounded, so a GPU shared with another process falls back to the always-safe same-stream order.  Round 5:
+        // pt_render itself no longer waits here — it keeps frames pending until the predecessor is resident (launch_ready) and
+        // only a call that blocks anyway (pt_synchronize, a read, a present) waits, for at most chain_wait_us.
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!resident) {
+            const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (waited >= waitUs) break;
+            if (waited > 200) std::this_thread::sleep_for(std::chrono::microseconds(20)); // (long waits: do not burn the core)
+            resident = predecessor_resident(h);
+        }
+    }
+    return resident;
+}
+
+// ---- step 5: the hand-over bound's bookkeeping (pt_renderer.hpp).  A tagged launch gets a sequence number and the handle's abandon word
+// (call with a.chainTag / a.keepTags set), and is remembered — its kernel argument and an event behind it — until a join has put its
+// repair pass behind it or it is seen complete with the flag down.
+void arm_handover(pt_handle h, pt::FrameArgs &a)
+{
+    a.launchSeq = ++h->launchSeq;
+    if (a.launchSeq == 0 || a.launchSeq >= 0xfffffff0u) a.launchSeq = h->launchSeq = 1; // (0: a fresh roll call; ~0: "no launch abandoned")
+    a.abandonWord = h->dAbandon;
+    a.tileFlags = a.chainTag == 0.0f ? h->dTileFlags : nullptr; // (the first launch of a chain: alpha = 1 could mean "untouched" or "finished")
+}
+void remember_launch(pt_handle h, const pt::FrameArgs &a, hipEvent_t done)
+{
+    // A launch seen COMPLETE with the flag DOWN — read in that order: an abandoning launch raises the flag before it ends — ran to its
+    // end and needs no repair pass.
+    auto flag_down = [&]() -> bool { return !(h->hostErrWord && *(volatile unsigned int *)h->hostErrWord); };
+    while (h->unverified.size() > 2 && hipEventQuery(h->unverified.front().done) == hipSuccess && flag_down()) h->unverified.pop_front();
+    (void)hipGetLastError(); // (hipErrorNotReady of the query is not an error)
+    static_assert(pt_renderer::kLaunchEvents / 2 <= pt::kMaxUnverifiedLaunches, "frame-tag window (pt_kernels.hpp)");
+    if (h->unverified.size() >= (size_t)pt_renderer::kLaunchEvents / 2) { // (the event ring must not lap a remembered launch; also the frame-tag window's bound)
+        (void)hipEventSynchronize(h->unverified.front().done);
+        if (flag_down()) h->unverified.pop_front();
+    }
+    h->unverified.push_back({a, done});
+}
+
+// ---- frame-fed launches (pt_renderer.hpp: FeedState).  Wanted when few frames go out and nothing says the host is about to join: the
+// reference's own usage.  Conditions that only cost speed elsewhere: one sample per pixel (the tile-pass kernels), a full-size share.
+bool feed_wanted(pt_handle h, const pt::FrameArgs &a, int n, bool lastOfFlush)
+{
+    if (pt::tuning().feed == 0 || pt::tuning().serialLaunches != 0 || n >= 8 || !lastOfFlush || h->flushFinal || a.spp != 1 || (long long)a.tilesX * a.tilesY < pt::tuning().feedMinTiles) return false;
+    // ... and a host that has turned deferral OFF (pt_set_frame_batch(1): every Render() is handed to the GPU at once — the interactive
+    // setting).  With deferral allowed, frames that arrive while the GPU is busy are collected and go out as one classic launch, which has the
+    // lower fixed cost (no open / close hand-shake: the driver's `--steps 20` command measures 17.45 that way against 16.69 Gsamples/s fed)
+    if (!h->snapshotTarget && !(h->maxBatchExplicit && h->maxBatch == 1)) return false;
+    if (h->feedHoldoff > 0) { // (a host too slow to keep a launch fed: see note_abandonment)
+        h->feedHoldoff--;
+        return false;
+    }
+    if (h->snapshotTarget) {
+        // A host that shows every frame: the launch tone-maps into the present slots' images itself (fused display) — for slots whose image
+        // stays on the device (pt_present_bind_device_image: the interop-style present).  A slot with a host image needs the runtime's copy
+        // kernel per frame, which finds no room beside resident wavefronts (measured: it ran when the launch ended) and is PCIe-bound
+        // anyway (0.157 ms per 1080p frame): such hosts keep the per-frame launches.
+        if (pt::tuning().feedDisplay == 0 || n != 1 || !h->lastPresentBound) return false;
+        for (const ptimpl::PresentSlot &s : h->slots)
+            if (s.boundDev && s.boundBytes < h->tilePixels() * 4) return false;
+    }
+    return true;
+}
+
+// Turn `a` (a chained launch of frames [firstFrame, firstFrame + n) on stream st = launch stream si) into a frame-fed launch: capacity
+// kFeedCapacity, n frames published, control words initialised.  *word = the host word it reads, or -1 when none is free (no fed launch now).
+int feed_prepare(pt_handle h, pt::FrameArgs &a, int si, hipStream_t st, int firstFrame, int n, int *word)
+{
+    *word = -1;
+    const int w = h->feedWordNext % pt_renderer::kFeedHostWords;
+    if (!h->feedWordBusy[w]) PT_HIP(h, hipEventCreateWithFlags(&h->feedWordBusy[w], hipEventDisableTiming));
+    else if (hipEventQuery(h->feedWordBusy[w]) != hipSuccess) { // (the launch that read this word eight fed launches ago still runs)
+        (void)hipGetLastError();
+        return PT_OK;
+    }
+    if (h->feedCountersStale) {
+        // an abandoned launch left the per-frame counters short of the running totals: start them again from zero — only with nothing of
+        // the handle in flight that counts or compares them (else: no fed launch yet; the next join resets them as well)
+        if (gpu_busy(h) || hipStreamQuery(h->copyStream) != hipSuccess) {
+            (void)hipGetLastError();
+            return PT_OK;
+        }
+        PT_HIP(h, hipMemsetAsync(h->dFeedDone, 0, (size_t)16 * pt::kFeedDoneStride * sizeof(unsigned long long), st));
+        std::memset(h->feedDoneBase, 0, sizeof h->feedDoneBase);
+        h->feedCountersStale = false;
+    }
+    h->feedWordNext++;
+    pt_renderer::FeedState &f = h->feed;
+    f.published = n;
+    f.slots16 = 0;
+    f.pendingSlot = -1;
+    f.display = h->snapshotTarget != nullptr;
+    __atomic_store_n(&h->hostFeedDone[w], 0u, __ATOMIC_RELEASE);
+    __atomic_store_n(&h->hostFeed[w], ((unsigned int)n << 16), __ATOMIC_RELEASE);
+    a.feedHostDone = h->devFeedHostDone + w;
+    std::memcpy(a.feedBase, h->feedDoneBase[si], sizeof a.feedBase);
+    a.feedPixels = (unsigned long long)h->tilePixels();
+    unsigned int *const bcast = h->dFeedDev + (size_t)si * pt::kFeedBcastSlots * pt::kFeedBcastStride; // (one set of broadcast slots per launch stream)
+    PT_HIP(h, hipMemsetAsync(bcast, 0, (size_t)pt::kFeedBcastSlots * pt::kFeedBcastStride * sizeof(unsigned int), st)); // (behind the previous launch of this stream)
+    a.batchFrames = pt::kFeedCapacity;
+    a.keepTags = 1; // (which frame is the last is not known when the launch starts: the host restores alpha = 1 before anything observes the image)
+    const int wg = pt::tuning().feedWorkgroupsPerCU;
+    a.variant = 10 + (wg >= 1 && wg <= 6 ? wg : 6) - 1;
+    a.feedHost = h->devFeedHost + w;
+    a.feedBcast = bcast;
+    a.feedDone = h->dFeedDone + (size_t)8 * pt::kFeedDoneStride * si;
+    const long idleUs = pt::tuning().feedIdleUs;
+    a.feedIdleTicks = (unsigned int)((double)(idleUs < 1 ? 1 : (idleUs > 10000000 ? 10000000 : idleUs)) * h->wallClockKhz / 1000.0); // (ticks of the constant-rate counter: 100 MHz on gfx950)
+    a.displayImages[0] = a.displayImages[1] = a.displayImages[2] = nullptr;
+    a.displayPrev = 0;
+    a.displayOn = f.display && pt::tuning().feedDisplay != 2 ? 1 : 0; // (feed_display = 2: debug — the protocol without the tone map)
+    if (f.display)
+        for (int i = 0; i < PT_PRESENT_SLOTS; i++) a.displayImages[i] = (uchar4 *)h->slots[i].boundDev; // (null: an unbound slot is never entered into the feed word)
+    a.snapshot = nullptr;
+    f.hostWord = w;
+    *word = w;
+    return PT_OK;
+}
+
+// pt_render with a fed launch open: publish the newest frame (h->frame - 1) into it.  False = it could not take the frame (it has been
+// closed: the caller goes on as if there had been none).
+bool feed_try_publish(pt_handle h, bool presentsEveryFrame)
+{
+    pt_renderer::FeedState &f = h->feed;
+    const int frame = h->frame - 1;
+    const bool ok = f.open && f.published < pt::kFeedCapacity && frame == f.firstFrame + f.published && h->pendingFrames == 1 &&
+                    f.display == presentsEveryFrame && !(h->hostErrWord && *(volatile unsigned int *)h->hostErrWord);
+    if (!ok) {
+        FEED_LOG("publish refused: open %d published %d frame %d first %d pending %d display %d/%d flag %u", (int)f.open, f.published, frame, f.firstFrame, h->pendingFrames,
+                 (int)f.display, (int)presentsEveryFrame, h->hostErrWord ? *(volatile unsigned int *)h->hostErrWord : 0u);
+        ptimpl::feed_close(h);
+        return false;
+    }
+    // (a launch opened right after an input change runs without cached tile masks: once the inputs have been left alone, let the next
+    // launch build them — one launch boundary for ~7 % on every frame after it)
+    if (!f.withMasks && pt::tuning().tileMasks != 0 && !h->tileMasksValid && h->launchesSinceInputChange > 2 && f.published >= 3 && f.pendingSlot < 0) {
+        ptimpl::feed_close(h);
+        return false;
+    }
+    h->launchesSinceInputChange++;
+    const int j = f.published; // this frame's index in the launch
+    f.slots16 &= ~(3u << (2 * (j & 7))); // (the entry of frame j - 8 becomes frame j's: not shown so far)
+    f.published++;
+    __atomic_store_n(&h->hostFeed[f.hostWord], ptimpl::feed_word(f, false), __ATOMIC_RELEASE);
+    h->pendingFrames = 0;
+    h->lastTag = 2.0f + (float)(frame & pt::kFrameTagMask);
+    h->snapFrame = -1;
+    h->statPublishes++;
+    FEED_LOG("publish frame %d: word %d = %08x pendingSlot %d", frame, f.hostWord, ptimpl::feed_word(f, false), f.pendingSlot);
+    if (f.pendingSlot >= 0) { // the frame before this one was presented: its image is complete when this frame is (the launch's monitor says when)
+        h->slots[f.pendingSlot].fusedWaiting = false;
+        f.pendingSlot = -1;
+    }
+    return true;
+}
+
+// ---- step 6a: chained launch — alternate between the main stream and the chain stream; the pixels' alpha tags order it behind the
+// previous launch (which may still be draining on the other stream), nothing else does
+int launch_chained(pt_handle h, pt::FrameArgs &a, int firstFrame, int n, long waitUs, bool lastOfFlush)
+{
+    a.y0 = h->y0;
+    a.rows = h->rows;
+    a.accum = h->accum();
+    a.audit = h->dAudit;
+    a.snapshot = h->snapshotTarget;
+    a.tilesY = (h->rows + 7) / 8;
+    a.keepTags = (h->flushFinal && lastOfFlush) ? 0 : 1;
+    if (!lastOfFlush) a.snapshot = nullptr; // (the snapshot shows the flush's LAST frame)
+    if (int rc = use_tile_masks(h, a)) return rc;
+    const bool resident = wait_for_residency(h, a, waitUs);
+    int si = resident ? (h->lastStreamIdx ^ 1) : h->lastStreamIdx;
+    if (h->chainBroken) {
+        // something else happened since the last tagged launch (an upload, a read, a striped frame ...): it was joined into
+        // the main stream; start there again, and let the chain stream see those inputs before its next launch
+        if (int rc = join_stripes(h)) return rc;
+        si = 0;
+        PT_HIP(h, hipEventRecord(h->inputsReady, h->stream));
+        h->chainNeedsInputs = true;
+    }
+    a.chainTag = h->tagsLive ? h->lastTag : 0.0f;
+    hipStream_t st = h->stream;
+    if (si == 1) {
+        // the chain stream IS the helper stream of stripe 1: the library keeps at most three streams busy (main, this one, copy) —
+        // HIP multiplexes streams onto 4 hardware queues, and two of the library's streams that share a queue execute in order
+        if (int rc = ptimpl::ensure_stripe(h, 1)) return rc;
+        st = h->stripeStream[1];
+        if (h->chainNeedsInputs) {
+            PT_HIP(h, hipStreamWaitEvent(st, h->inputsReady, 0));
+            h->chainNeedsInputs = false;
+        }
+    }
+    a.startedFlags = h->devStarted;
+    arm_handover(h, a);
+    a.queue = h->dQueue + (si == 1 ? ptimpl::kChainQueueWord : 0); // each launch stream draws tickets from its own counter
+    a.queueBase = si == 1 ? h->chainQueueBase : h->stripeQueueBase[0];
+    unsigned int tickets = 0;
+    int workgroups = 0;
+    // a frame-fed launch when the host is not far ahead (few frames, not the flush of a call that joins next); else — or when this
+    // kernel configuration has no fed instantiation — the classic launch of exactly these n frames
+    bool fed = false;
+    if (feed_wanted(h, a, n, lastOfFlush)) {
+        const pt::FrameArgs classic = a;
+        int word = -1;
+        if (int rc = feed_prepare(h, a, si, st, firstFrame, n, &word)) return rc;
+        if (word >= 0) {
+            fed = true;
+            const hipError_t e = pt::launch_integrate(a, st, &tickets, &workgroups, &fed);
+            if (e != hipSuccess && e != hipErrorNotSupported) return hip_fail(h, e, "launch_integrate (frame-fed)");
+            if (e != hipSuccess) {
+                fed = false;
+                h->feedHoldoff = 256; // (this scene's kernel has no fed instantiation: do not prepare one per launch)
+            }
+            (void)hipGetLastError();
+        }
+        if (!fed) a = classic;
+    }
+    if (!fed) {
+        if (a.snapshot && h->snapReadPending[h->snapshotIndex]) PT_HIP(h, hipStreamWaitEvent(st, h->snapRead[h->snapshotIndex], 0));
+        PT_HIP(h, pt::launch_integrate(a, st, &tickets, &workgroups));
+    }
+    (si == 1 ? h->chainQueueBase : h->stripeQueueBase[0]) += tickets;
+    h->lastWorkgroups = workgroups;
+    h->lastStreamIdx = si;
+    hipEvent_t done = ptimpl::next_launch_event(h);
+    if (!done) return fail(h, PT_E_HIP, "hipEventCreate failed");
+    PT_HIP(h, hipEventRecord(done, st));
+    remember_launch(h, a, done);
+    if (si == 1) {
+        h->chainDone = done;
+        h->chainInFlight = h->chainPending = true;
+    } else {
+        h->mainDone = done;
+        h->mainInFlight = true;
+    }
+    if (a.snapshot) h->snapLaunches.push_back({st, done, 0, h->tilePixels()});
+    if (fed) { // pt_render publishes the frames that follow into this launch (feed_try_publish) until something closes it
+        pt_renderer::FeedState &f = h->feed;
+        PT_HIP(h, hipEventRecord(h->feedWordBusy[f.hostWord], st));
+        f.open = true;
+        f.firstFrame = firstFrame;
+        f.published = n;
+        f.streamIdx = si;
+        f.seq = a.launchSeq;
+        f.workgroups = workgroups;
+        f.queueChunk = a.queueChunk;
+        f.tilesFrame = (long long)a.tilesX * a.tilesY;
+        f.pixelsPerFrame = (unsigned long long)h->tilePixels();
+        f.withMasks = a.tileMasks != nullptr;
+        std::memcpy(f.base, h->feedDoneBase[si], sizeof f.base);
+        h->statFeedOpens++;
+        FEED_LOG("open: first %d n %d stream %d word %d display %d wg %d", firstFrame, n, si, f.hostWord, (int)f.display, workgroups);
+    }
+    h->chainBroken = false; // (join_stripes above set it; this launch re-opens the chain)
+    h->mainDirty = true;    // a striped frame that follows must order its helper stripe behind this launch
+    h->tagsLive = a.keepTags != 0;
+    h->lastTag = 2.0f + (float)((firstFrame + n - 1) & pt::kFrameTagMask); // pt::frame_tag of the launch's last frame
+    return PT_OK;
+}
+
+// ---- step 6b: one kernel on the main stream (A/B variants, caller-owned streams)
+int launch_single_stream(pt_handle h, pt::FrameArgs &a, const LaunchMode &m)
+{
+    if (int rc = join_stripes(h)) return rc;
+    h->tagsLive = false; // (the plain path stores alpha = 1 for every pixel; a tagged launch of an A/B variant stores 1 last)
+    a.y0 = h->y0;
+    a.rows = h->rows;
+    a.accum = h->accum();
+    a.audit = h->dAudit;
+    a.snapshot = m.kernelVariant >= 10 ? h->snapshotTarget : nullptr; // (only the persistent kernels write snapshots)
+    if (a.snapshot && h->snapReadPending[h->snapshotIndex]) PT_HIP(h, hipStreamWaitEvent(h->stream, h->snapRead[h->snapshotIndex], 0));
+    a.tilesY = (h->rows + 7) / 8;
+    a.queue = h->dQueue;
+    a.queueBase = h->stripeQueueBase[0];
+    if (m.tagged) arm_handover(h, a); // (a tagged launch of an A/B variant: alone on the main stream, but its frames still hand pixels over)
+    unsigned int tickets = 0;
+    PT_HIP(h, pt::launch_integrate(a, h->stream, &tickets));
+    h->stripeQueueBase[0] += tickets; // unsigned wrap-around is fine: the kernel subtracts queueBase modulo 2^32
+    hipEvent_t done = ptimpl::next_launch_event(h);
+    if (!done) return fail(h, PT_E_HIP, "hipEventCreate failed");
+    PT_HIP(h, hipEventRecord(done, h->stream));
+    if (m.tagged) remember_launch(h, a, done);
+    h->mainDone = done;
+    h->mainInFlight = true;
+    if (a.snapshot) h->snapLaunches.push_back({h->stream, h->mainDone, 0, h->tilePixels()});
+    return PT_OK;
+}
+
+// ---- step 6c: one frame as row stripes, each on its own stream.  Inputs uploaded on the main stream (scene, environment, clears) must
+// be visible to the stripe streams; a stripe's frame f+1 follows its own frame f in stream order, which is the only dependency between
+// frames (the helpers only wait when something other than stripe 0's own frames went onto the main stream since the last striped frame:
+// stripe 0 runs there, and the helper stripes must not wait for ITS previous frame — overlapping one stripe's drain with the other's
+// main phase is the point of the stripes)
+int launch_striped(pt_handle h, pt::FrameArgs &a, const LaunchMode &m)
+{
+    if (h->chainPending || h->tagsLive) { // a chained launch may still run on the chain stream: the stripes read its pixels plainly
+        if (int rc = join_stripes(h)) return rc;
+        h->tagsLive = false; // every pixel gets alpha = 1 from this frame
+    }
+    const bool orderHelpers = h->mainDirty;
+    if (orderHelpers) PT_HIP(h, hipEventRecord(h->inputsReady, h->stream));
+    h->mainDirty = false;
+    for (int j = 0; j < m.stripes; j++) {
+        int r0 = (int)((long long)h->rows * j / m.stripes), r1 = (int)((long long)h->rows * (j + 1) / m.stripes);
+        r0 &= ~7; // stripe boundaries on 8-row tile boundaries (the last stripe takes the ragged remainder)
+        if (j + 1 < m.stripes) r1 &= ~7;
+        if (r1 <= r0) continue;
+        a.y0 = h->y0 + r0;
+        a.localRow0 = r0;
+        a.rows = r1 - r0;
+        a.accum = h->accum() + (size_t)r0 * h->width;
+        a.audit = h->dAudit ? h->dAudit + (size_t)r0 * h->width : nullptr;
+        a.snapshot = h->snapshotTarget ? h->snapshotTarget + (size_t)r0 * h->width : nullptr;
+        a.tilesY = (a.rows + 7) / 8;
+        a.queue = h->dQueue + 16 * j;
+        a.queueBase = h->stripeQueueBase[j];
+        if (int rc = ptimpl::ensure_stripe(h, j)) return rc;
+        h->stripeRow0[j] = r0;
+        h->stripeRows[j] = r1 - r0;
+        hipStream_t st = ptimpl::stripe_stream(h, j);
+        if (j > 0 && orderHelpers) PT_HIP(h, hipStreamWaitEvent(st, h->inputsReady, 0));
+        if (a.snapshot && h->snapReadPending[h->snapshotIndex]) PT_HIP(h, hipStreamWaitEvent(st, h->snapRead[h->snapshotIndex], 0));
+        unsigned int tickets = 0;
+        PT_HIP(h, pt::launch_integrate(a, st, &tickets));
+        h->stripeQueueBase[j] += tickets;
+        PT_HIP(h, hipEventRecord(h->stripeDone[j], st));
+        if (a.snapshot) h->snapLaunches.push_back({st, h->stripeDone[j], (size_t)r0 * h->width, (size_t)(r1 - r0) * h->width});
+        h->stripePending[j] = true;
+        h->stripeInFlight[j] = true;
+    }
+    return PT_OK;
+}
+
+int launch_frames(pt_handle h, int firstFrame, int n, long waitUs, bool lastOfFlush)
+{
+    if (int rc = bind_device(h)) return rc;
+    h->statLaunches++;
+    if (!h->snapshotTarget) h->snapFrame = -1; // frames rendered without a present snapshot: an older snapshot no longer shows the image
+    pt::FrameArgs a;
+    if (int rc = fill_frame_args(h, a, firstFrame, n)) return rc;
+    const LaunchMode m = choose_launch_mode(h, a, n);
+    if (m.tagged && h->hostErrWord && *(volatile unsigned int *)h->hostErrWord) {
         // a launch of this handle was abandoned: put its repair (and that of everything launched since) behind a join before anything new
         // builds on those frames
         if (int rc = join_stripes(h)) return rc;
         if (*(volatile unsigned int *)h->hostErrWord) ptimpl::note_abandonment(h);
     }
-
-    if (tagged && chainable) {
-        // ---- chained launch: alternate between the main stream and the chain stream; the pixels' alpha tags order it behind
-        // the previous launch (which may still be draining on the other stream), nothing else does
-        a.y0 = h->y0;
-        a.rows = h->rows;
-        a.accum = h->accum();
-        a.audit = h->dAudit;
-        a.snapshot = h->snapshotTarget;
-        a.tilesY = (h->rows + 7) / 8;
-        a.keepTags = (h->flushFinal && lastOfFlush) ? 0 : 1;
-        if (!lastOfFlush) a.snapshot = nullptr; // (the snapshot shows the flush's LAST frame)
-        // Cached tile masks (the tile pass of the spp = 1 kernels, the fresh-tile batch passes of the spp > 1 kernel): valid masks are simply used; stale ones are rebuilt once the camera / lens / spheres /
-        // tiling have been left alone for two launches — the launches still in flight read the old buffer, so the rebuild joins the two
-        // launch streams first (chainBroken: this launch starts on the main stream, behind the mask kernel)
-        if (pt::tuning().tileMasks != 0) {
-            h->launchesSinceInputChange++;
-            if (!h->tileMasksValid && h->launchesSinceInputChange > 2) {
-                if (int rc = join_stripes(h)) return rc;
-                // (the buffer is sized by ensure_accum with the image: nothing is allocated on the render path)
-                if ((size_t)a.tilesX * a.tilesY <= h->tileMaskTiles) {
-                    PT_HIP(h, pt::launch_tile_masks(a, h->dTileMasks, h->stream));
-                    h->tileMasksValid = true;
-                    h->statMaskBuilds++;
-                }
-            }
-            if (h->tileMasksValid) a.tileMasks = h->dTileMasks;
-        }
-        // Beside its predecessor (other stream) only if that launch is fully resident — then this launch can only ever get the slots
-        // the predecessor's workgroups give up when they are done; otherwise behind it on the same stream (no overlap, always safe).
-        // (after an abandonment the device is evidently contended: for a while launches run behind their predecessor, the always-safe order)
-        if (h->overlapHoldoff > 0) h->overlapHoldoff--;
-        const bool mayChain = !h->chainBroken && h->lastWorkgroups > 0 && h->lastWorkgroups <= ptimpl::kStartedWords && h->overlapHoldoff == 0;
-        auto all_started = [&]() -> bool {
-            for (int i = 0; i < h->lastWorkgroups; i++)
-                if (((volatile unsigned int *)h->hostStarted)[i] != h->launchSeq) return false;
-            return true;
-        };
-        bool resident = mayChain && all_started();
-        // (small shares — a 1/8 share of 1080p has 4,050 tiles per frame — lose 4 % when two launches overlap: the second launch's first
-        // frames all wait for the first one's last; measured, tools/emulate_strong.py)
-        const bool bigShare = (long long)a.tilesX * a.tilesY >= 12000;
-        if (mayChain && !resident && (bigShare || h->flushFinal)) {
-            // Back-pressure (round 3): the host is more than one launch ahead of the GPU — the predecessor still queues behind ITS
-            // predecessor.  Launching behind it on the same stream would expose a full drain + ramp per launch (0.096 ms at 1080p);
-            // instead the call waits until the predecessor is resident (i.e. until the launch before it has left the machine) and
-            // then chains.  Bounded, so a GPU shared with another process falls back to the always-safe same-stream order.  Round 5:
-            // pt_render itself no longer waits here — it keeps frames pending until the predecessor is resident (launch_ready) and
-            // only a call that blocks anyway (pt_synchronize, a read, a present) waits, for at most chain_wait_us.
-            const long waitLimitUs = waitUs;
-            const auto t0 = std::chrono::steady_clock::now();
-            for (long spins = 0; !resident; spins++) {
-                const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
-                if (waited >= waitLimitUs) break;
-                if (waited > 200) std::this_thread::sleep_for(std::chrono::microseconds(20)); // (long waits: do not burn the core)
-                resident = all_started();
-            }
-        }
-        int si = resident ? (h->lastStreamIdx ^ 1) : h->lastStreamIdx;
-        if (h->chainBroken) {
-            // something else happened since the last tagged launch (an upload, a read, a striped frame ...): it was joined into
-            // the main stream; start there again, and let the chain stream see those inputs before its next launch
-            if (int rc = join_stripes(h)) return rc;
-            si = 0;
-            PT_HIP(h, hipEventRecord(h->inputsReady, h->stream));
-            h->chainNeedsInputs = true;
-        }
-        a.chainTag = h->tagsLive ? h->lastTag : 0.0f;
-        hipStream_t st = h->stream;
-        if (si == 1) {
-            // the chain stream IS the helper stream of stripe 1: the library keeps at most three streams busy (main, this one, copy) —
-            // HIP multiplexes streams onto 4 hardware queues, and two of the library's streams that share a queue execute in order
-            if (int rc = ptimpl::ensure_stripe(h, 1)) return rc;
-            st = h->stripeStream[1];
-            if (h->chainNeedsInputs) {
-                PT_HIP(h, hipStreamWaitEvent(st, h->inputsReady, 0));
-                h->chainNeedsInputs = false;
-            }
-        }
-        if (a.snapshot && h->snapReadPending[h->snapshotIndex]) PT_HIP(h, hipStreamWaitEvent(st, h->snapRead[h->snapshotIndex], 0));
-        a.startedFlags = h->devStarted;
-        arm_handover();
-        a.queue = h->dQueue + (si == 1 ? ptimpl::kChainQueueWord : 0); // each launch stream draws tickets from its own counter
-        a.queueBase = si == 1 ? h->chainQueueBase : h->stripeQueueBase[0];
-        unsigned int tickets = 0;
-        int workgroups = 0;
-        PT_HIP(h, pt::launch_integrate(a, st, &tickets, &workgroups));
-        (si == 1 ? h->chainQueueBase : h->stripeQueueBase[0]) += tickets;
-        h->lastWorkgroups = workgroups;
-        h->lastStreamIdx = si;
-        hipEvent_t done = ptimpl::next_launch_event(h);
-        if (!done) return fail(h, PT_E_HIP, "hipEventCreate failed");
-        PT_HIP(h, hipEventRecord(done, st));
-        remember_launch(done);
-        if (si == 1) {
-            h->chainDone = done;
-            h->chainInFlight = h->chainPending = true;
-        } else {
-            h->mainDone = done;
-            h->mainInFlight = true;
-        }
-        if (a.snapshot) h->snapLaunches.push_back({st, done, 0, h->tilePixels()});
-        h->chainBroken = false; // (join_stripes above set it; this launch re-opens the chain)
-        h->mainDirty = true;    // a striped frame that follows must order its helper stripe behind this launch
-        h->tagsLive = a.keepTags != 0;
-        h->lastTag = 2.0f + (float)((firstFrame + n - 1) & pt::kFrameTagMask); // pt::frame_tag of the launch's last frame
-    } else if (stripes == 1) {
-        if (int rc = join_stripes(h)) return rc;
-        h->tagsLive = false; // (the plain path stores alpha = 1 for every pixel; a tagged launch of an A/B variant stores 1 last)
-        a.y0 = h->y0;
-        a.rows = h->rows;
-        a.accum = h->accum();
-        a.audit = h->dAudit;
-        a.snapshot = kernelVariant >= 10 ? h->snapshotTarget : nullptr; // (only the persistent kernels write snapshots)
-        if (a.snapshot && h->snapReadPending[h->snapshotIndex]) PT_HIP(h, hipStreamWaitEvent(h->stream, h->snapRead[h->snapshotIndex], 0));
-        a.tilesY = (h->rows + 7) / 8;
-        a.queue = h->dQueue;
-        a.queueBase = h->stripeQueueBase[0];
-        if (tagged) arm_handover(); // (a tagged launch of an A/B variant: alone on the main stream, but its frames still hand pixels over)
-        unsigned int tickets = 0;
-        PT_HIP(h, pt::launch_integrate(a, h->stream, &tickets));
-        h->stripeQueueBase[0] += tickets; // unsigned wrap-around is fine: the kernel subtracts queueBase modulo 2^32
-        hipEvent_t done = ptimpl::next_launch_event(h);
-        if (!done) return fail(h, PT_E_HIP, "hipEventCreate failed");
-        PT_HIP(h, hipEventRecord(done, h->stream));
-        if (tagged) remember_launch(done);
-        h->mainDone = done;
-        h->mainInFlight = true;
-        if (a.snapshot) h->snapLaunches.push_back({h->stream, h->mainDone, 0, h->tilePixels()});
-    } else {
-        // inputs uploaded on the main stream (scene, environment, clears) must be visible to the stripe streams;
-        // a stripe's frame f+1 follows its own frame f in stream order, which is the only dependency between frames
-        // (only when something other than stripe 0's own frames went onto the main stream since the last striped frame:
-        // stripe 0 runs there, and the helper stripes must not wait for ITS previous frame — overlapping one stripe's drain
-        // with the other's main phase is the point of the stripes)
-        if (h->chainPending || h->tagsLive) { // a chained launch may still run on the chain stream: the stripes read its pixels plainly
-            if (int rc = join_stripes(h)) return rc;
-            h->tagsLive = false; // every pixel gets alpha = 1 from this frame
-        }
-        const bool orderHelpers = h->mainDirty;
-        if (orderHelpers) PT_HIP(h, hipEventRecord(h->inputsReady, h->stream));
-        h->mainDirty = false;
-        for (int j = 0; j < stripes; j++) {
-            int r0 = (int)((long long)h->rows * j / stripes), r1 = (int)((long long)h->rows * (j + 1) / stripes);
-            r0 &= ~7; // stripe boundaries on 8-row tile boundaries (the last stripe takes the ragged remainder)
-            if (j + 1 < stripes) r1 &= ~7;
-            if (r1 <= r0) continue;
-            a.y0 = h->y0 + r0;
-            a.localRow0 = r0;
-            a.rows = r1 - r0;
-            a.accum = h->accum() + (size_t)r0 * h->width;
-            a.audit = h->dAudit ? h->dAudit + (size_t)r0 * h->width : nullptr;
-            a.snapshot = h->snapshotTarget ? h->snapshotTarget + (size_t)r0 * h->width : nullptr;
-            a.tilesY = (a.rows + 7) / 8;
-            a.queue = h->dQueue + 16 * j;
-            a.queueBase = h->stripeQueueBase[j];
-            if (int rc = ptimpl::ensure_stripe(h, j)) return rc;
-            h->stripeRow0[j] = r0;
-            h->stripeRows[j] = r1 - r0;
-            hipStream_t st = ptimpl::stripe_stream(h, j);
-            if (j > 0 && orderHelpers) PT_HIP(h, hipStreamWaitEvent(st, h->inputsReady, 0));
-            if (a.snapshot && h->snapReadPending[h->snapshotIndex]) PT_HIP(h, hipStreamWaitEvent(st, h->snapRead[h->snapshotIndex], 0));
-            unsigned int tickets = 0;
-            PT_HIP(h, pt::launch_integrate(a, st, &tickets));
-            h->stripeQueueBase[j] += tickets;
-            PT_HIP(h, hipEventRecord(h->stripeDone[j], st));
-            if (a.snapshot) h->snapLaunches.push_back({st, h->stripeDone[j], (size_t)r0 * h->width, (size_t)(r1 - r0) * h->width});
-            h->stripePending[j] = true;
-            h->stripeInFlight[j] = true;
-        }
-    }
-    return PT_OK;
+    if (m.tagged && m.chainable) return launch_chained(h, a, firstFrame, n, waitUs, lastOfFlush);
+    if (m.stripes == 1) return launch_single_stream(h, a, m);
+    return launch_striped(h, a, m);
 }
 
 // Is an integrator launch of this handle still running (or queued) on the GPU?  Cheap event queries, no waiting.
@@ -993,7 +1309,7 @@ int batch_limit(pt_handle h)
 // have to queue behind it on the same stream, or wait: pt_render keeps the frames pending instead.)
 bool launch_ready(pt_handle h)
 {
-    if (h->chainBroken || h->lastWorkgroups <= 0 || h->lastWorkgroups > kStartedWords || h->overlapHoldoff > 0) return true; // (no chaining decision to wait for)
+    if (h->chainBroken || h->lastWorkgroups <= 0 || h->lastWorkgroups > kStartedWords || h->overlapHoldoff > 0 || pt::tuning().serialLaunches != 0) return true; // (no chaining decision to wait for)
     for (int i = 0; i < h->lastWorkgroups; i++)
         if (((volatile unsigned int *)h->hostStarted)[i] != h->launchSeq) return false;
     return true;
@@ -1004,6 +1320,7 @@ bool launch_ready(pt_handle h)
 // tuning knob chain_wait_us).  maxLaunches > 0: stop after that many launches (the rest stays pending).
 int flush_frames_bounded(pt_handle h, long waitUs, int maxLaunches)
 {
+    feed_close(h); // (whoever flushes is about to launch, or to change an input: the open fed launch takes no more frames)
     const int limit = batch_limit(h);
     int launches = 0;
     while (h->pendingFrames > 0 && (maxLaunches <= 0 || launches < maxLaunches)) {
@@ -1075,15 +1392,15 @@ int ensure_slot_host(pt_handle h, int slot, size_t pixels)
 // Launch the pending frames with a present snapshot attached: their launch stores its last frame's pixels into snapshot buffer
 // h->snapNext while it resolves them (FrameArgs::snapshot).  On return h->snapLaunches lists the launches that write it (empty if
 // a kernel variant without snapshot support rendered the frames) and h->snapFrame is the frame count the snapshot shows.
-int flush_with_snapshot(pt_handle h, long waitUs)
+static int ensure_snapshot_buffer(pt_handle h, int k, size_t pixels)
 {
-    const int k = h->snapNext;
-    const size_t pixels = h->tilePixels();
     if (pixels > h->snapCapacity[k]) {
         // (a launch queued earlier may still write the old buffer, a tone map may still read it: drain the handle's streams first)
+        feed_close(h);
         for (int j = 0; j < ptimpl::kMaxStripes; j++)
             if (h->stripeStream[j]) PT_HIP(h, hipStreamSynchronize(h->stripeStream[j]));
         PT_HIP(h, hipStreamSynchronize(h->stream));
+        PT_HIP(h, hipStreamSynchronize(h->copyStream));
         if (h->snapReadPending[k]) PT_HIP(h, hipEventSynchronize(h->snapRead[k]));
         h->snapReadPending[k] = false;
         if (h->dSnap[k]) PT_HIP(h, hipFree(h->dSnap[k]));
@@ -1093,6 +1410,14 @@ int flush_with_snapshot(pt_handle h, long waitUs)
         h->snapCapacity[k] = pixels;
     }
     if (!h->snapRead[k]) PT_HIP(h, hipEventCreateWithFlags(&h->snapRead[k], hipEventDisableTiming));
+    return PT_OK;
+}
+
+int flush_with_snapshot(pt_handle h, long waitUs)
+{
+    const int k = h->snapNext;
+    const size_t pixels = h->tilePixels();
+    if (int rc = ensure_snapshot_buffer(h, k, pixels)) return rc;
     h->snapshotTarget = h->dSnap[k];
     h->snapshotIndex = k;
     h->snapGeneration[k]++;
@@ -1106,6 +1431,46 @@ int flush_with_snapshot(pt_handle h, long waitUs)
         // every snapshot launch takes the next buffer, presented or not: two launches that may run beside each other must never
         // write the same snapshot (their plain stores to one pixel are not ordered by the tags)
         h->snapNext = (k + 1) % pt_renderer::kSnapshots;
+    }
+    return PT_OK;
+}
+
+// Wait (on the host) until the previous present into slot `s` has left it: an event for the classic paths; for a FUSED present
+// (frame-fed launch) the launch's monitor wavefront reports complete frames in a host-mapped word — a fused present whose successor frame
+// was never published is first turned into a classic one (close + join: resolve_fused_orphan).  Returns with the slot idle; *abandoned
+// is set when a fused present's launch gave up (the caller re-does the image behind a join).
+int wait_slot(pt_handle h, PresentSlot &s, bool *abandoned)
+{
+    if (abandoned) *abandoned = false;
+    if (!s.inFlight) return PT_OK;
+    if (s.fedPresent && s.fusedWaiting) {
+        feed_close(h);
+        if (int rc = join_stripes(h)) return rc;
+        if (s.fusedWaiting) return fail(h, PT_E_HIP, "present: a fused present was left without its image");
+    }
+    if (s.fedPresent) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned long spins = 0;; spins++) {
+            if (__atomic_load_n(&h->hostFeedDone[s.fusedWord], __ATOMIC_ACQUIRE) >= s.fusedNeed) break;
+            if ((h->hostErrWord && *(volatile unsigned int *)h->hostErrWord) || h->abandonEpoch != s.abandonEpoch) {
+                // its launch was abandoned (a contended device, or it ended idle) — now, or since the present (the host has already noted it)
+                if (abandoned) *abandoned = true;
+                break;
+            }
+            if ((spins & 63) == 63) {
+                const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+                if (waited > 2000000) { // (2 s: nothing of this library takes that long — treat the launch as lost, the join below sorts it out)
+                    if (abandoned) *abandoned = true;
+                    break;
+                }
+                if (waited > 100) std::this_thread::yield();
+            }
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+        }
+    } else {
+        PT_HIP(h, hipEventSynchronize(s.copied));
     }
     return PT_OK;
 }
@@ -1153,6 +1518,10 @@ PT_API int pt_render(pt_handle h, int *out_total_samples)
     h->pendingFrames++;
     h->frame++; // PathTracer.cs:117 post-increment
     if (out_total_samples) *out_total_samples = h->frame * h->spp; // PathTracer.cs:112
+    // Round 6: a frame-fed launch is open — this frame is PUBLISHED into it (one store to a host-mapped word; the resident wavefronts
+    // start it when they run out of earlier work) instead of being launched.  If it cannot take the frame it is closed, and the frame
+    // goes the usual way below.
+    if (h->feed.open && feed_try_publish(h, presentsEveryFrame)) return PT_OK;
     // Round 3: a host that presents every frame through pt_present_rgba8_async gets this frame launched with a present snapshot
     // attached: the launch stores the frame's pixels a second time while it resolves them (FrameArgs::snapshot), the present that
     // follows tone-maps that copy, and the tone map never stands between two frames.  (Launched NOW, not by the present: a host
@@ -1272,6 +1641,10 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
     const size_t pixels = h->tilePixels();
     h->presentCadence = h->rendersSincePresent;
     h->rendersSincePresent = 0;
+    h->lastPresentBound = h->slots[slot].boundDev != nullptr;
+    // (an open fed launch that does not show its frames itself takes no more of them: this present is about to flush and join — and may
+    // allocate first: the launch must not sit waiting for frames meanwhile)
+    if (h->feed.open && !h->feed.display) ptimpl::feed_close(h);
     if (int rc = ptimpl::ensure_slot_events(h, slot)) return rc;
     if (s.boundDev) { // the displayed image stays on the device (interop-style present): no slot images of the library's own
         if (s.boundBytes < pixels * 4) return fail(h, PT_E_BAD_ARGUMENT, "bound device image is smaller than rows*width*4 bytes");
@@ -1283,6 +1656,43 @@ PT_API int pt_present_rgba8_async(pt_handle h, int slot)
     // ---- snapshot path: the launch of the frames shown writes its last frame into a snapshot buffer while it resolves the pixels;
     // the tone map follows that launch on its stream, the copy on the copy stream, and nothing waits for them: the next pt_render
     // chains its launch beside this one.
+    // ---- frame-fed path (round 6), FUSED DISPLAY: the newest frame sits in the open launch.  Nothing is launched, flushed or tone-mapped
+    // here: the slot is entered into the feed word, and the tile passes of the NEXT frame — which read every pixel of this one anyway —
+    // tone-map it into the slot's image (FrameArgs::displayImages).  The gate that tells when the image is complete is enqueued when that
+    // next frame is published (feed_try_publish); if none comes, whoever closes the launch tone-maps the classic way (resolve_fused_orphan).
+    if (h->feed.open && h->feed.display && h->pendingFrames == 0 && h->feed.pendingSlot < 0 && h->frame == h->feed.firstFrame + h->feed.published &&
+        !(h->hostErrWord && *(volatile unsigned int *)h->hostErrWord)) {
+        pt_renderer::FeedState &f = h->feed;
+        if (s.boundDev != nullptr) { // (the launch knows the slots' bound images: binding closes it)
+            if (s.inFlight) { // (a host that reuses a slot before having waited for it: wait here)
+                if (int rc = ptimpl::wait_slot(h, s, nullptr)) return rc;
+                s.inFlight = false;
+            }
+            if (!f.open) return pt_present_rgba8_async(h, slot); // (the wait closed the launch: the classic way — presentCadence is set again, harmless)
+            const int j = f.published - 1;
+            f.slots16 = (f.slots16 & ~(3u << (2 * (j & 7)))) | ((unsigned int)(slot + 1) << (2 * (j & 7)));
+            f.pendingSlot = slot; // (the word that publishes the next frame carries the entry)
+            FEED_LOG("present frame %d into slot %d (fused, waits for the next frame)", h->frame, slot);
+            s.inFlight = true;
+            s.valid = false;
+            s.frame = h->frame;
+            s.rows = h->rows;
+            s.width = h->width;
+            s.snapSource = image; // (non-null: pt_present_wait looks at the abandon epoch)
+            s.snapGeneration = 0;
+            s.abandonEpoch = h->abandonEpoch;
+            s.fedPresent = true;
+            s.fusedWaiting = true;
+            s.fusedWord = f.hostWord;
+            s.fusedNeed = (unsigned int)(j + 2); // (frame j + 1 of the launch complete = its tile passes have tone-mapped frame j everywhere)
+            return PT_OK;
+        }
+    }
+    if (s.inFlight && s.fedPresent) { // (the slot's previous present was a fused one: no event to order behind — wait for it here)
+        if (int rc = ptimpl::wait_slot(h, s, nullptr)) return rc;
+        s.inFlight = false;
+    }
+    s.fedPresent = false;
     const bool snapshotCapable = (h->variant == 0 || h->variant >= 10) && !h->externalStream() && !ptimpl::timeline_blocks_pipelining(h);
     if (snapshotCapable && h->pendingFrames > 0)
         if (int rc = ptimpl::flush_with_snapshot(h, pt::tuning().renderWaitUs)) return rc;
@@ -1367,11 +1777,16 @@ PT_API int pt_present_bind_device_image(pt_handle h, int slot, void *device_rgba
     if (device_rgba8 && bytes < h->tilePixels() * 4) return fail(h, PT_E_BAD_ARGUMENT, "device image smaller than rows*width*4 bytes");
     if (int rc = bind_device(h)) return rc;
     ptimpl::PresentSlot &s = h->slots[slot];
+    if (h->feed.open || h->fusedOrphanSlot >= 0) { // (an open fed launch writes the slots' images as they were when it started)
+        ptimpl::feed_close(h);
+        if (int rc = join_stripes(h)) return rc;
+    }
     if (s.inFlight) { // a present into the slot's previous image may still be running
-        PT_HIP(h, hipEventSynchronize(s.copied));
+        if (int rc = ptimpl::wait_slot(h, s, nullptr)) return rc;
         s.inFlight = false;
     }
     s.valid = false;
+    s.fedPresent = false;
     s.boundDev = device_rgba8;
     s.boundBytes = device_rgba8 ? bytes : 0;
     return PT_OK;
@@ -1386,7 +1801,11 @@ PT_API int pt_present_wait(pt_handle h, int slot, const uint8_t **out_host_rgba8
     if (!s.inFlight && !s.valid) return fail(h, PT_E_BAD_ARGUMENT, "nothing was presented into this slot");
     if (int rc = bind_device(h)) return rc;
     if (s.inFlight) {
-        PT_HIP(h, hipEventSynchronize(s.copied));
+        // (a fused present whose successor frame has not been published: nobody will tone-map it on the device — wait_slot closes the launch
+        // and joins: resolve_fused_orphan tone-maps the frame from the accumulation image, which holds exactly that frame)
+        bool fusedAbandoned = false;
+        if (int rc = ptimpl::wait_slot(h, s, &fusedAbandoned)) return rc;
+        if (fusedAbandoned) s.abandonEpoch = h->abandonEpoch - 1; // (the image is re-done below, behind a join)
         s.inFlight = false;
         s.valid = true;
         // The image's frames are complete (the copy stream is behind them).  An image tone-mapped behind a JOIN had the hand-over repair
@@ -1398,7 +1817,20 @@ PT_API int pt_present_wait(pt_handle h, int slot, const uint8_t **out_host_rgba8
                 if (int rc = join_stripes(h)) return rc;
                 if (*(volatile unsigned int *)h->hostErrWord) ptimpl::note_abandonment(h);
             }
-            if (s.abandonEpoch != h->abandonEpoch) {
+            if (s.abandonEpoch != h->abandonEpoch && s.fedPresent) {
+                // a frame-fed launch was abandoned (a hand-over out of its budget, or it ended idle while this frame was being published):
+                // the snapshot may lack pixels and its buffer may already hold later frames.  Behind the join the accumulation image is
+                // complete (repair passes): show THAT — every frame rendered so far, at least the frame this slot was presented at
+                if (int rc = ptimpl::fix_alpha(h)) return rc;
+                void *const image = s.boundDev ? s.boundDev : s.dRgba8;
+                const size_t pixels = (size_t)s.rows * s.width;
+                PT_HIP(h, pt::launch_postprocess(h->accum(), image, pixels, h->stream));
+                if (!s.boundDev) PT_HIP(h, hipMemcpyAsync(s.host, s.dRgba8, pixels * 4, hipMemcpyDeviceToHost, h->stream));
+                PT_HIP(h, hipStreamSynchronize(h->stream));
+                if (int rc = ptimpl::settle_handover(h)) return rc;
+                s.abandonEpoch = h->abandonEpoch;
+                s.frame = h->frame;
+            } else if (s.abandonEpoch != h->abandonEpoch) {
                 int k = -1;
                 for (int i = 0; i < pt_renderer::kSnapshots; i++)
                     if (h->dSnap[i] == s.snapSource && h->snapGeneration[i] == s.snapGeneration) k = i;
@@ -1624,8 +2056,17 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_handover_stats(pt
 
 // Test aid (not declared in the public header): how the handle has been launching.  out[0] = pt_render-driven launch_frames calls (a striped
 // frame counts once), [1] = 1 while the cached tile masks are valid, [2] = frames accepted by pt_render and not launched yet, [3] = tile-mask
-// rebuilds, [4] = frame counter, [5] = flushes forced by an input change (upload / set_params with different values).  Does not flush or join.
-extern "C" __attribute__((visibility("default"))) int pt_debug_launch_stats(pt_handle h, unsigned long long out[6])
+// rebuilds, [4] = frame counter, [5] = flushes forced by an input change (upload / set_params with different values), [6] = frames published into frame-fed launches, [7] = fed
+// launches opened, [8] = fed launches that ended idle, [9] = 1 while one is open, [10] = 1 once the host has pipelined frames (single frames then go
+// out as tagged launches).  Does not flush or join.
+#ifdef PT_FEED_TIMES
+extern "C" __attribute__((visibility("default"))) int pt_debug_feed_times(pt_handle h, unsigned int *out128)
+{
+    for (int i = 0; i < 64; i++) { out128[i] = h->hostStarted[3000 + i]; out128[64 + i] = h->hostStarted[3100 + i]; }
+    return PT_OK;
+}
+#endif
+extern "C" __attribute__((visibility("default"))) int pt_debug_launch_stats(pt_handle h, unsigned long long out[12])
 {
     PT_CHECK_HANDLE(h);
     if (!out) return fail(h, PT_E_BAD_ARGUMENT, "out == NULL");
@@ -1636,6 +2077,12 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_launch_stats(pt_h
     out[3] = r->statMaskBuilds;
     out[4] = (unsigned long long)r->frame;
     out[5] = r->statFlushes;
+    out[6] = r->statPublishes;
+    out[7] = r->statFeedOpens;
+    out[8] = r->statFeedIdle;
+    out[9] = r->feed.open ? 1 : 0;
+    out[10] = r->sawBatch ? 1 : 0;
+    out[11] = 0;
     return PT_OK;
 }
 

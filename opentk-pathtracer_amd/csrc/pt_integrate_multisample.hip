@@ -45,6 +45,21 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
     const int CONT_BATCH_MIN = a.contBatchMin; // parked continuations that make a batch pass worth its ~950 instructions
     const int parkCapacity = a.contCapacity; // per wavefront (whatever LDS is left next to scene and rings, see the launch)
     ContEntry *cq = (ContEntry *)(ringBase + NWAVES * 64 * (int)sizeof(PathEntryM)) + wave * parkCapacity;
+    // IRR_LDS (the kernels whose materials live in device memory: the addresses cost them registers, and they have the materials' LDS to
+    // spare): the lane's running irradiance sum — touched only where a sample ends, a path is popped or a pixel is parked — lives in three
+    // LDS planes of 64 floats per wavefront instead of three VGPRs that are live across the whole bounce (round 5: these two
+    // instantiations spilled 6 and 24 VGPRs to scratch)
+    constexpr bool IRR_LDS = !MATLDS;
+    [[maybe_unused]] float *const laneIrr = (float *)(ringBase + NWAVES * 64 * (int)sizeof(PathEntryM) + NWAVES * parkCapacity * (int)sizeof(ContEntry)) + wave * 4 * 64 + lane;
+    v3 irrReg = V(0, 0, 0);
+    auto get_irr = [&]() -> v3 {
+        if constexpr (IRR_LDS) return V(laneIrr[0], laneIrr[64], laneIrr[128]);
+        else return irrReg;
+    };
+    auto set_irr = [&](v3 v) -> void {
+        if constexpr (IRR_LDS) { laneIrr[0] = v.x; laneIrr[64] = v.y; laneIrr[128] = v.z; }
+        else irrReg = v;
+    };
     // image coordinates of accumulation pixel `p` of this launch: x | global row << 16
     auto pixel_xy = [&](int p) -> int { // p = x | local row << 16 (no division anywhere)
         ColdArgs ca = cold_args();
@@ -63,14 +78,37 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         return sl >= parkCapacity ? sl - parkCapacity : sl;
     };
     bool exhausted = false;
-    int pix = -1, sample = 0, bounce = 0, fj = 0;
+    // the lane's counters in ONE register, in PathEntryM's layout: bounces done | sample << 12 | frame of the batch << 24 (three registers
+    // live across the bounce were two too many for the instantiations that read materials from device memory)
+    // IRR_LDS kernels: the lane's PIXEL lives in a fourth LDS plane too (it is only read where a pixel is parked, resolved or given a new
+    // primary ray), and "this lane holds no path" is bit 31 of the counters
+    int pixReg = -1, counters = IRR_LDS ? -1 : 0;
+    auto lane_idle = [&]() -> bool {
+        if constexpr (IRR_LDS) return counters < 0;
+        else return pixReg < 0;
+    };
+    auto set_idle = [&]() -> void {
+        if constexpr (IRR_LDS) counters = -1;
+        else pixReg = -1;
+    };
+    auto get_pix = [&]() -> int {
+        if constexpr (IRR_LDS) return __builtin_bit_cast(int, laneIrr[192]);
+        else return pixReg;
+    };
+    auto set_pix = [&](int p) -> void { // (followed by an assignment of the counters, which clears the idle bit)
+        if constexpr (IRR_LDS) laneIrr[192] = __builtin_bit_cast(float, p);
+        else pixReg = p;
+    };
+    auto c_bounce = [&]() -> int { return counters & 0xfff; };
+    auto c_sample = [&]() -> int { return (counters >> 12) & 0xfff; };
+    auto c_fj = [&]() -> int { return (counters >> 24) & 0x7f; };
     bool needRay = false, pending = false;
-    float walkFrom = -1.0f, walkFresh = -1.0f; // (WALK SLICES, as in the persistent kernel)
+    float walkFrom = -1.0f; // (WALK SLICES, as in the persistent kernel)
 #ifdef PT_PROFILE
     unsigned long long prof_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // (this kernel has no section counters of its own)
 #endif
     uint32_t seed = 0;
-    v3 ro = V(0, 0, 0), rd = V(0, 0, 1), throughput = V(1, 1, 1), rad = V(0, 0, 0), irr = V(0, 0, 0);
+    v3 ro = V(0, 0, 0), rd = V(0, 0, 1), throughput = V(1, 1, 1), rad = V(0, 0, 0);
 
     auto fold = [&](float4 last, v3 rirr, int rfj) -> float4 { // compute.glsl:125-129
         ColdArgs ca = cold_args();
@@ -119,10 +157,11 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         if (room > 0) {
             if (lane < room) { // (every lane waits, so lane l parks into the l-th free slot)
                 ContEntry e;
-                e.pix = pix; e.seed = seed; e.sfj = sample | (fj << 16); // sample == spp marks "last sample done, waiting"
+                e.pix = get_pix(); e.seed = seed; e.sfj = c_sample() | (c_fj() << 16); // sample == spp marks "last sample done, waiting"
+                const v3 irr = get_irr();
                 e.irr[0] = irr.x; e.irr[1] = irr.y; e.irr[2] = irr.z;
                 cq[qslot(parked + lane)] = e;
-                pix = -1;
+                set_idle();
                 pending = false;
             }
             parked += room < 64 ? room : 64;
@@ -131,7 +170,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
     };
 
     for (;;) {
-        bool idle = pix < 0;
+        bool idle = lane_idle();
         unsigned long long m = __ballot(idle);
         // ---- forced batch pass (the progress guarantee of the pipelining).  When EVERY lane holds a finished pixel that waits for its
         // previous frame, nothing pops the ring or runs a batch pass any more — and the work those lanes wait for may be parked in this
@@ -141,7 +180,12 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         // leaves at least as much room in the queue as it put paths into the ring — so rescue() below can then free lanes for them.
         // Waiting records it meets are retried and rotate to the back of the FIFO.  With the tickets handed out frame-major, all
         // work of the oldest unfinished frame is therefore always executed by whichever wavefront holds it: no cycle of waits.
-        bool forcePass = parked > 0 && avail < 64 && __ballot(!(pix >= 0 && pending && !needRay)) == 0ull;
+        bool forcePass = parked > 0 && avail < 64 && __ballot(!(!lane_idle() && pending && !needRay)) == 0ull;
+        // EARLY PASS (sphere-grid scenes only, round 5 measurement / round 6 merge): a batch pass as soon as the queue is within 40 records
+        // of full and the ring has room for it, so that the queue never overflows — an overflowing continuation takes its next sample's
+        // first bounce in the lane, unculled, against all 256 spheres: +3.5 % at C3 4 spp; the 48-sphere scene's unculled bounce is cheaper
+        // than a thin pass (-2 % there), hence tied to GRID (profiles/r05/multisample_early_pass.log)
+        if constexpr (GRID) forcePass = forcePass || (parked + 40 >= parkCapacity && avail <= 24 && parked > 0);
         for (int pass = 0; pass < 16 && (m != 0ull || forcePass); pass++) {
             if (avail == 0 || forcePass) {
                 // ---- batch pass: 64 parked continuations, or the next tile's 64 pixels (sample 0)
@@ -225,6 +269,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                     cull_spheres(sc, a.numSpheres, valid, to, td, masks); // (continuations of several tiles: bounded from the rays themselves)
                 }
                 bool tcont = false;
+                float walkFresh = -1.0f; // (the batch pass never walks the grid: a local, not a register carried round the main loop)
                 if (valid) {
                     if (0 < a.rayDepth) tcont = bounce_step_t<true, MATLDS>(sc, a.numSpheres, a.numCuboids, env, to, td, tthr, trad, tseed, masks, walkFresh PROF_DUMMY);
                     if (1 >= a.rayDepth) tcont = false;
@@ -297,10 +342,8 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             if (idle && rank < avail) {
                 const PathEntryM e = ring[avail - 1 - rank];
-                pix = e.pix;
-                bounce = e.counters & 0xfff;
-                sample = (e.counters >> 12) & 0xfff;
-                fj = (e.counters >> 24) & 0x7f;
+                set_pix(e.pix);
+                counters = e.counters & 0x7fffffff;
                 needRay = e.counters < 0;
                 pending = false;
                 walkFrom = -1.0f; // (a fresh path: no unfinished grid walk)
@@ -309,15 +352,15 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
                 rd = V(e.rd[0], e.rd[1], e.rd[2]);
                 throughput = V(e.thr[0], e.thr[1], e.thr[2]);
                 rad = V(e.rad[0], e.rad[1], e.rad[2]);
-                irr = V(e.irr[0], e.irr[1], e.irr[2]);
-                if (!needRay && bounce >= a.rayDepth && sample >= a.spp) pending = true; // a resolve that had to wait
+                set_irr(V(e.irr[0], e.irr[1], e.irr[2]));
+                if (!needRay && c_bounce() >= a.rayDepth && c_sample() >= a.spp) pending = true; // a resolve that had to wait
             }
             const int n = __builtin_popcountll(m);
             avail = n < avail ? avail - n : 0;
-            idle = pix < 0;
+            idle = lane_idle();
             m = __ballot(idle);
         }
-        bool active = pix >= 0;
+        bool active = !lane_idle();
         if (__ballot(active) == 0ull) {
             if (exhausted && avail == 0 && parked == 0) break;
             if (bound.tick(0ull, stallSince, true)) stop_queue(&queue); // (only waiting records left in the queue: they are retried — or, abandoned, dropped — by the batch passes above)
@@ -329,35 +372,35 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
             // (round 4: the lanes rescue() has just emptied are NOT active any more.  They used to run one bounce of their dead path below —
             // harmless while a bounce left nothing behind in the lane, but a grid walk cut short (WALK SLICES) leaves walkFrom, and the
             // path the lane pops next would have resumed someone else's walk: found by tools/handover_stress --multisample)
-            active = pix >= 0;
+            active = !lane_idle();
         }
         // (a wavefront that has done nothing but wait for FrameArgs::waitBudget abandons the launch: waiting records move between lanes,
         // ring and queue, so the bound is kept per wavefront, not per lane)
         // ... and a result that sits in a lane is timed like the spp = 1 kernel's: the same lanes waiting for the whole budget.  (Any waiting
         // lane also makes the wavefront look at the abandon word now and then: an abandoned launch stops drawing tickets.)
-        const bool nothingTraced = __ballot(pix >= 0 && !pending) == 0ull;
-        const unsigned long long laneWaits = __ballot(pix >= 0 && pending && !needRay);
+        const bool nothingTraced = __ballot(!lane_idle() && !pending) == 0ull;
+        const unsigned long long laneWaits = __ballot(!lane_idle() && pending && !needRay);
         if (nothingTraced || stallSince != 0u || laneWaits != 0ull)
             if (bound.tick(laneWaits, stallSince, nothingTraced)) stop_queue(&queue);
         if (active && needRay) { // fallback (queue was full): the next sample's primary ray, generated in the lane
-            const int pxy = pixel_xy(pix);
+            const int pxy = pixel_xy(get_pix());
             primary_ray(a, pxy & 0xffff, pxy >> 16, seed, ro, rd);
             throughput = V(1.0f, 1.0f, 1.0f);
             rad = V(0.0f, 0.0f, 0.0f);
-            bounce = 0;
+            counters &= ~0xfff; // bounce = 0
             needRay = false;
         }
         bool wantPark = false;
         const bool trace = active && !pending; // (one divergent region around the bounce, as in the persistent kernel)
         bool cont = false;
-        if (trace && bounce < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID, (MATLDS && !GRID)>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr, walkFrom PROF_DUMMY);
+        if (trace && c_bounce() < a.rayDepth) cont = bounce_step_t<false, MATLDS, GRID, (MATLDS && !GRID)>(sc, a.numSpheres, a.numCuboids, env, ro, rd, throughput, rad, seed, nullptr, walkFrom PROF_DUMMY);
         if (trace) {
             const bool sliced = GRID && walkFrom >= 0.0f; // (the grid walk of this bounce continues in the next iteration: pt_device.hpp, WALK SLICES)
-            if (!sliced) bounce++;
-            if (!sliced && (!cont || bounce >= a.rayDepth)) {
-                irr = v_add(irr, rad); // compute.glsl:122
-                sample++;
-                if (sample < a.spp) wantPark = true;
+            if (!sliced) counters++; // bounce++ (< 4096 by the ABI's ray_depth limit: no carry into the sample field)
+            if (!sliced && (!cont || c_bounce() >= a.rayDepth)) {
+                set_irr(v_add(get_irr(), rad)); // compute.glsl:122
+                counters += 1 << 12; // sample++
+                if (c_sample() < a.spp) wantPark = true;
                 else pending = true; // the pixel's last sample: fold into the accumulation image
             }
         }
@@ -368,10 +411,11 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
             const int room = parkCapacity - parked;
             if (wantPark && rank < room) {
                 ContEntry e;
-                e.pix = pix; e.seed = seed; e.sfj = sample | (fj << 16);
+                e.pix = get_pix(); e.seed = seed; e.sfj = c_sample() | (c_fj() << 16);
+                const v3 irr = get_irr();
                 e.irr[0] = irr.x; e.irr[1] = irr.y; e.irr[2] = irr.z;
                 cq[qslot(parked + rank)] = e;
-                pix = -1;
+                set_idle();
             } else if (wantPark) {
                 needRay = true;
             }
@@ -379,14 +423,14 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
             parked += n < room ? n : room;
             __builtin_amdgcn_wave_barrier();
         }
-        if (pix >= 0 && pending) {
-            if (try_resolve(pix, fj, irr) || bound.abandoned) { // (abandoned launch: a result that still has to wait is dropped, the host's repair pass renders it)
-                pix = -1;
+        if (!lane_idle() && pending) {
+            if (try_resolve(get_pix(), c_fj(), get_irr()) || bound.abandoned) { // (abandoned launch: a result that still has to wait is dropped, the host's repair pass renders it)
+                set_idle();
                 pending = false;
             }
         }
         { // nothing but waiting paths left in this wavefront: do not hammer the pixel
-            const bool act = pix >= 0;
+            const bool act = !lane_idle();
             if (__ballot(act && pending) != 0ull && __ballot(act && !pending) == 0ull && parked < CONT_BATCH_MIN && avail == 0)
                 __builtin_amdgcn_s_sleep(8);
         }

@@ -287,12 +287,22 @@ struct DrainControl {        // static LDS, one per workgroup
 // generic bounce loop.  Per path the arithmetic is unchanged (same tests in the same order, same RNG draws).
 // COMPACT = false: the donate / adopt code of the drain compaction is compiled out (pipelined launches never use it, and while it sits in
 // the main loop the compiler keeps a second copy of the path state around it: "feed" was 20 % of the 256-sphere scene's wavefront time).
-template <int NWAVES, int MIN_WAVES_PER_SIMD, bool TIMELINE, bool SPP1, bool MATLDS, bool GRID = false, bool CARRY = false, bool COMPACT = true>
+// FEED = true: a FRAME-FED launch (FrameArgs::feedHost, round 6) — the launch is started with room for kFeedCapacity frames and begins a
+// frame when the host has published it (PathTracer.Render() of a host that shows every frame: the wavefronts stay resident between frames
+// instead of draining and being launched again).  Differences, all behind `if constexpr (FEED)`: tickets come through queue_pop_tile_feed
+// (a wavefront may be told "not yet"), a wavefront with nothing to trace and nothing published waits (bounded: feedIdleTicks, then the
+// launch is abandoned with reason "idle"), resolved pixels are counted per frame (feedDone: the present's gate), and every frame may
+// store a present snapshot (snapshots[]).  The arithmetic per pixel is untouched: bit-identical to every other kernel.
+template <int NWAVES, int MIN_WAVES_PER_SIMD, bool TIMELINE, bool SPP1, bool MATLDS, bool GRID = false, bool CARRY = false, bool COMPACT = true, bool FEED = false>
 __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_persistent_kernel(const FrameArgs a)
 {
     static_assert(!(CARRY && COMPACT), "the carrying kernels are only launched without drain compaction");
+    static_assert(!FEED || (SPP1 && !COMPACT && !TIMELINE), "frame-fed launches: spp = 1, no drain compaction");
     __shared__ __attribute__((aligned(16))) BlockQueue queue; // 16 B: keeps the dynamic-LDS base 16-byte aligned
     __shared__ __attribute__((aligned(16))) DrainControl drain; // 32 B
+    __shared__ __attribute__((aligned(16))) FeedQueue feedq;    // 16 B (FEED kernels only; the others never touch it: not allocated)
+    __shared__ unsigned int wgDone[8];                          // FEED: pixels resolved per frame slot by this workgroup whose stores are complete, since its last flush
+    __shared__ unsigned int waveDone[FEED ? NWAVES * 8 : 1];    // FEED: ... per wavefront, not yet released (their stores may still be on their way)
     const int numTilesFrame = a.tilesX * a.tilesY;
     const int numTiles = numTilesFrame * a.batchFrames;         // (frame, tile) pairs, frame-major
     // 1 / (frame + j + 1): running-mean weight of the batch's frame j.  In DYNAMIC LDS between the scene and the rings, sized by the
@@ -322,13 +332,88 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         drain.alive = (unsigned int)NWAVES;
         drain.pushing = 0u;
         drain.lock = 0u;
+        if constexpr (FEED) {
+            feedq.stash = 0ull;
+            feedq.limit = 0u; // (refreshed by the first refill)
+            feedq.word = 0u;
+            feedq.pollAt = 0u;
+        }
         if (a.startedFlags) // "this workgroup is resident" (launch chaining): a system-scope store, the host polls the word
             __hip_atomic_store(a.startedFlags + blockIdx.x, a.launchSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if constexpr (FEED) {
+        if (threadIdx.x < 8) wgDone[threadIdx.x] = 0u;
+        if (threadIdx.x < NWAVES * 8) waveDone[threadIdx.x] = 0u;
     }
     CHAOS(1);
     SceneLds sc = stage_scene(a); // ends with __syncthreads()
     EnvRef env{nullptr, (LdsFloats)sc.lut, 0, 0}; // descriptor is cold-loaded at the miss-shading site (bounce_step)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // FEED: a resolved pixel of frame j of the launch counts into slot j & 7 of its WAVEFRONT's LDS counters (one ds_add per resolving
+    // lane).  release_resolved() — called where the wavefront has just waited for its memory operations anyway (the tile pass, behind the
+    // tile's pixel load) — moves them to the WORKGROUP's counters: only pixels whose stores (image + display) are complete are ever
+    // counted on.  flush_resolved() — the wavefront that starts a new ticket, or runs out of work — moves the workgroup's counters to
+    // FrameArgs::feedDone: one device atomic per non-empty slot per ticket (~4,000 per 1080p frame; one per wavefront iteration was
+    // 86,000, and the atomics of one address serialise at ~8 ns each: 0.69 ms per frame).
+    [[maybe_unused]] unsigned int *const myDone = waveDone + (FEED ? wave * 8 : 0);
+    [[maybe_unused]] auto count_resolved = [&](int rfj) -> void {
+        if constexpr (FEED) atomicAdd(myDone + (rfj & 7), 1u);
+    };
+    [[maybe_unused]] auto release_resolved = [&]() -> void {
+        if constexpr (FEED) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane < 8) {
+                const unsigned int v = lds_load(myDone + lane);
+                if (v != 0u) {
+                    lds_store(myDone + lane, 0u);
+                    atomicAdd(wgDone + lane, v);
+                }
+            }
+        }
+    };
+    [[maybe_unused]] auto flush_resolved = [&]() -> void {
+        if constexpr (FEED) {
+            if (lane < 8) {
+                const unsigned int v = atomicExch(wgDone + lane, 0u);
+                if (v != 0u) __hip_atomic_fetch_add(cold_args()->feedDone + lane * kFeedDoneStride, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    // FEED, fused display (FrameArgs::displayImages): the present slot + 1 of frame rfj - 1 of the launch (0: that frame is not shown), from
+    // the workgroup's copy of the feed word — whoever is handed a tile of frame rfj has seen a word whose count includes it, and the host
+    // puts the slot of frame rfj - 1 into the word that publishes frame rfj.  Wave-uniform for a wave-uniform rfj.
+    [[maybe_unused]] auto display_slot_before = [&](int rfj) -> unsigned int {
+        if constexpr (FEED) {
+            if (rfj == 0) return (unsigned int)cold_args()->displayPrev;
+            return (lds_load(&feedq.word) >> (2 * ((rfj - 1) & 7))) & 3u;
+        } else {
+            return 0u;
+        }
+    };
+    // PostProcessing/fragment.glsl:17-26 for one pixel: ACES + gamma 2.4 -> RGBA8 (the arithmetic of pt_postprocess_kernel)
+    [[maybe_unused]] auto display_pixel = [&](unsigned int slot, int rpix, float r, float g, float b) -> void {
+        if constexpr (FEED) {
+            ColdArgs ca = cold_args();
+            uchar4 *img = slot == 1u ? ca->displayImages[0] : (slot == 2u ? ca->displayImages[1] : ca->displayImages[2]);
+            uchar4 o;
+            o.x = to_unorm8(linear_to_inverse_gamma(aces_film(r), 2.4f));
+            o.y = to_unorm8(linear_to_inverse_gamma(aces_film(g), 2.4f));
+            o.z = to_unorm8(linear_to_inverse_gamma(aces_film(b), 2.4f));
+            o.w = 255;
+            unsigned int packed;
+            __builtin_memcpy(&packed, &o, 4);
+            asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" : : "v"(img + rpix), "v"(packed) : "memory"); // (write-through: read by the host's copy / GL while this launch runs)
+        }
+    };
+    // the present snapshot of the launch's LAST frame, if the launch feeds a present (classic launches; a fed launch shows its frames
+    // through the fused display instead)
+    [[maybe_unused]] auto store_snapshot = [&](int rpix, int rfj, float4 next) -> void {
+        if constexpr (!FEED) {
+            if (float4 *snap = cold_args()->snapshot) // (wave-uniform, almost always null)
+                if (rfj == cold_args()->batchFrames - 1) snap[rpix] = make_float4(next.x, next.y, next.z, 1.0f);
+        }
+    };
+
     // the ring lives behind the staged scene in dynamic LDS
     static_assert(!CARRY || SPP1, "the pixel travels with the path in the tile-pass kernels only");
     using PathRec = typename std::conditional<CARRY, PathEntryCarry, PathEntry>::type;
@@ -354,6 +439,42 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
     const int donateMax = a.drainCompaction < DONATE_MAX ? a.drainCompaction : DONATE_MAX; // a wavefront this thin donates
     const bool leader = lane == 0;
 
+    if constexpr (FEED) {
+        // ---- the MONITOR: the last wavefront of workgroup 0 takes no tiles.  It is the launch's only reader of the host word (PCIe), which
+        // it broadcasts to the workgroups' slots (FrameArgs::feedBcast) whenever it changes, and it tells the host which frames are
+        // complete (FrameArgs::feedHostDone).
+        if (blockIdx.x == 0 && wave == NWAVES - 1) {
+            ColdArgs ca = cold_args();
+            unsigned int j = 0;      // frames [0, j) of the launch are complete
+            unsigned int seen = 0u;  // the word broadcast last (0: none yet — the slots were zeroed before the launch)
+            for (;;) {
+                unsigned int w = __hip_atomic_load(ca->feedHost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                w = (unsigned int)__builtin_amdgcn_readfirstlane((int)w);
+                if (w != seen) { // (the word only ever grows: a newer count, then the closed bit)
+#ifdef PT_FEED_TIMES
+                    if (lane == 0 && a.startedFlags) __hip_atomic_store(a.startedFlags + 3100 + (feed_count(w) & 63), (unsigned int)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+                    for (int s4 = lane; s4 < kFeedBcastSlots; s4 += 64)
+                        __hip_atomic_store(ca->feedBcast + s4 * kFeedBcastStride, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    seen = w;
+                }
+                while (j < (unsigned int)ca->batchFrames) {
+                    const unsigned long long need = ca->feedBase[j & 7] + ca->feedPixels * (unsigned long long)(j / 8 + 1);
+                    const unsigned long long have = __hip_atomic_load(ca->feedDone + (j & 7) * kFeedDoneStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!__builtin_amdgcn_readfirstlane((int)(have >= need))) break;
+                    j++;
+                    if (lane == 0) __hip_atomic_store(ca->feedHostDone, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef PT_FEED_TIMES
+                    if (lane == 0 && a.startedFlags) __hip_atomic_store(a.startedFlags + 3000 + (j & 63), (unsigned int)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+                }
+                if (((w & kFeedClosed) && j >= feed_count(w)) || j >= (unsigned int)ca->batchFrames) break; // every frame the launch will ever have is complete
+                if (launch_abandoned()) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            return;
+        }
+    }
     int avail = 0;           // wave-uniform: ring entries [0, avail) are unconsumed
     bool exhausted = false;
     bool lastAlive = false;  // this wavefront found itself the last one of its workgroup: it can neither donate nor leave early
@@ -405,8 +526,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         AUDIT_RESOLVE(a, (size_t)rpix, a.frame + rfj, last, next, 7);
         if (!a.tagged) a.accum[rpix] = next;
         else store_pixel_sc1(a.accum + rpix, next);
-        if (float4 *snap = cold_args()->snapshot) // (wave-uniform, almost always null: the present snapshot of the launch's last frame)
-            if (rfj == cold_args()->batchFrames - 1) snap[rpix] = make_float4(next.x, next.y, next.z, 1.0f);
+        store_snapshot(rpix, rfj, next);
+        count_resolved(rfj);
     };
     // False = the pixel still holds an older frame (only possible inside a batch): try again in the next iteration.
     auto try_resolve = [&](int rpix, int rfj, v3 rirr) -> bool {
@@ -423,13 +544,19 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         float4 last = load_pixel_sc1(ptr);
         const float expected = rfj > 0 ? frame_tag(a.frame + rfj - 1) : a.chainTag; // (0 = the launch's first frame has no predecessor in flight)
         if (expected != 0.0f && last.w != expected) return false;
+        if constexpr (FEED) { // fused display: this pixel's tile pass could not show frame rfj - 1 (its value was not there yet): here it is
+            if (cold_args()->displayOn != 0) {
+                const unsigned int dslot = (rfj == 0) ? (unsigned int)cold_args()->displayPrev : ((lds_load(&feedq.word) >> (2 * ((rfj - 1) & 7))) & 3u);
+                if (dslot != 0u) display_pixel(dslot, rpix, last.x, last.y, last.z);
+            }
+        }
         if (AUDIT_SABOTAGED(a, rpix, rfj)) last.x += 1.0f; // (audit build + PT_AUDIT_SABOTAGE only: a simulated stale / torn read)
         CHAOS(11);
         const float4 next = fold(last, rirr, rfj);
         AUDIT_RESOLVE(a, (size_t)rpix, a.frame + rfj, last, next, 4);
         store_pixel_sc1(ptr, next);
-        if (float4 *snap = cold_args()->snapshot) // the launch's last frame: the present snapshot (plain store, read after the launch)
-            if (rfj == cold_args()->batchFrames - 1) snap[rpix] = make_float4(next.x, next.y, next.z, 1.0f);
+        store_snapshot(rpix, rfj, next); // the launch's last frame (FEED: every frame): the present snapshot
+        count_resolved(rfj);
         CHAOS(12);
         return true;
     };
@@ -472,17 +599,34 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         __builtin_amdgcn_wave_barrier();
     };
 
+    [[maybe_unused]] bool starved = false;          // FEED: the queue said "not yet" in this iteration (wave-uniform)
+    [[maybe_unused]] unsigned int idlePolls = 0u;
+    [[maybe_unused]] unsigned int lastLimit = 0u;   // FEED: feedq.limit when this wavefront last looked (a change = the host published)
+    [[maybe_unused]] unsigned int idleSince = 0u;   // FEED: (clock | 1) since when this wavefront has had nothing to trace and nothing published
     for (;;) {
         // ---- feed idle lanes: pop from the ring; if the ring runs dry while lanes are still idle, refill it with the next
         // tile and pop again in the SAME iteration (a lane never idles through a bounce iteration because the ring happened
         // to hold fewer rays than there were idle lanes)
         bool idle = pix < 0;
         unsigned long long m = __ballot(idle);
+        if constexpr (FEED) starved = false;
         for (int pass = 0; (SPP1 ? pass < 16 : pass < 2) && m != 0ull; pass++) {
             if (avail == 0) {
                 if (exhausted) break;
                     // ---- refill the ring: one tile, every lane generates one primary ray
-                    int tile = queue_pop_tile(&queue);
+                    int tile;
+                    if constexpr (FEED) {
+                        tile = queue_pop_tile_feed(&queue, &feedq);
+                        if (tile < 0) release_resolved(); // (no tile: nothing else will make this wavefront wait for its stores)
+                        if ((tile & 7) == 0 || tile < 0) flush_resolved(); // (the first tile of a ticket, or no tile: move the workgroup's counts on)
+                        if (tile == QUEUE_NOT_YET) { // the next frame is not published yet: go on with what the lanes hold, ask again next iteration
+                            starved = true;
+                            break;
+                        }
+                        idleSince = 0u;
+                    } else {
+                        tile = queue_pop_tile(&queue);
+                    }
                     if (tile < 0) {
                         exhausted = true;
                         if (TIMELINE) tExhausted = wall_clock64();
@@ -537,6 +681,18 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                                 plast = a.accum[tpix];
                                 const float expected = tfj > 0 ? frame_tag(a.frame + tfj - 1) : a.chainTag;
                                 plastOk = !a.tagged || expected == 0.0f || plast.w == expected;
+                                if constexpr (FEED) {
+                                    // (the wavefront has just waited for the tile's pixels: every store it issued before — the pixels it
+                                    // has counted so far — is complete; the resolves below are counted now and released by the NEXT tile pass)
+                                    release_resolved();
+                                    // FUSED DISPLAY: the tile's 64 pixels as frame tfj - 1 left them are in registers, all lanes
+                                    // together — if that frame is shown, this is its tone map (a lane whose previous frame is not in yet
+                                    // shows it when its own resolve loads the pixel: try_resolve)
+                                    if (cold_args()->displayOn != 0) { // (wave-uniform)
+                                        const unsigned int dslot = display_slot_before(tfj);
+                                        if (dslot != 0u && plastOk) display_pixel(dslot, tpix, plast.x, plast.y, plast.z);
+                                    }
+                                }
                             }
                             if (CARRY && !tcont && plastOk) { // ended at its first bounce, previous frame already there: fold and store, no second load
                                 commit_resolve(tpix, tfj, v_add(V(0.0f, 0.0f, 0.0f), trad), V(plast.x, plast.y, plast.z));
@@ -567,6 +723,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                         }
                         __builtin_amdgcn_wave_barrier(); // ring entries are read by other lanes of this wave below
                         avail = __builtin_popcountll(cm);
+                        if constexpr (!CARRY) release_resolved(); // (FEED kernels that do not read the tile's pixels here: an explicit wait for the wavefront's stores)
 #ifdef PT_PROFILE
                         { // slot 6 = the tile pass (taken out of the feed slot)
                             const unsigned long long d_ = __builtin_readcyclecounter() - prof_tile0;
@@ -704,6 +861,9 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         }
         bool active = pix >= 0;
         const unsigned long long am = __ballot(active);
+        if constexpr (FEED) {
+            if (am != 0ull) idleSince = 0u; // (the idle clock runs only while the wavefront has nothing to trace)
+        }
         if (am == 0ull) {
             if (parking && nparked > 0) { // nothing to trace: look after the parked resolves (they must be gone before leaving)
                 service_parked();
@@ -714,6 +874,55 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                     }
                 }
                 if (nparked > 0 && exhausted && avail == 0) __builtin_amdgcn_s_sleep(8);
+            }
+            if constexpr (FEED) {
+                if (starved && !exhausted && nparked == 0) {
+                    // nothing to trace, nothing published: wait for the host — bounded; a host that has stopped rendering must not keep
+                    // the GPU (hand-over bound, reason "idle": the host's next call joins, repairs what a racing publish left undone,
+                    // and launches anew)
+                    // Wait HERE, cheaply, until the workgroup's view of the feed word changes (a frame was published, or the launch
+                    // closed) — a waiting wavefront must cost the wavefronts still working next to it nothing: going round the main
+                    // loop (ballots, the queue's LDS atomics, its lock) every 2 us, five waiting wavefronts per SIMD issued more
+                    // instructions than the one still tracing, and a lone frame took 0.5 ms.  One round = a long sleep + two LDS reads;
+                    // the workgroup's wavefronts take turns at looking at its broadcast slot (no lock: they would store the same words).
+                    // idle = no NEW frame for feedIdleTicks (on a small image most wavefronts never get a tile while the host publishes
+                    // away); the clock and the abandon word are looked at every 8th round (~30 us).
+                    release_resolved(); // (whatever this wavefront has counted since its last tile — parked results that came in — must not wait here with it)
+                    flush_resolved();
+                    for (unsigned int round = 0;; round++) {
+                        const unsigned int lim = (unsigned int)__builtin_amdgcn_readfirstlane((int)lds_load(&feedq.limit));
+                        const unsigned int wd = (unsigned int)__builtin_amdgcn_readfirstlane((int)lds_load(&feedq.word));
+                        if (lim != lastLimit || (wd >> 31) != 0u) { // more frames, or closed: back to the queue
+                            lastLimit = lim;
+                            idleSince = 0u;
+                            break;
+                        }
+                        if ((round & 7u) == 0u) {
+                            const unsigned int now = (unsigned int)wall_clock64();
+                            if (idleSince == 0u) idleSince = now | 1u;
+                            if ((int)(now - idleSince) > (int)cold_args()->feedIdleTicks) {
+                                abandon_launch(kAbandonIdle);
+                                stop_queue(&queue);
+                                break;
+                            }
+                            if (launch_abandoned()) {
+                                stop_queue(&queue);
+                                break;
+                            }
+                        }
+                        __builtin_amdgcn_s_sleep(127);
+                        if ((round & (NWAVES - 1)) == (unsigned int)wave) { // this wavefront's turn to look at the workgroup's broadcast slot
+                            ColdArgs ca = cold_args();
+                            unsigned int w = __hip_atomic_load(ca->feedBcast + (blockIdx.x % kFeedBcastSlots) * kFeedBcastStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            w = (unsigned int)__builtin_amdgcn_readfirstlane((int)w);
+                            if (lane == 0) {
+                                lds_store(&feedq.limit, feed_count(w) * (unsigned int)(ca->tilesX * ca->tilesY));
+                                lds_store(&feedq.word, w);
+                            }
+                        }
+                    }
+                    continue;
+                }
             }
             if (!(exhausted && avail == 0 && nparked == 0)) continue;
             if (!compaction) break;
@@ -891,6 +1100,8 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         } // !SPP1
         PROF_MARK(7) // resolve
     }
+    release_resolved();
+    flush_resolved();
 #ifdef PT_PROFILE
     if (a.timeline && lane == 0)
         for (int k = 0; k < 8; k++) {
@@ -956,9 +1167,12 @@ static int pool_tiles_for_variant(int variant)
     }
 }
 
-hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned int *ticketsConsumed, int *workgroups)
+hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned int *ticketsConsumed, int *workgroups, bool *fed)
 {
     FrameArgs a = args;
+    const bool wantFeed = fed != nullptr && *fed;
+    if (fed) *fed = false;
+    if (!wantFeed) { a.feedHost = nullptr; a.feedBcast = nullptr; a.feedDone = nullptr; a.displayImages[0] = a.displayImages[1] = a.displayImages[2] = nullptr; a.displayPrev = 0; a.displayOn = 0; }
     a.materialsInLds = 1;
     a.gridLdsBytes = 0;
     *ticketsConsumed = 0;
@@ -1043,14 +1257,14 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         }
         bool carry = spp1 && (!useGrid || gridCarry) && !perWaveTimeline && tiles >= 12000 && tune.carryLast != 0 && a.drainCompaction == 0;
         auto queue_bytes = [&](bool c) -> size_t {
-            if (useBatchPass) return (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry));
+            if (useBatchPass) return (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry)) + (size_t)waves * 64 * 16; // (+ the IRR_LDS lane slots of the lean instantiations — irradiance + pixel: counted always, 4 KB)
             return (spp1 ? frame_weight_bytes(a.batchFrames) : 0) +
                    (size_t)waves * 64 * (spp1 ? (c ? sizeof(PathEntryCarry) : sizeof(PathEntry)) + lane_last_bytes(c) : sizeof(RingEntry)) +
                    (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0) // no pool without drain compaction
                    + (spp1 && a.tagged && a.drainCompaction == 0 ? (size_t)waves * a.parkedMax * sizeof(ParkedResolve) : 0); // parked resolves of tagged launches
         };
         // materials leave LDS when they would cost a resident workgroup (160 KB per CU; 64 B of static LDS per workgroup)
-        const size_t ldsPerCU = 160 * 1024, fixedLds = 64; // (static LDS of the persistent kernels: queue, drain control)
+        const size_t ldsPerCU = 160 * 1024, fixedLds = wantFeed ? 256 : 64; // (static LDS of the persistent kernels: queue, drain control; frame-fed: + feed queue, per-wavefront counters)
         const bool forceLean = tune.forceLeanLds != 0; // A/B runs: materials always from the UBO copy
         size_t queues = 0, ldsTotal = 0;
         a.parkedMax = carry ? 0 : parkedMaxPlain;
@@ -1103,6 +1317,13 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
 #define PT_LAUNCH_PERSISTENT(TL, S1, ML) \
     hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, (S1 ? PT_SPP1_WAVES : 5), TL, S1, ML>), dim3(nwg), dim3(256), ldsTotal, stream, a)
         const bool matLds = a.materialsInLds != 0;
+        // frame-fed launch: instantiated for the tile-pass kernels with materials in LDS (the default scene's kernels), five workgroups per CU
+        const bool feed = wantFeed && spp1 && matLds && !useGrid && !perWaveTimeline && a.tagged && a.drainCompaction == 0 && blocksPerCU <= 6 &&
+                          a.batchFrames == kFeedCapacity && a.feedHost && a.feedBcast && a.feedDone;
+        if (wantFeed && !feed) return hipErrorNotSupported; // (the caller launches the classic way instead; nothing was enqueued)
+        if (feed && carry) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, 6, false, true, true, false, true, false, true>), dim3(nwg), dim3(256), ldsTotal, stream, a);
+        else if (feed) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, 6, false, true, true, false, false, false, true>), dim3(nwg), dim3(256), ldsTotal, stream, a);
+        else
         if (perWaveTimeline && spp1 && matLds) PT_LAUNCH_PERSISTENT(true, true, true); // per-wavefront timestamps (tools/timeline.py)
         else if (spp1 && matLds && carry) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_SPP1_WAVES, false, true, true, false, true, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1 && matLds && a.drainCompaction == 0) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_SPP1_WAVES, false, true, true, false, false, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
@@ -1118,6 +1339,10 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         // every workgroup draws tickets until its first failing one: (numChunks - nwg) successful + nwg failing
         // (a pipelined batch draws every chunk dynamically: numChunks successful + nwg failing)
         *ticketsConsumed = a.tagged ? (unsigned int)(numChunks + nwg) : (unsigned int)(numChunks > nwg ? numChunks : nwg);
+        if (feed) { // (the successful tickets depend on how many frames the host publishes: added when it closes the launch)
+            *ticketsConsumed = (unsigned int)nwg;
+            *fed = true;
+        }
         if (workgroups) *workgroups = nwg;
     } else {
         int poolTiles = pool_tiles_for_variant(a.variant);

@@ -120,13 +120,14 @@ PT_DEV bool launch_abandoned()
     return __builtin_amdgcn_readfirstlane((int)(w <= ca->launchSeq)) != 0;
 }
 // give the launch up (any lane may call; one atomic per wavefront is enough, more are harmless)
-PT_DEV void abandon_launch()
+// (reason: kAbandonContended = a hand-over ran out of its budget; kAbandonIdle = a frame-fed launch waited too long for its next frame)
+PT_DEV void abandon_launch(unsigned int reason = kAbandonContended)
 {
     ColdArgs ca = cold_args();
     if (ca->abandonWord == nullptr) return;
     if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(true))) {
         atomicMin((unsigned int *)ca->abandonWord, ca->launchSeq);
-        __hip_atomic_fetch_or((unsigned int *)ca->errorWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_or((unsigned int *)ca->errorWord, reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 // Wave-uniform state of the bound.  tick() is called once per iteration in which something of the wavefront waits: waitMask = the lanes
@@ -183,7 +184,11 @@ PT_DEV float4 load_pixel_sc1(const float4 *p)
 PT_DEV void store_pixel_sc1(float4 *p, float4 c)
 {
     f32x4 v = {c.x, c.y, c.z, c.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    // (s_nop 1: a VMEM store of more than 64 bits must not be followed within 2 wait states by a VALU write of its data registers — gfx940+
+    // "VMEM store data hazard".  The compiler's hazard recognizer covers its own stores but cannot see into an asm block: without the
+    // nop the instruction it schedules next may overwrite v[0] while the store still reads it — seen in round 6 as snapshot pixels whose
+    // red channel was 0.)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 
 struct RingEntry { // 40 bytes (spp > 1)
@@ -225,7 +230,7 @@ constexpr int PARKED_MAX = 64; // upper bound; FrameArgs::parkedMax is what a la
 // LDS bytes of the per-launch frame table (spp = 1 persistent kernels), 16-byte aligned: per frame of the batch its running-mean weight
 // 1 / (frame + 1) and the alpha it stores (its tag, or the reference's 1 for the launch's last frame) — everything a resolve needs to
 // know about its frame in one 8-byte LDS read, no scalar arithmetic
-__host__ __device__ constexpr size_t frame_weight_bytes(int batchFrames) { return (size_t)((batchFrames + 63) & ~63) * 8; }
+__host__ __device__ constexpr size_t frame_weight_bytes(int batchFrames) { return (size_t)((batchFrames + 31) & ~31) * 8; }
 
 struct BlockQueue {            // one per workgroup, in static LDS
     unsigned long long pair;   // (end << 32) | cursor : absolute tile indices of the current chunk
@@ -294,6 +299,110 @@ PT_DEV int queue_pop_tile(BlockQueue *q)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (leader) atomicExch(&q->lock, 0u);
+        } else {
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+}
+
+// ---- frame-fed launches (FrameArgs::feedHost): the workgroup's view of what the host has published, and the ticket it holds meanwhile
+struct FeedQueue {             // one per workgroup, static LDS (only the FEED kernels touch it)
+    unsigned long long stash;  // (end << 32) | first + 1 of a drawn ticket whose tiles are not all published yet; 0 = none
+    unsigned int limit;        // (frame, tile) pairs below this index may be started: published frames x tiles per frame
+    unsigned int word;         // the feed word as last seen: kFeedClosed | count << 16 | display slots (FrameArgs::feedHost)
+    unsigned int pollAt;       // feed_refresh calls of this workgroup so far (every fourth one looks at the broadcast slot)
+    unsigned int pad[3];
+};
+PT_DEV unsigned int feed_count(unsigned int word) { return (word >> 16) & 0x7fffu; }
+constexpr int QUEUE_NOT_YET = -2; // queue_pop_tile_feed: work exists, but the host has not published its frame yet
+
+// What has the host published?  The launch's MONITOR wavefront is the only one that reads the host word (over PCIe) — it broadcasts every
+// new word into kFeedBcastSlots device words, and a workgroup reads the slot blockIdx % kFeedBcastSlots.  (Round 6, first version: every
+// workgroup polled ONE device word, at most one of them per microsecond the host word.  Whenever the launch ran out of published frames —
+// every frame, for a host that shows each frame before it renders the next but one — 1,536 workgroups hammered that one address and the
+// abandon word: loads of one address serialise at the memory side, the monitor's own loads queued behind them, and a frame took 1 ms.)
+// Call from ONE wavefront of the workgroup (the refill lock's holder); wave-uniform.
+PT_DEV void feed_refresh(FeedQueue *fq)
+{
+    ColdArgs ca = cold_args();
+    // (rate limit by COUNTING the workgroup's calls, not by the clock: s_memrealtime from thousands of waiting wavefronts is itself a
+    // hot spot — every fourth call looks, i.e. about every 2 - 3 us while the workgroup's four wavefronts retry)
+    const unsigned int calls = (unsigned int)__builtin_amdgcn_readfirstlane((int)lds_load(&fq->pollAt));
+    if ((threadIdx.x & 63) == 0) lds_store(&fq->pollAt, calls + 1u);
+    if ((calls & 3u) != 0u) return;
+    unsigned int w = __hip_atomic_load(ca->feedBcast + (blockIdx.x % kFeedBcastSlots) * kFeedBcastStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w = (unsigned int)__builtin_amdgcn_readfirstlane((int)w);
+    if ((threadIdx.x & 63) == 0) {
+        lds_store(&fq->limit, feed_count(w) * (unsigned int)(ca->tilesX * ca->tilesY));
+        lds_store(&fq->word, w);
+    }
+}
+
+// queue_pop_tile for a frame-fed launch: a ticket's tiles are handed out only as far as their frames are published; the rest of the ticket
+// waits in the workgroup's stash.  -> tile index, -1 (all handed out: closed, or capacity used up), QUEUE_NOT_YET.  Wave-uniform.
+// Every workgroup still draws exactly one failing ticket, and every ticket below ceil(final tiles / chunk) succeeds: the host's ticket
+// accounting (queueBase) only needs the final frame count.
+PT_DEV int queue_pop_tile_feed(BlockQueue *q, FeedQueue *fq)
+{
+    const bool leader = (threadIdx.x & 63) == 0;
+    for (;;) {
+        unsigned long long old = 0;
+        if (leader) old = atomicAdd(&q->pair, 1ull);
+        unsigned int cursor = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)old);
+        unsigned int end = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(old >> 32));
+        if (cursor < end) return (int)cursor;
+        if (__builtin_amdgcn_readfirstlane((int)lds_load(&q->done))) return -1;
+        unsigned int got = 1;
+        if (leader) got = atomicCAS(&q->lock, 0u, 1u);
+        if (__builtin_amdgcn_readfirstlane((int)got) == 0) { // this wavefront refills
+            bool notYet = false;
+            unsigned long long cur = lds_load64(&q->pair);
+            unsigned int isDone = lds_load(&q->done);
+            if (!isDone && (unsigned int)cur >= (unsigned int)(cur >> 32)) {
+                ColdArgs ca = cold_args();
+                const unsigned int capTiles = (unsigned int)(ca->tilesX * ca->tilesY * ca->batchFrames), chunk = (unsigned int)ca->queueChunk;
+                unsigned long long st = lds_load64(&fq->stash);
+                unsigned int first, last;
+                if (__builtin_amdgcn_readfirstlane((int)(st != 0ull))) {
+                    first = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)st) - 1u;
+                    last = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(st >> 32));
+                } else {
+                    unsigned int ticket = 0;
+                    CHAOS(2);
+                    if (leader) ticket = atomicAdd(ca->queue, 1u) - ca->queueBase;
+                    ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+                    const unsigned long long f64 = (unsigned long long)ticket * chunk;
+                    first = f64 > 0xfffffff0ull ? 0xfffffff0u : (unsigned int)f64;
+                    last = first + chunk < capTiles ? first + chunk : capTiles;
+                }
+                unsigned long long newStash = 0ull;
+                if (first >= capTiles) { // beyond the launch's capacity: this workgroup's failing ticket
+                    if (leader) lds_store(&q->done, 1u);
+                } else {
+                    unsigned int limit = (unsigned int)__builtin_amdgcn_readfirstlane((int)lds_load(&fq->limit));
+                    unsigned int closed = (unsigned int)__builtin_amdgcn_readfirstlane((int)lds_load(&fq->word)) >> 31;
+                    if (last > limit && !closed) {
+                        feed_refresh(fq);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        limit = (unsigned int)__builtin_amdgcn_readfirstlane((int)lds_load(&fq->limit));
+                        closed = (unsigned int)__builtin_amdgcn_readfirstlane((int)lds_load(&fq->word)) >> 31;
+                    }
+                    if (first < limit) { // (part of) the ticket is published
+                        const unsigned int upto = last < limit ? last : limit;
+                        if (leader) atomicExch(&q->pair, ((unsigned long long)upto << 32) | (unsigned long long)first);
+                        if (upto < last && !closed) newStash = ((unsigned long long)last << 32) | (unsigned long long)(upto + 1u);
+                    } else if (closed) { // nothing of it will ever be published: the failing ticket
+                        if (leader) lds_store(&q->done, 1u);
+                    } else {
+                        newStash = ((unsigned long long)last << 32) | (unsigned long long)(first + 1u);
+                        notYet = true;
+                    }
+                }
+                if (leader) __hip_atomic_store(&fq->stash, newStash, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (leader) atomicExch(&q->lock, 0u);
+            if (notYet) return QUEUE_NOT_YET;
         } else {
             __builtin_amdgcn_s_sleep(2);
         }

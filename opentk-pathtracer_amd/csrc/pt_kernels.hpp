@@ -90,6 +90,35 @@ struct FrameArgs {
     // also stores the pixel's new value here (same indexing as accum) — a consistent image of that frame that later frames never
     // touch, so the tone map can read it while the next launch (chained, ordered per pixel by the tags) already overwrites accum.
     float4 *snapshot;
+    // Frame-fed launch (round 6; nullptr = a classic launch that knows its frames when it starts).  The launch is started with CAPACITY
+    // batchFrames but may only begin the frames the host has PUBLISHED: feedHost (one host-mapped word, written by the host only) holds
+    // count << 16 | display slots (below), | kFeedClosed once the host has closed the launch (then the count is final).  The launch's MONITOR
+    // wavefront (below) reads it about once per microsecond and broadcasts a new word into feedBcast; a workgroup whose next ticket lies
+    // beyond what it knows looks at its broadcast slot.  Wavefronts with nothing
+    // to trace and no published work wait; once no new frame has come for feedIdleTicks the launch is ABANDONED with reason "idle"
+    // (hand-over bound: the host repairs whatever a racing publish left unrendered), so a host that stops rendering never keeps the GPU.
+    // feedDone: 8 cumulative counters (never reset; slot s at word s * kFeedDoneStride) — frame j of the launch adds its resolved pixels
+    // to slot j & 7 once their stores are complete — which the launch's monitor wavefront compares with the host's running total (below).
+    // FUSED DISPLAY (PostProcessing/fragment.glsl:17-26 for a host that shows every frame, MainWindow.cs:49-64): the tile pass of frame
+    // j + 1 reads every pixel's value after frame j anyway (all 64 lanes, coherent) — when frame j is to be shown it tone-maps that value
+    // into displayImages[slot - 1] right there (+4 % instructions; a separate tone-map kernel beside the resident wavefronts took 540
+    // instead of 14 us, and a snapshot per frame costs 16 more bytes per pixel).  The low 16 bits of the feed word hold, for the 8 most
+    // recent frames j, the present slot + 1 of frame j in bits 2 (j & 7) .. +1 (0 = not shown); displayPrev = that of the frame before
+    // the launch's first.  The image of frame j is complete when frame j + 1 is (its count in feedDone).
+    const unsigned int *feedHost;
+    unsigned int *feedBcast;   // kFeedBcastSlots device words, kFeedBcastStride words apart: the feed word as the monitor last read it
+    unsigned long long *feedDone;
+    unsigned int feedIdleTicks;
+    // ... and who tells the host that a frame is complete: ONE wavefront of the launch itself (the last one of workgroup 0: the MONITOR —
+    // it takes no tiles) compares the counters with the running totals (feedBase[s] = what slot s reads once every earlier launch has
+    // finished; feedPixels = pixels per frame) and stores the number of complete frames into feedHostDone, a host-mapped word the host
+    // polls (pt_present_wait).  No second kernel: a gate kernel beside the resident wavefronts was dispatched up to a millisecond late.
+    unsigned int *feedHostDone;
+    unsigned long long feedBase[8];
+    unsigned long long feedPixels;
+    uchar4 *displayImages[3]; // (null for a slot that is not bound to device memory: never referenced)
+    int displayPrev;
+    int displayOn;            // 1 = this launch shows frames (the feed word's slot bits are looked at)
     // Hand-over audit (only compiled into the -DPT_AUDIT build, tools/handover_stress.cpp; nullptr otherwise): one 64-bit word per
     // accumulation pixel = (frames folded so far) << 32 | hash of the colour stored last, maintained with device-scope atomic
     // exchanges next to every read-modify-write of the pixel — an independent, atomics-only record of compute.glsl:126-129's
@@ -108,6 +137,13 @@ constexpr int kFrameTagMask = 0xFFFFF;
 constexpr int kMaxBatchFrames = 256, kMaxUnverifiedLaunches = 128;
 static_assert((long long)kMaxBatchFrames * (kMaxUnverifiedLaunches + 2) * 8 <= (kFrameTagMask + 1) / 2, "frame tags would alias within the repair window");
 static_assert(kFrameTagMask + 2 < (1 << 24), "frame tags must be exact in binary32");
+constexpr unsigned int kFeedClosed = 0x80000000u; // FrameArgs::feedHost: the count in the low bits is final
+constexpr int kFeedBcastSlots = 256, kFeedBcastStride = 16; // FrameArgs::feedBcast: 256 words, 64 bytes apart (spread over the memory channels)
+constexpr int kFeedDoneStride = 64;               // FrameArgs::feedDone: slot s lives at word s * kFeedDoneStride (512 bytes apart: its own memory channel)
+constexpr int kFeedCapacity = 32;                 // frames a fed launch can take.  32, not 64: its frame table is then 256 bytes smaller than a classic launch's,
+                                                  // which pays for the kernel's extra static LDS (feed queue + pixel counters: 192 bytes) — the default scene's
+                                                  // workgroup sits 96 bytes below the sixth-workgroup-per-CU limit (LDS granules of 1,280 bytes)
+constexpr unsigned int kAbandonContended = 1u, kAbandonIdle = 2u; // bits of the host-visible abandon flag (FrameArgs::errorWord)
 constexpr int kAuditLogRecords = 1024, kAuditRecordWords = 12;
 constexpr int kTileMaskWords = 8; // 64 bytes per tile (FrameArgs::tileMasks)
 constexpr int kStartedWords = 4096; // capacity of FrameArgs::startedFlags (a launch with more workgroups does not report in)
@@ -128,7 +164,10 @@ struct AtmoArgs {
 
 // ticketsConsumed: by how much the launch advances *a.queue (the caller adds it to the next launch's queueBase)
 // workgroups: the grid size of the launch (persistent kernels)
-hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int *ticketsConsumed, int *workgroups = nullptr);
+// fed (in/out): in = the caller wants a frame-fed launch (a.feedHost etc. set, a.batchFrames = frames published at launch); out = whether one
+// was launched (only some kernel configurations have a fed instantiation; otherwise the classic launch of a.batchFrames frames).  For a fed
+// launch ticketsConsumed is the count for ZERO frames (workgroups failing tickets): the host adds feed_tickets(frames, ...) when it closes it.
+hipError_t launch_integrate(const FrameArgs &a, hipStream_t stream, unsigned int *ticketsConsumed, int *workgroups = nullptr, bool *fed = nullptr);
 // Hand-over repair (pt_repair_kernel): enqueued behind a join of the handle's streams, once per tagged launch since the previous join, in
 // launch order — a no-op unless a.abandonWord says the launch (or one it builds on) was abandoned; then every pixel's missing frames of the
 // launch described by `a` are re-rendered.  ctl = 4 device words (pairs rendered, inconsistent pixels, joins with repairs, spare).

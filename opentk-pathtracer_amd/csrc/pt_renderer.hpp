@@ -48,6 +48,10 @@ struct PresentSlot {
     // handle's abandon epoch at that time — if a launch was abandoned meanwhile, pt_present_wait repairs and tone-maps again
     const void *snapSource = nullptr;
     unsigned int snapGeneration = 0, abandonEpoch = 0;
+    bool fedPresent = false;      // the image is produced by a frame-fed launch's fused display (FrameArgs::displayImages)
+    int fusedWord = 0;            // ... which host word of the feed ring its launch reports completed frames in,
+    unsigned int fusedNeed = 0;   // ... and how many frames of that launch must be complete for the image to be
+    bool fusedWaiting = false;    // ... and the frame that produces it (the one after the frame shown) has not been published yet: no event to wait for so far
 };
 } // namespace ptimpl
 
@@ -78,7 +82,7 @@ struct pt_renderer {
     unsigned long long *dTileMasks = nullptr;
     size_t tileMaskTiles = 0;        // capacity in tiles
     bool tileMasksValid = false;
-    int launchesSinceInputChange = 0;
+    int launchesSinceInputChange = 0; // (frames launched or published since the inputs last changed; the name is from round 4, when it counted launches)
     unsigned long long statLaunches = 0, statMaskBuilds = 0, statFlushes = 0; // pt_debug_launch_stats: integrator launches, mask rebuilds, input-change flushes
     unsigned char *dGrid = nullptr; // (kMaxCells + 1) * 2 + kMaxRefs bytes
     float *dLut = nullptr;          // 256-entry sRGB table
@@ -105,6 +109,7 @@ struct pt_renderer {
     unsigned int inconsistentSeen = 0;    // dRepairCtl[1] at that reading
     unsigned int abandonEpoch = 0;        // bumped whenever the host finds hostErrWord raised (present slots remember it)
     int overlapHoldoff = 0;               // launches that still run BEHIND their predecessor after an abandonment (a contended device)
+    int wallClockKhz = 100000;            // rate of the device's constant-rate counter (s_memrealtime)
     unsigned int waitBudgetUnits = 0, waitCheckUnits = 0; // FrameArgs::waitBudget / waitCheckInterval for this device's wall clock
     int queueChunk = 0;             // tiles per global ticket; 0 = automatic (tuning knob queue_chunk)
     unsigned long long *dTimeline = nullptr; // tuning only (pt_debug_timeline)
@@ -115,6 +120,7 @@ struct pt_renderer {
     bool maxBatchExplicit = false; // the host called pt_set_frame_batch: its limit is kept as given (no automatic 256-frame launches)
     int batchWorkgroupsPerCU = 6; // grid of the batch kernel (tuning knob batch_wg)
     bool batchLaunched = false;   // a batch kernel ran since the last error-word check
+    bool lastPresentBound = false; // the newest present went into a slot bound to caller-owned device memory (pt_present_bind_device_image)
     int rendersSincePresent = 0;  // pt_render calls since the last pt_present_rgba8_async ...
     int presentCadence = 0;       // ... and how many there were before that present (1 = the host presents every frame)
     hipEvent_t mainDone = nullptr; // recorded behind the last integrator launch on the main stream
@@ -192,6 +198,40 @@ struct pt_renderer {
     struct SnapLaunch { hipStream_t stream; hipEvent_t done; size_t firstPixel, pixels; };
     std::vector<SnapLaunch> snapLaunches;        // the launch(es) that write the snapshot: stream, its "done" event, the rows they cover
 
+    // Frame-fed launch (round 6; FrameArgs::feedHost, pt_integrate_persistent.hip FEED).  When a launch of a few frames goes out while the
+    // host is not far ahead — the reference's own usage: Render() then show, every frame (MainWindow.cs:49-64) — it is started with room
+    // for kFeedCapacity frames, and the pt_render calls that follow PUBLISH their frame into it (one store to a host-mapped word) instead
+    // of launching: the wavefronts stay resident between frames.  Only the host closes a launch (the count is then final and exact);
+    // anything that launches, joins, flushes or changes an input closes it first.  A launch whose wavefronts wait too long for the next
+    // frame abandons itself with reason "idle" (hand-over bound), so a host that stops rendering never keeps the GPU.
+    struct FeedState {
+        bool open = false;           // pt_render may publish into the launch
+        int firstFrame = 0, published = 0;
+        int streamIdx = 0, hostWord = 0;
+        unsigned int seq = 0;        // its launchSeq (its LaunchRecord is patched with the final frame count when it is closed)
+        int workgroups = 0, queueChunk = 8;
+        long long tilesFrame = 0;
+        bool withMasks = false;      // it runs with the cached tile masks
+        bool display = false;        // FUSED DISPLAY: the launch tone-maps the frames the host shows into the present slots' images itself
+        unsigned int slots16 = 0;    // ... the low 16 bits of the feed word: present slot + 1 of the 8 most recent frames
+        int pendingSlot = -1;        // ... the slot the newest published frame was presented into: its image is produced by the NEXT frame's tile passes
+        unsigned long long base[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // feedDoneBase of its stream when it was opened
+        unsigned long long pixelsPerFrame = 0;
+    } feed;
+    static constexpr int kFeedHostWords = 8;
+    unsigned int *hostFeedDone = nullptr, *devFeedHostDone = nullptr; // ... and per word: frames of that launch its monitor wavefront has seen complete
+    unsigned int *hostFeed = nullptr, *devFeedHost = nullptr; // kFeedHostWords host-mapped words, handed out in rotation ...
+    hipEvent_t feedWordBusy[kFeedHostWords] = {};             // ... a word is reused only when the launch that read it is complete
+    int feedWordNext = 0;
+    unsigned int *dFeedDev = nullptr;          // 2 x kFeedBcastSlots broadcast slots (per launch stream): the feed word as the launch's monitor last read it
+    unsigned long long *dFeedDone = nullptr;   // 2 x 8 cumulative per-frame-slot counters (per launch stream)
+    unsigned long long feedDoneBase[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}}; // what the counters read once every closed launch has finished
+    hipEvent_t feedResetEvent = nullptr;
+    bool feedCountersStale = false;            // a launch was abandoned: its counts are short; re-zero behind a full join before the next fed launch
+    int fusedOrphanSlot = -1;                  // a present into this slot was left without a successor frame when its launch was closed: the next join tone-maps it from the image
+    int feedIdleStrikes = 0, feedHoldoff = 0;  // fed launches that ended idle in a row; launches for which no fed launch is tried
+    unsigned long long statPublishes = 0, statFeedOpens = 0, statFeedIdle = 0;
+
     // group handle (pt_create_multi): parts[i] renders its share on device_ids[i]; this struct then only carries the root
     // device's streams, the gather buffers and the present slots
     std::vector<pt_renderer *> parts;
@@ -231,6 +271,7 @@ int hip_fail(pt_handle h, hipError_t e, const char *what);
     } while (0)
 
 int bind_device(pt_handle h);
+void feed_close(pt_handle h);   // the open frame-fed launch (if any) takes no more frames; bookkeeping of its final frame count
 int flush_frames(pt_handle h);  // launch the frames pt_render deferred (a blocking entry point's flush: may wait chain_wait_us per launch)
 int flush_frames_bounded(pt_handle h, long waitUs, int maxLaunches);
 int batch_limit(pt_handle h);
@@ -251,6 +292,7 @@ int ensure_slot_device(pt_handle h, int slot, size_t pixels);
 int ensure_slot_host(pt_handle h, int slot, size_t pixels);
 int ensure_slot_events(pt_handle h, int slot);
 void free_slots(pt_handle h);
+int wait_slot(pt_handle h, PresentSlot &s, bool *abandoned); // host-side wait for the previous present into a slot (event, or a fused present's host word)
 
 // group handles (mi355pt_multi.cpp)
 int group_destroy(pt_handle g);

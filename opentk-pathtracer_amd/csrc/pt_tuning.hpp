@@ -23,6 +23,15 @@ struct Tuning {
     // launches (mi355pt.cpp: launch_frames)
     int auditSabotage = 0;         // -DPT_AUDIT builds only: every n-th (pixel, frame) folds into a perturbed colour
     int noSingleTagged = 0;        // 1: single frames never chain
+    int serialLaunches = 0;        // 1: every tagged launch goes BEHIND its predecessor on the same stream and pt_render never defers a full batch for
+                                   //    residency — launches do not overlap, so rocprofv3's per-launch durations add up to the elapsed time (profiles' cross-check)
+    int feed = 1;                  // 0: never a frame-fed launch (every short launch knows its frames when it starts, rounds 1-5)
+    long long feedMinTiles = 12000; // images with fewer tiles per frame never get a fed launch (tests / stress runs lower it)
+    int feedLog = 0;               // debug: frame-fed launch events (open / publish / close / present) to stderr
+    int feedDisplay = 0;           // 1: a host that shows every frame into bound device images gets fed launches with the FUSED DISPLAY (measured slower than the
+                                   // per-frame launches + snapshot tone maps of round 3 when the host runs at most two frames ahead: DESIGN.md section 3.1; 2 = debug, no tone map)
+    int feedWorkgroupsPerCU = 6;   // workgroups per CU of a fed launch (its present needs no room beside it: the display is fused into the tile pass)
+    long feedIdleUs = 150;         // a fed launch whose wavefronts have waited this long for the next frame ends itself (reason "idle")
     int shortWorkgroupsPerCU = 5;  // workgroups per CU of launches of fewer than 8 frames
     long chainWaitUs = 60000;      // back-pressure: how long a launch issued by a BLOCKING entry point waits for its predecessor to become resident
     long renderWaitUs = 2000;      // ... and the most pt_render itself ever waits (only when the host is 16 launches ahead)
@@ -69,7 +78,14 @@ inline bool tuning_set(const char *key, long long v)
     PT_KNOB("allow_staged_gather", allowStagedGather)
     PT_KNOB("audit_sabotage", auditSabotage)
     PT_KNOB("no_single_tagged", noSingleTagged)
+    PT_KNOB("serial_launches", serialLaunches)
     PT_KNOB("short_wg", shortWorkgroupsPerCU)
+    PT_KNOB("feed", feed)
+    PT_KNOB("feed_idle_us", feedIdleUs)
+    PT_KNOB("feed_display", feedDisplay)
+    PT_KNOB("feed_log", feedLog)
+    PT_KNOB("feed_wg", feedWorkgroupsPerCU)
+    PT_KNOB("feed_min_tiles", feedMinTiles)
     PT_KNOB("chain_wait_us", chainWaitUs)
     PT_KNOB("render_wait_us", renderWaitUs)
     PT_KNOB("handover_budget_ms", handoverBudgetMs)

@@ -242,10 +242,11 @@ def debug_launch_stats(handle) -> dict:
     L = load()
     L.pt_debug_launch_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     L.pt_debug_launch_stats.restype = C.c_int
-    out = (C.c_ulonglong * 6)()
+    out = (C.c_ulonglong * 12)()
     check(L.pt_debug_launch_stats(handle, out), handle)
     return {"launches": int(out[0]), "tile_masks_valid": bool(out[1]), "pending_frames": int(out[2]), "mask_builds": int(out[3]),
-            "frame": int(out[4]), "input_change_flushes": int(out[5])}
+            "frame": int(out[4]), "input_change_flushes": int(out[5]), "published": int(out[6]), "feed_opens": int(out[7]),
+            "feed_idle": int(out[8]), "feed_open": bool(out[9]), "saw_batch": bool(out[10]), "snapshot_pixels_reread": int(out[11])}
 
 
 def debug_handover_stats(handle) -> dict:

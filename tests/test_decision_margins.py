@@ -24,7 +24,7 @@ import pytest
 import fixtures
 import tolerances as tol
 
-TAU = 1e-7           # relative error of the arithmetic's primitives (1 ulp of binary32 = 6e-8)
+TAU = 2e-8           # relative error of the arithmetic's primitives (1 ulp of binary32 = 6e-8)
 _REPORT = []
 
 

@@ -5,7 +5,7 @@
 # `run`: GPU suite log + smoke; per workload tools/profile_round.sh (rocprofv3 --kernel-trace --stats + separate --pmc passes; the default
 # workload with the depth-0 FETCH/WRITE calibration) and tools/summarize_profile.py ON THE BOX (so that profiles/traffic.json /
 # valu_insts.json there carry this build's numbers) and bench.py once more; the default workload's stats pass once more with launches that
-# do not overlap (chain_wait_us = 0: the sum of launch durations is then a time per frame); tools/bench_configs.sh; the driver's command
+# do not overlap (serial_launches = 1: the sum of launch durations is then a time per frame); tools/bench_configs.sh; the driver's command
 # line; emulated strong scaling; present rates; the 2- and 8-rank one-GPU runs of bench.py; short runs; the native stress driver on the
 # four builds; the oracle-checked fuzzer.  --quick: fewer stress / fuzz cases (a re-profile after a small change).
 # `collect`: summarise the merged raw counters locally into the tracked files under profiles/ and copy the logs.
@@ -65,7 +65,7 @@ unset PROFILE_NO_CAL PROFILE_PASSES PROFILE_BENCH_EXTRA PROFILE_STEPS PROFILE_WA
 # the default workload's stats pass with launches that go BEHIND each other (with back-pressure chaining every launch waits beside its
 # predecessor and rocprofv3's durations add up to ~2x the elapsed time)
 ( OUT=$R/gpurun_out/prof_${RND}_unchained; mkdir -p $OUT; cd /tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python $R/bench.py --steps 640 --warmup 320 --clock-warmup-ms 0 --steady-ms 0 --no-cpu-baseline --tune chain_wait_us=0 > $OUT/bench.json 2> $OUT/stats.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python $R/bench.py --steps 640 --warmup 320 --clock-warmup-ms 0 --steady-ms 0 --no-cpu-baseline --tune serial_launches=1 > $OUT/bench.json 2> $OUT/stats.log
   python - "$OUT" "$R/gpurun_out/$RND" "$RND" <<'PY'
 import csv, glob, json, sys
 out, dst, rnd = sys.argv[1:4]
@@ -76,7 +76,7 @@ f = (glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True) + glob.glob(
 open(f"{dst}/{rnd}_default_kernel_stats_unchained.csv", "w").write(open(f).read())
 r = [x for x in csv.DictReader(open(f)) if "pt_integrate" in x["Name"]][0]
 bench = json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])
-res = {"what": "default workload, rocprofv3 --kernel-trace --stats with the tuning knob chain_wait_us = 0: launches do not overlap, the sum of their "
+res = {"what": "default workload, rocprofv3 --kernel-trace --stats with the tuning knob serial_launches = 1: launches do not overlap, the sum of their "
                "durations / frames is comparable with bench.py's HIP-event kernel_ms of the same run", "frames": frames,
        "unchained": {"calls": int(r["Calls"]), "total_ns": int(r["TotalDurationNs"]), "avg_ns": float(r["AverageNs"]), "ns_per_frame": int(r["TotalDurationNs"]) / frames,
                      "bench_kernel_ms_same_run": bench["roofline"].get("kernel_ms"), "bench_value": bench["value"]},
