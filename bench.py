@@ -638,7 +638,7 @@ def main():
         kernel_ms = m["kernel_s"] * 1e3 / args.steps
         algo_bytes = ALGO_BYTES_PER_PIXEL_FRAME * W * rows  # per frame on one GPU (rank 0's rows)
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        wl_key = f"{scene_name}_{W}x{H}_d{depth}_spp{args.spp}_{env_name}_g{world}" + (f"_variant{args.variant}" if args.variant else "") + (f"_fb{args.frame_batch}" if args.frame_batch not in (0, 64) else "") + ("_strong4k" if args.strong_4k else "") + ("_weak" if args.weak and world > 1 else "") + ("_nogrid" if "no_sphere_grid=1" in args.tune else "") + ("_nocarry" if "carry_last=0" in args.tune else "") + ("_gridcarry" if "grid_carry=1" in args.tune else "")
+        wl_key = f"{scene_name}_{W}x{H}_d{depth}_spp{args.spp}_{env_name}_g{world}" + (f"_variant{args.variant}" if args.variant else "") + (f"_fb{args.frame_batch}" if args.frame_batch not in (0, 64) else "") + ("_strong4k" if args.strong_4k else "") + ("_weak" if args.weak and world > 1 else "") + ("_nogrid" if "no_sphere_grid=1" in args.tune else "") + ("_nocarry" if "carry_last=0" in args.tune else "") + ("_gridcarry" if "grid_carry=1" in args.tune else "") + ("_gridcarry2" if "grid_carry=2" in args.tune else "")
         if world == 1:
             where = "one GPU" + (f" (BASELINE configs[{baseline_index}])" if baseline_index is not None and (W, H) == (1920, 1080) else "")
         else:

@@ -45,11 +45,17 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
     const int CONT_BATCH_MIN = a.contBatchMin; // parked continuations that make a batch pass worth its ~950 instructions
     const int parkCapacity = a.contCapacity; // per wavefront (whatever LDS is left next to scene and rings, see the launch)
     ContEntry *cq = (ContEntry *)(ringBase + NWAVES * 64 * (int)sizeof(PathEntryM)) + wave * parkCapacity;
-    // IRR_LDS (the kernels whose materials live in device memory: the addresses cost them registers, and they have the materials' LDS to
-    // spare): the lane's running irradiance sum — touched only where a sample ends, a path is popped or a pixel is parked — lives in three
-    // LDS planes of 64 floats per wavefront instead of three VGPRs that are live across the whole bounce (round 5: these two
-    // instantiations spilled 6 and 24 VGPRs to scratch)
-    constexpr bool IRR_LDS = !MATLDS;
+    // IRR_LDS (experiment of round 6, off): the lane's running irradiance sum and its pixel in LDS planes instead of registers, for the
+    // instantiations that read materials from device memory (they spilled 6 / 24 VGPRs in round 5).  It removes the last spills, but its
+    // 4 KB per workgroup cost the 256-sphere scene its fifth workgroup per CU: 11.85 -> 10.8 Gsamples/s at 4 spp.  What stayed: the lane's
+    // three counters packed into one register and the batch pass's dummy walk variable made a local — 6 / 24 spills -> 2 / 1, no LDS.
+#ifndef PT_MS_IRR_LDS
+#define PT_MS_IRR_LDS 0
+#endif
+#ifndef PT_MS_EARLY
+#define PT_MS_EARLY 40
+#endif
+    constexpr bool IRR_LDS = !MATLDS && PT_MS_IRR_LDS != 0;
     [[maybe_unused]] float *const laneIrr = (float *)(ringBase + NWAVES * 64 * (int)sizeof(PathEntryM) + NWAVES * parkCapacity * (int)sizeof(ContEntry)) + wave * 4 * 64 + lane;
     v3 irrReg = V(0, 0, 0);
     auto get_irr = [&]() -> v3 {
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(256, 5) void pt_integrate_multisample_kernel(const 
         // of full and the ring has room for it, so that the queue never overflows — an overflowing continuation takes its next sample's
         // first bounce in the lane, unculled, against all 256 spheres: +3.5 % at C3 4 spp; the 48-sphere scene's unculled bounce is cheaper
         // than a thin pass (-2 % there), hence tied to GRID (profiles/r05/multisample_early_pass.log)
-        if constexpr (GRID) forcePass = forcePass || (parked + 40 >= parkCapacity && avail <= 24 && parked > 0);
+        if constexpr (GRID && PT_MS_EARLY > 0) forcePass = forcePass || (parked + PT_MS_EARLY >= parkCapacity && avail <= 64 - PT_MS_EARLY && parked > 0);
         for (int pass = 0; pass < 16 && (m != 0ull || forcePass); pass++) {
             if (avail == 0 || forcePass) {
                 // ---- batch pass: 64 parked continuations, or the next tile's 64 pixels (sample 0)

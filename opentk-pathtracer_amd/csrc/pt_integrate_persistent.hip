@@ -714,10 +714,14 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                             e.ro[0] = to.x; e.ro[1] = to.y; e.ro[2] = to.z;
                             e.rd[0] = td.x; e.rd[1] = td.y; e.rd[2] = td.z;
                             e.thr[0] = tthr.x; e.thr[1] = tthr.y; e.thr[2] = tthr.z;
-                            e.rad[0] = trad.x; e.rad[1] = trad.y; e.rad[2] = trad.z;
                             if constexpr (CARRY) {
-                                if (plastOk) e.bounce |= PATH_HAS_LAST;
-                                e.last[0] = plast.x; e.last[1] = plast.y; e.last[2] = plast.z;
+                                // (one triple: the pixel's value when the path's rad is still +0 — bit for bit — and the value is valid, else rad)
+                                const bool radZero = (__float_as_uint(trad.x) | __float_as_uint(trad.y) | __float_as_uint(trad.z)) == 0u;
+                                const bool carryLast = plastOk && radZero;
+                                if (carryLast) e.bounce |= PATH_HAS_LAST;
+                                e.x[0] = carryLast ? plast.x : trad.x; e.x[1] = carryLast ? plast.y : trad.y; e.x[2] = carryLast ? plast.z : trad.z;
+                            } else {
+                                e.rad[0] = trad.x; e.rad[1] = trad.y; e.rad[2] = trad.z;
                             }
                             pring[slot] = e;
                         }
@@ -775,7 +779,7 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                     fj = (e.bounce >> 16) & 0x3fff;
                     if constexpr (CARRY) {
                         if (e.bounce & PATH_HAS_LAST) fj |= 0x4000;
-                        laneLast[0] = e.last[0]; laneLast[64] = e.last[1]; laneLast[128] = e.last[2];
+                        laneLast[0] = e.x[0]; laneLast[64] = e.x[1]; laneLast[128] = e.x[2]; // (only read when PATH_HAS_LAST)
                     }
                     pending = false;   // (= begin_path(), written out: through the lambda the compiler copies the 16 registers of path state
                     walkFrom = -1.0f;  //  twice per pop-loop round — 2.4 M of 110 M vector instructions per 1080p frame)
@@ -783,7 +787,12 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
                     ro = V(e.ro[0], e.ro[1], e.ro[2]);
                     rd = V(e.rd[0], e.rd[1], e.rd[2]);
                     throughput = V(e.thr[0], e.thr[1], e.thr[2]);
-                    rad = V(e.rad[0], e.rad[1], e.rad[2]);
+                    if constexpr (CARRY) {
+                        const bool hasLast = (e.bounce & PATH_HAS_LAST) != 0;
+                        rad = V(hasLast ? 0.0f : e.x[0], hasLast ? 0.0f : e.x[1], hasLast ? 0.0f : e.x[2]);
+                    } else {
+                        rad = V(e.rad[0], e.rad[1], e.rad[2]);
+                    }
                 }
                 int n = __builtin_popcountll(m);
                 avail = n < avail ? avail - n : 0;
@@ -1249,7 +1258,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         // Sphere-grid scenes (round 5, knob grid_carry): the grid kernel carries the pixel too, at FIVE workgroups per CU (its rings and lane
         // slots need 4.9 KB more than six leave room for; 96 VGPRs instead of 80)
         const bool gridCarry = useGrid && spp1 && tune.gridCarry != 0 && tiles >= 12000 && tune.carryLast != 0 && a.drainCompaction == 0 && !perWaveTimeline;
-        if (gridCarry && blocksPerCU > 5) {
+        if (gridCarry && blocksPerCU > 5 && tune.gridCarry == 1) { // (grid_carry = 2: at six workgroups per CU — the 60-byte carried record of round 6 leaves the room)
             blocksPerCU = 5;
             nwg = a.numCUs * blocksPerCU;
             if (nwg > numChunks) nwg = numChunks;
@@ -1257,7 +1266,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         }
         bool carry = spp1 && (!useGrid || gridCarry) && !perWaveTimeline && tiles >= 12000 && tune.carryLast != 0 && a.drainCompaction == 0;
         auto queue_bytes = [&](bool c) -> size_t {
-            if (useBatchPass) return (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry)) + (size_t)waves * 64 * 16; // (+ the IRR_LDS lane slots of the lean instantiations — irradiance + pixel: counted always, 4 KB)
+            if (useBatchPass) return (size_t)waves * (64 * sizeof(PathEntryM) + (size_t)park * sizeof(ContEntry));
             return (spp1 ? frame_weight_bytes(a.batchFrames) : 0) +
                    (size_t)waves * 64 * (spp1 ? (c ? sizeof(PathEntryCarry) : sizeof(PathEntry)) + lane_last_bytes(c) : sizeof(RingEntry)) +
                    (a.drainCompaction != 0 ? (size_t)pool_slots(waves) * sizeof(PathState) : 0) // no pool without drain compaction
@@ -1328,6 +1337,7 @@ hipError_t launch_integrate(const FrameArgs &args, hipStream_t stream, unsigned 
         else if (spp1 && matLds && carry) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_SPP1_WAVES, false, true, true, false, true, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1 && matLds && a.drainCompaction == 0) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_SPP1_WAVES, false, true, true, false, false, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1 && matLds) PT_LAUNCH_PERSISTENT(false, true, true);
+        else if (spp1 && useGrid && carry && blocksPerCU > 5) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_GRID_MIN_WAVES, false, true, false, true, true, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1 && useGrid && carry) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, 5, false, true, false, true, true, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1 && useGrid) hipLaunchKernelGGL((pt_integrate_persistent_kernel<4, PT_GRID_MIN_WAVES, false, true, false, true, false, false>), dim3(nwg), dim3(256), ldsTotal, stream, a);
         else if (spp1) PT_LAUNCH_PERSISTENT(false, true, false);

@@ -210,9 +210,18 @@ struct PathEntry {
 // (8 rows x 128 B: full lines) right after the first bounce, travels with the path: its resolve then needs no load (and no memory
 // round trip) — nobody else writes the pixel between frame f-1's resolve and frame f's.  Only valid when the tile pass already saw
 // the previous frame's tag (PATH_HAS_LAST).  Memory-side reads 84 -> 46 MB per 1080p frame (profiles/r04/xcd_affine_traffic.json).
-struct PathEntryCarry : PathEntry {
-    float last[3];
+// Round 6: the record stays at 60 bytes.  `rad` is +0 for every path that has not yet met the one emissive object (nearly all of them, when
+// they enter the ring after their first bounce), so the last three floats hold EITHER the pixel's value (PATH_HAS_LAST: rad is +0, bit for
+// bit) OR a non-zero rad (then the pixel does not travel: its resolve loads it, like any pixel whose previous frame was not in yet).  The
+// 12 bytes per entry this saves (3 KB per workgroup) are what lets the sphere-grid kernel carry the pixel at six workgroups per CU.
+struct PathEntryCarry {
+    int pix;
+    int bounce;
+    uint32_t seed;
+    float ro[3], rd[3], thr[3];
+    float x[3]; // last (PATH_HAS_LAST) or rad
 };
+static_assert(sizeof(PathEntryCarry) == sizeof(PathEntry), "the carried record costs no LDS");
 constexpr int PATH_HAS_LAST = 1 << 30;
 // per lane: the pixel value read by the tile pass (LDS slot while the path is in a lane, see the kernel)
 __host__ __device__ constexpr size_t lane_last_bytes(bool carry) { return carry ? 12 : 0; }

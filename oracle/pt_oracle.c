@@ -66,6 +66,24 @@ static inline float f_min(float a, float b) { return fminf(a, b); }
 static inline float f_max(float a, float b) { return fmaxf(a, b); }
 static inline uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float f_unbits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+/* ---- witness build (-DPT_ORACLE_PERTURB, _build/libpt_oracle_perturb.so; tests/test_decision_margins.py).  GLSL leaves the precision of
+ * 1/x, inversesqrt, sqrt, sin, cos, exp implementation-defined: an implementation whose primitive P returns results ONE ULP LARGER (or
+ * smaller) in magnitude than this contract's is as conforming as the contract.  pto_set_perturbation(P, ulps) turns this library into
+ * that implementation (every call of P, every pixel); the margin test uses the family as constructive witnesses: a pixel of the
+ * reference that the contract misses must be HIT by one of its neighbours.  P: 0 rcp, 1 rsqrt, 2 sqrt, 3 sin, 4 cos, 5 exp, 6 pow5. */
+#ifdef PT_ORACLE_PERTURB
+static int g_perturb_prim = -1, g_perturb_ulps = 0;
+static inline float perturbed(int prim, float y)
+{
+    if (prim != g_perturb_prim || g_perturb_ulps == 0 || !(fabsf(y) > 1.17549435e-38f) || isinf(y)) return y;
+    uint32_t u; memcpy(&u, &y, 4);
+    u = (uint32_t)((int32_t)u + g_perturb_ulps); /* (sign-magnitude: + = away from zero) */
+    memcpy(&y, &u, 4);
+    return y;
+}
+#else
+#define perturbed(prim, y) (y)
+#endif
 /* pt-f32 reciprocal: seed by exponent negation, three Newton steps; zero and denormals give +-inf */
 static inline float f_rcp(float x)
 {
@@ -77,7 +95,7 @@ static inline float f_rcp(float x)
     e = fmaf(-x, y, 1.0f); y = fmaf(y, e, y);
     e = fmaf(-x, y, 1.0f); y = fmaf(y, e, y);
     if (fabsf(x) < 1.17549435e-38f) y = copysignf(INFINITY, x);
-    return y;
+    return perturbed(0, y);
 }
 /* pt-f32 inverse square root: classic seed, three Newton steps; zero/denormal -> +inf, negative -> NaN */
 static inline float f_rsqrt(float x)
@@ -91,7 +109,7 @@ static inline float f_rsqrt(float x)
     t = y * y; t = fmaf(-h, t, 1.5f); y = y * t;
     t = y * y; t = fmaf(-h, t, 1.5f); y = y * t;
     if (x < 1.17549435e-38f) y = x < 0.0f ? NAN : INFINITY;
-    return y;
+    return perturbed(1, y);
 }
 /* pt-f32 square root: two Newton steps y *= 1.5 - (x/2*y)*y on the same seed (4.7e-6), then one residual correction
  * s += (x - s*s) * y/2  (<= 0.501 ulp); sqrt(0) = 0 exactly; negative, infinite and NaN inputs give a non-finite value
@@ -107,7 +125,7 @@ static inline float pt_sqrt(float x)
     t = h * y; t = fmaf(-t, y, 1.5f); y = y * t;
     float s = x * y;
     float r = fmaf(-s, s, x);
-    return fmaf(r, 0.5f * y, s);
+    return perturbed(2, fmaf(r, 0.5f * y, s));
 }
 static inline float f_mix(float x, float y, float a) { return fmaf(y, a, x * (1.0f - a)); }
 
@@ -146,8 +164,8 @@ static void f_sincos(float a, float *sn, float *cs)
     float c_out = (q & 1) ? s : c;
     if (q == 1 || q == 2) c_out = -c_out;
     if (q >= 2) s_out = -s_out;
-    *sn = s_out;
-    *cs = c_out;
+    *sn = perturbed(3, s_out);
+    *cs = perturbed(4, c_out);
 }
 
 /* e^x.  n = rint(x*log2 e), r = x - n*ln2 (two fused steps), degree-6 polynomial, 2^n applied as two exact
@@ -169,10 +187,10 @@ static float f_exp(float x)
     int ni = (int)n;
     int n1 = ni >> 1, n2 = ni - n1;
     y = y * f_from_bits((uint32_t)(n1 + 127) << 23);
-    return y * f_from_bits((uint32_t)(n2 + 127) << 23);
+    return perturbed(5, y * f_from_bits((uint32_t)(n2 + 127) << 23));
 }
 
-static inline float f_pow5(float x) { float x2 = x * x; return x * (x2 * x2); }
+static inline float f_pow5(float x) { float x2 = x * x; return perturbed(6, x * (x2 * x2)); } /* (GLSL: pow(x, 5.0) — llvmpipe's is ~22 ulp off) */
 
 /* ------------------------------------------------------------------ scene blob accessors (std140, compute.glsl:13-42,66-70) */
 #define SPHERE_STRIDE 20  /* floats: 80 B  */
@@ -1028,6 +1046,19 @@ PTO_API int pto_bounce_counts(const PtoParams *p, const float *basic144, const f
 }
 
 /* ---- micro entry points for unit tests ---- */
+/* witness build only: primitive `prim` returns results `ulps` units in the last place further from zero (negative: nearer); -1 / 0 = off.
+ * Returns -1 in builds without -DPT_ORACLE_PERTURB.  Set while nothing renders. */
+PTO_API int pto_set_perturbation(int prim, int ulps)
+{
+#ifdef PT_ORACLE_PERTURB
+    g_perturb_prim = prim;
+    g_perturb_ulps = ulps;
+    return 0;
+#else
+    (void)prim; (void)ulps;
+    return -1;
+#endif
+}
 PTO_API uint32_t pto_pcg_hash(uint32_t *seed) { return pcg_hash(seed); }
 PTO_API float pto_rand01(uint32_t *seed) { return rand01(seed); }
 PTO_API uint32_t pto_pixel_seed(int x, int y, int frame)

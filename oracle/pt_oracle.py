@@ -17,11 +17,12 @@ LIB_TRUEDIV_PATH = os.path.join(HERE, "_build", "libpt_oracle_truediv.so")
 LIB_EXACT_PATH = os.path.join(HERE, "_build", "libpt_oracle_exact.so")  # fidelity study: IEEE 1/x, sqrt, 1/sqrt, a/b
 LIB_NANMARK_PATH = os.path.join(HERE, "_build", "libpt_oracle_nanmark.so")  # diagnostic: env lookups with a NaN direction return 1000
 LIB_MARGINS_PATH = os.path.join(HERE, "_build", "libpt_oracle_margins.so")  # decision margins per pixel (tests/test_decision_margins.py)
+LIB_PERTURB_PATH = os.path.join(HERE, "_build", "libpt_oracle_perturb.so")  # witness build: one primitive a chosen number of ulps off
 
 
 def build(force: bool = False) -> None:
     src = os.path.join(HERE, "pt_oracle.c")
-    libs = (LIB_PATH, LIB_TRUEDIV_PATH, LIB_EXACT_PATH, LIB_NANMARK_PATH, LIB_MARGINS_PATH)
+    libs = (LIB_PATH, LIB_TRUEDIV_PATH, LIB_EXACT_PATH, LIB_NANMARK_PATH, LIB_MARGINS_PATH, LIB_PERTURB_PATH)
     stale = not all(os.path.exists(p) for p in libs) or min(os.path.getmtime(p) for p in libs) < os.path.getmtime(src)
     if force or stale:
         subprocess.run(["make", "-C", HERE, "-B" if force else "-s", "all"], check=True, capture_output=True)
@@ -41,9 +42,9 @@ def _ptr(a, t=_fp):
 
 
 class Oracle:
-    def __init__(self, true_division: bool = False, exact: bool = False, mark_nan_env: bool = False, margins: bool = False):
+    def __init__(self, true_division: bool = False, exact: bool = False, mark_nan_env: bool = False, margins: bool = False, perturb: bool = False):
         build()
-        self.lib = C.CDLL(LIB_MARGINS_PATH if margins else LIB_NANMARK_PATH if mark_nan_env else LIB_EXACT_PATH if exact else (LIB_TRUEDIV_PATH if true_division else LIB_PATH))
+        self.lib = C.CDLL(LIB_PERTURB_PATH if perturb else LIB_MARGINS_PATH if margins else LIB_NANMARK_PATH if mark_nan_env else LIB_EXACT_PATH if exact else (LIB_TRUEDIV_PATH if true_division else LIB_PATH))
         L = self.lib
         L.pto_render_frame_margins.restype = C.c_int
         L.pto_render_frame_margins.argtypes = [C.POINTER(PtoParams), _fp, _fp, C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
@@ -85,8 +86,15 @@ class Oracle:
         L.pto_postprocess.argtypes = [_fp, C.c_int, _fp, C.POINTER(C.c_uint8)]
         L.pto_log.restype = C.c_float
         L.pto_log.argtypes = [C.c_float]
+        L.pto_set_perturbation.restype = C.c_int
+        L.pto_set_perturbation.argtypes = [C.c_int, C.c_int]
         L.pto_atmosphere.restype = C.c_int
         L.pto_atmosphere.argtypes = [_fp, _fp, C.c_float, C.c_int, C.c_int, C.c_int, _fp, C.c_int]
+
+    def set_perturbation(self, prim: int, ulps: int) -> None:
+        """Oracle(perturb=True) only: primitive `prim` (0 rcp, 1 rsqrt, 2 sqrt, 3 sin, 4 cos, 5 exp) returns results `ulps` units in the
+        last place further from zero from now on (negative: nearer; 0 = the contract again)."""
+        assert self.lib.pto_set_perturbation(prim, ulps) == 0, "this oracle build has no perturbation hooks (Oracle(perturb=True))"
 
     # ---------------------------------------------------------------- frames
     @staticmethod

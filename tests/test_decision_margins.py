@@ -73,12 +73,91 @@ def test_every_out_of_band_pixel_of_the_full_size_configs_sits_on_a_knife_edge(o
     check(name, fx["expected"], got[:, :3], margin, cont, fx["env"].dtype == np.uint8)
 
 
+# ---- constructive witnesses (round 6).  "Sits on a knife edge" is an upper bound from a first-order analysis; the converse can be SHOWN
+# for part of the pixels: a pixel of the reference that the contract misses and that IS HIT by a neighbouring conforming implementation —
+# the contract with one of its primitives one or two ulps off EVERYWHERE (oracle build -DPT_ORACLE_PERTURB), with the literal slab
+# division, or with correctly rounded 1/x, sqrt, 1/sqrt; GLSL allows every one of them, llvmpipe is yet another — is a demonstrated flip.
+# Measured: this family of 26 GLOBAL variants hits 40 - 60 % of the out-of-band pixels (a wider one — +-4 ulps, +-16 on exp and pow, which
+# is what llvmpipe's exp is off by — adds almost nothing).  The others need their ONE knife-edge comparison decided the other way while
+# everything else stays as it is, which no global shift of a primitive does: the targeted single-decision flip (re-render the pixel with
+# comparison #k inverted, k from the margins build) is the witness that can reach 100 %; it is not built.  What is gated here is the
+# family's overall share, so that the statistic cannot silently rot.
+WITNESS_VARIANTS = [("truediv", None), ("exact", None)] + [(f"{name}{ulps:+d}", (prim, ulps)) for prim, name in
+                                                           enumerate(["rcp", "rsqrt", "sqrt", "sin", "cos", "exp"]) for ulps in (1, -1, 2, -2)]
+_WITNESS_REPORT = []
+
+
+@pytest.fixture(scope="module")
+def witness_oracles():
+    import __graft_entry__ as graft
+    po = graft.load_oracle()
+    return {"truediv": po.Oracle(true_division=True), "exact": po.Oracle(exact=True), "perturb": po.Oracle(perturb=True)}
+
+
+def _variant_frames(orcs, variant, fx, sparse):
+    name, pert = variant
+    o = orcs["perturb"] if pert else orcs[name]
+    if pert:
+        o.set_perturbation(*pert)
+    try:
+        if sparse:
+            return o.render_pixels(fx["width"], fx["height"], fx["basic"], fx["objects"], fx["env"], fx["xy"], **fixtures.kwargs(fx))[:, :3]
+        imgs = o.render(fx["width"], fx["height"], fx["basic"], fx["objects"], fx["env"], num_frames=fx["frames"], dump_each=True, **fixtures.kwargs(fx))
+        return [imgs[fi][..., :3] for fi in fx["frame_indices"]]
+    finally:
+        if pert:
+            o.set_perturbation(-1, 0)
+
+
+def _witness(name, refs, gots, variants, srgb):
+    band = tol.SRGB_REL_TOL if srgb else tol.REL_TOL
+    for k, (ref, got) in enumerate(zip(refs, gots)):
+        both_nan = np.isnan(ref).any(-1) & np.isnan(got).any(-1)
+        out = ~(tol.within(ref, got, band) | both_nan)
+        hit = np.zeros_like(out)
+        for v in variants:
+            vk = v[k]
+            hit |= tol.within(ref, vk, band) | (np.isnan(ref).any(-1) & np.isnan(vk).any(-1))
+        missing = int((out & ~hit).sum())
+        _WITNESS_REPORT.append((f"{name} #{k}", int(out.sum()), missing))
+    # (no per-fixture gate: see test_witness_share below)
+
+
+@pytest.mark.parametrize("name", fixtures.names("frame_"))
+def test_every_out_of_band_pixel_of_a_frame_fixture_has_a_conforming_witness(oracle, witness_oracles, name):
+    fx = fixtures.load(name)
+    imgs = oracle.render(fx["width"], fx["height"], fx["basic"], fx["objects"], fx["env"], num_frames=fx["frames"], dump_each=True, **fixtures.kwargs(fx))
+    gots = [imgs[fi][..., :3] for fi in fx["frame_indices"]]
+    variants = [_variant_frames(witness_oracles, v, fx, False) for v in WITNESS_VARIANTS]
+    _witness(name, fx["expected"], gots, variants, fx["env"].dtype == np.uint8)
+
+
+@pytest.mark.parametrize("name", fixtures.names("sparse_"))
+def test_every_out_of_band_pixel_of_the_full_size_configs_has_a_conforming_witness(oracle, witness_oracles, name):
+    fx = fixtures.load(name)
+    got = oracle.render_pixels(fx["width"], fx["height"], fx["basic"], fx["objects"], fx["env"], fx["xy"], **fixtures.kwargs(fx))[:, :3]
+    variants = [[_variant_frames(witness_oracles, v, fx, True)] for v in WITNESS_VARIANTS]
+    _witness(name, [fx["expected"]], [got], variants, fx["env"].dtype == np.uint8)
+
+
+def test_witness_share():
+    """(runs after the witness tests) of all out-of-band pixels of all fixtures' first frames, the share the 26 global variants hit."""
+    firsts = [r for r in _WITNESS_REPORT if r[0].endswith("#0")]
+    if not firsts:
+        pytest.skip("the witness tests did not run in this session")
+    nout, missing = sum(r[1] for r in firsts), sum(r[2] for r in firsts)
+    assert nout > 0 and 1.0 - missing / nout >= 0.40, f"only {nout - missing} of {nout} out-of-band pixels have a witness in the global family"
+
+
 def test_report(capsys):
     """(not a check: prints what the tests above measured; runs last in this module)"""
     with capsys.disabled():
         print("\n  decision margins: fixture, pixels outside the band, largest eps among them, share of pixels with M >= TAU (proven inside)")
         for name, nout, n, worst, safe in _REPORT:
             print(f"    {name:44s} {nout:5d} / {n:7d}   {worst:9.2e}   {100 * safe:6.2f} %")
+        print("  witnesses: fixture, pixels outside the band, of which NO neighbouring conforming implementation lands inside")
+        for name, nout, missing in _WITNESS_REPORT:
+            print(f"    {name:44s} {nout:5d}   {missing:5d}")
 
 
 @pytest.mark.gpu

@@ -28,7 +28,8 @@ EXTRA=("sky2048|default_1920x1080_d8_spp1_sky2048_g1|--env sky2048"
        "variant14|default_1920x1080_d8_spp1_atmosphere256_g1_variant14|--variant 14"
        "C3nogrid|stress256_1920x1080_d8_spp1_atmosphere256_g1_nogrid|--config C3 --tune no_sphere_grid=1"
        "nocarry|default_1920x1080_d8_spp1_atmosphere256_g1_nocarry|--tune carry_last=0"
-       "C3gridcarry|stress256_1920x1080_d8_spp1_atmosphere256_g1_gridcarry|--config C3 --tune grid_carry=1")
+       "C3gridcarry|stress256_1920x1080_d8_spp1_atmosphere256_g1_gridcarry|--config C3 --tune grid_carry=1"
+       "C3gridcarry2|stress256_1920x1080_d8_spp1_atmosphere256_g1_gridcarry2|--config C3 --tune grid_carry=2")
 
 if [ "$MODE" = collect ]; then
   mkdir -p profiles/$RND
@@ -96,6 +97,10 @@ bash tools/unchained_timed.sh $RND > gpurun_out/$RND/unchained_timed.log 2>&1
 if [ -x tools/ab/libP.so ]; then for sc in default stress glass; do MI355PT_LIB=$R/tools/ab/libP.so timeout 200 python tools/profile_sections.py $sc 0 640 2>&1 | grep -v amdgpu; done > gpurun_out/$RND/profile_sections.log; fi
 N=12000; NM=5000; F1=600; F2=400; F4=1000; if [ "$QUICK" = --quick ]; then N=3000; NM=2000; F1=200; F2=150; F4=400; fi
 { for L in "" _audit _chaos _audit_chaos; do echo "== libmi355pt$L.so"; timeout 900 tools/handover_stress.bin opentk-pathtracer_amd/libmi355pt$L.so $N $((700 + ${#L})) | grep -v "^\.\.\."; done
+  echo "== round 6: frame-fed launches on every image size (--tune feed_min_tiles=0), idle budget 150 us and 0"
+  for L in "" _audit_chaos; do timeout 900 tools/handover_stress.bin opentk-pathtracer_amd/libmi355pt$L.so $((N / 2)) $((720 + ${#L})) --tune feed_min_tiles=0 | grep -v "^\.\.\."; done
+  timeout 900 tools/handover_stress.bin opentk-pathtracer_amd/libmi355pt_audit.so $((N / 4)) 731 --tune feed_min_tiles=0 --tune feed_idle_us=1 | grep -v "^\.\.\."
+  timeout 900 tools/handover_stress.bin opentk-pathtracer_amd/libmi355pt.so $((N / 4)) 732 --tune feed_min_tiles=0 --tune handover_budget_ms=0 | grep -v "^\.\.\."
   echo "== multisample focus, batch-pass kernel forced onto tiny images (--tune batch_pass_min_tiles=0)"
   timeout 600 tools/handover_stress.bin opentk-pathtracer_amd/libmi355pt_audit_chaos.so $NM 711 --multisample --tune batch_pass_min_tiles=0 | grep -v "^\.\.\."
   timeout 600 tools/handover_stress.bin opentk-pathtracer_amd/libmi355pt.so $NM 712 --multisample --tune batch_pass_min_tiles=0 | grep -v "^\.\.\."; } > gpurun_out/$RND/handover_stress.log 2>&1
