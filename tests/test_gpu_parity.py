@@ -632,9 +632,12 @@ def test_atmosphere_equals_oracle_and_reference(pkg, native_lib, oracle):
         got = at.Result
         want = oracle.atmosphere(size, fx["ubo"].tobytes(), fx["light_pos"], float(fx["intensity"]), isteps, jsteps)
         assert np.array_equal(bits(got), bits(want)), f"{name}: HIP atmosphere differs from the oracle"
-        ref = fx["expected"]
-        scale = np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max())
-        assert (np.abs(got[..., :3] - ref) / scale).max() < 2e-3
+        # ... and the GPU's own cube against the reference's, with the per-fixture marks frozen in round 6 (24^2 / 32^2 / 48^2 — one of them
+        # not a power of two —, 3 and 15 sun-ray steps): the kernel's roots and its half-cube symmetry changed in round 5 together with
+        # the oracle, so "equals the oracle" alone would not show a drift from the reference
+        err = tol.atmo_error(fx["expected"], got[..., :3])
+        worst, share = tol.ATMO_MARKS[name]
+        assert err.max() <= worst and (err < 1e-4).mean() >= share, f"{name}: {err.max():.3g} / {100 * (err < 1e-4).mean():.2f} %"
         pt.Dispose()
     assert len(ubo) == 464
 

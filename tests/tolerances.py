@@ -18,6 +18,8 @@
 import json
 import os
 
+import numpy as np
+
 REL_TOL = 1e-4
 PIXEL_FRACTION = 0.975   # fallback only (fixtures newer than agreement.json)
 THRESHOLDS_SHA256 = "daf5fc5dbcbd08d2fbf19cf26f975c2192d45ac19af830116831854edb243bb6"  # of tests/golden/thresholds.json
@@ -100,3 +102,15 @@ def convergence_stats(mean_ref, stderr_ref, got) -> dict:
     return {"max_abs_z": float(az.max()), "rms_z": float(np.sqrt((az ** 2).mean())), "frac_abs_z_gt_1": float((az > 1).mean()),
             "mean_rel_err": float(abs(got[ok].mean() - mean_ref[ok].mean()) / abs(mean_ref[ok].mean())),
             "nan_mismatch": int((nan_ref != nan_got).sum()), "pixels": int(ok.all(-1).sum())}
+
+
+# ---- atmosphere cubes (AtmosphericScattering/compute.glsl on llvmpipe vs the pt-f32 restatement), FROZEN in round 6 from the measured
+# per-texel agreement: error = |got - ref| / max(|ref|, 1e-3 max|ref|); per fixture (largest error allowed = measured x 1.5, smallest share
+# of texels within 1e-4 = measured - 0.3 points).  Measured: 1.49e-4 / 99.63 %, 3.45e-4 / 97.84 %, 1.48e-4 / 99.94 %.  Until round 5 the
+# gate was a flat 2e-3 for every cube.  Moving a mark is a visible diff of this file.
+ATMO_MARKS = {"atmo_24_few_steps": (2.3e-4, 0.9933), "atmo_32_default": (5.2e-4, 0.9754), "atmo_48_noon": (2.3e-4, 0.9964)}
+
+
+def atmo_error(ref, got):
+    scale = np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max())
+    return np.abs(got - ref) / scale
