@@ -73,16 +73,67 @@ static inline float f_unbits(uint32_t u) { float f; memcpy(&f, &u, 4); return f;
  * reference that the contract misses must be HIT by one of its neighbours.  P: 0 rcp, 1 rsqrt, 2 sqrt, 3 sin, 4 cos, 5 exp, 6 pow5. */
 #ifdef PT_ORACLE_PERTURB
 static int g_perturb_prim = -1, g_perturb_ulps = 0;
-static inline float perturbed(int prim, float y)
+/* TARGETED witnesses (round 6).  A global shift of a primitive moves every value of the path; what separates the contract from the
+ * reference in an out-of-band pixel is usually ONE comparison that came out the other way.  Two single-site variants, both conforming
+ * (GLSL fixes neither the last bits of a primitive at one particular argument nor, therefore, the outcome of a comparison whose operands
+ * are closer than those bits):
+ *   - g_flip_at[]: the pixel's k-th data-dependent comparison (DECIDE sites: compute.glsl:169,201,208,234,247,269,293,322-332,347-350,
+ *     refract's k < 0) is inverted, everything else evaluated by the contract;
+ *   - g_tprim / g_tcall / g_tulps [g_tn]: the n-th call of primitive P in this pixel returns a result `ulps` off, every other call the
+ *     contract's (up to WIT_MAX_SITES such calls at once: pixels whose paths AMPLIFY — a few bounces on curved surfaces turn one ulp
+ *     into 1e-3 of the colour — are reached by a handful of calls a few ulps off, not by one).
+ * pto_witness_search tries them for one pixel (single-threaded; the counters are per thread, the targets are globals). */
+#define WIT_MAX_CLOSE 2048
+#define WIT_MAX_FLIPS 3
+static int g_flip_at[WIT_MAX_FLIPS] = { -1, -1, -1 };
+#define WIT_MAX_SITES 32
+static int g_tn = 0, g_tprim[WIT_MAX_SITES], g_tcall[WIT_MAX_SITES], g_tulps[WIT_MAX_SITES]; /* targeted primitive calls */
+static float g_record_gap = 0.0f; /* > 0: record the decisions whose operands are closer than this (relative to their scale) */
+static __thread int tl_dec_n, tl_call_n[8], tl_close_n, tl_nan_env;
+static __thread struct { int idx; float gap; } tl_close[WIT_MAX_CLOSE];
+static inline float ulp_shift(float y, int ulps)
 {
-    if (prim != g_perturb_prim || g_perturb_ulps == 0 || !(fabsf(y) > 1.17549435e-38f) || isinf(y)) return y;
+    if (!(fabsf(y) > 1.17549435e-38f) || isinf(y)) return y;
     uint32_t u; memcpy(&u, &y, 4);
-    u = (uint32_t)((int32_t)u + g_perturb_ulps); /* (sign-magnitude: + = away from zero) */
+    u = (uint32_t)((int32_t)u + ulps); /* (sign-magnitude: + = away from zero) */
     memcpy(&y, &u, 4);
     return y;
 }
+static inline float perturbed(int prim, float y)
+{
+    const int n = tl_call_n[prim]++;
+    for (int t = 0; t < g_tn; t++)
+        if (prim == g_tprim[t] && n == g_tcall[t]) return ulp_shift(y, g_tulps[t]);
+    if (prim != g_perturb_prim || g_perturb_ulps == 0) return y;
+    return ulp_shift(y, g_perturb_ulps);
+}
+static inline int decide(int cond, float diff, float scale)
+{
+    const int k = tl_dec_n++;
+    if (g_record_gap > 0.0f) {
+        const float gap = fabsf(diff) / fmaxf(fabsf(scale), 1e-30f);
+        if (gap < g_record_gap && tl_close_n < WIT_MAX_CLOSE) { tl_close[tl_close_n].idx = k; tl_close[tl_close_n].gap = gap; tl_close_n++; }
+    }
+    return (k == g_flip_at[0] || k == g_flip_at[1] || k == g_flip_at[2]) ? !cond : cond;
+}
+#define DECIDE(cond, diff, scale) decide((cond), (diff), (scale))
+/* "primitive" 7: a * b + c.  GLSL lets an implementation fuse it or not; the contract fuses where this file says fmaf, llvmpipe never
+ * does.  A targeted site (any non-zero shift) evaluates that ONE multiply-add the other way; pto_set_unfused(1) all of them (outside
+ * the primitives above, whose own Newton steps are part of their definition). */
+static int g_unfuse_all = 0, g_pow_neg_nan = 0, g_nan_env_set = 0;
+static float g_nan_env[3]; /* what texture(env, NaN direction) returns instead of the contract's clamped lookup (pto_set_nan_env) */
+static inline float wit_fma(float a, float b, float c)
+{
+    const int n = tl_call_n[7]++;
+    int unfused = g_unfuse_all;
+    for (int t = 0; t < g_tn; t++)
+        if (g_tprim[t] == 7 && n == g_tcall[t] && g_tulps[t] != 0) unfused = !unfused;
+    if (unfused) { const float m = a * b; return m + c; } /* (-ffp-contract=off: two roundings) */
+    return __builtin_fmaf(a, b, c);
+}
 #else
 #define perturbed(prim, y) (y)
+#define DECIDE(cond, diff, scale) (cond)
 #endif
 /* pt-f32 reciprocal: seed by exponent negation, three Newton steps; zero and denormals give +-inf */
 static inline float f_rcp(float x)
@@ -127,6 +178,9 @@ static inline float pt_sqrt(float x)
     float r = fmaf(-s, s, x);
     return perturbed(2, fmaf(r, 0.5f * y, s));
 }
+#ifdef PT_ORACLE_PERTURB
+#define fmaf(a, b, c) wit_fma((a), (b), (c)) /* (the vector helpers and the integrator; not the primitives) */
+#endif
 static inline float f_mix(float x, float y, float a) { return fmaf(y, a, x * (1.0f - a)); }
 
 static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
@@ -146,6 +200,9 @@ static inline v3 v_mix(v3 x, v3 y, float a)
 }
 
 static inline float f_from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+#ifdef PT_ORACLE_PERTURB
+#undef fmaf
+#endif
 
 /* sin and cos of a (radians), |a| small (the integrator only passes [0, 2*pi]).  Cody-Waite reduction by pi/2
  * with two fused steps, then the classic single-precision minimax polynomials on [-pi/4, pi/4]. */
@@ -190,7 +247,19 @@ static float f_exp(float x)
     return perturbed(5, y * f_from_bits((uint32_t)(n2 + 127) << 23));
 }
 
-static inline float f_pow5(float x) { float x2 = x * x; return perturbed(6, x * (x2 * x2)); } /* (GLSL: pow(x, 5.0) — llvmpipe's is ~22 ulp off) */
+static inline float f_pow5(float x) /* (GLSL: pow(x, 5.0) — llvmpipe's is ~22 ulp off) */
+{
+#ifdef PT_ORACLE_PERTURB
+    /* pow(x, y) is undefined for x < 0 (GLSL 4.60 section 8.2); llvmpipe's exp2(y log2 x) is NaN.  Mode 2: also for a base within four
+       ulps of 1 - cos = 0 — whether 1 - dot(-d, n) of two unit vectors comes out as +-1e-7 or 0 is the last bit of the dot product */
+    if (g_pow_neg_nan && (x < 0.0f || (g_pow_neg_nan == 2 && x < 4.8e-7f))) return NAN;
+#endif
+    float x2 = x * x;
+    return perturbed(6, x * (x2 * x2));
+}
+#ifdef PT_ORACLE_PERTURB
+#define fmaf(a, b, c) wit_fma((a), (b), (c))
+#endif
 
 /* ------------------------------------------------------------------ scene blob accessors (std140, compute.glsl:13-42,66-70) */
 #define SPHERE_STRIDE 20  /* floats: 80 B  */
@@ -346,6 +415,12 @@ static rgb sample_env(const Ctx *c, v3 d)
 #ifdef PT_ORACLE_MARK_NAN_ENV /* diagnostic build only (oracle/Makefile): flag the paths that end in texture(env, NaN direction) */
     if (d.x != d.x || d.y != d.y || d.z != d.z) { rgb mark = { 1000.0f, 1000.0f, 1000.0f }; return mark; }
 #endif
+#ifdef PT_ORACLE_PERTURB
+    if (d.x != d.x || d.y != d.y || d.z != d.z) { /* texture(env, NaN): undefined in GL (see pto_witness_search) */
+        tl_nan_env = 1;
+        if (g_nan_env_set) { rgb o_ = { g_nan_env[0], g_nan_env[1], g_nan_env[2] }; return o_; }
+    }
+#endif
     int S = c->envSize, face;
     float sc, tc, ma;
     dir_to_face(d.x, d.y, d.z, &face, &sc, &tc, &ma);
@@ -392,7 +467,10 @@ static int ray_sphere(v3 o, v3 d, v3 pos, float radius, float *t1, float *t2)
     float b = v_dot(d, oc);
     float c = fmaf(-radius, radius, v_dot(oc, oc));
     float disc = fmaf(b, b, -c);
-    if (disc < 0.0f) return 0;
+    if (DECIDE(disc < 0.0f, disc, f_max(b * b, fabsf(c)))) return 0;
+#ifdef PT_ORACLE_PERTURB
+    if (disc < 0.0f) disc = 0.0f; /* (the inverted decision: an implementation whose discriminant came out >= 0 grazes the sphere) */
+#endif
     float s = pt_sqrt(disc);
     *t1 = -b - s;
     *t2 = -b + s;
@@ -415,7 +493,7 @@ static int ray_cuboid(v3 o, v3 d, v3 invd, v3 mn, v3 mx, float *t1, float *t2)
     v3 bg = V(f_max(t0s.x, t1s.x), f_max(t0s.y, t1s.y), f_max(t0s.z, t1s.z));
     *t1 = f_max(FLOAT_MIN, f_max(sm.x, f_max(sm.y, sm.z)));
     *t2 = f_min(FLOAT_MAX, f_min(bg.x, f_min(bg.y, bg.z)));
-    return *t1 <= *t2;
+    return DECIDE(*t1 <= *t2, *t2 - *t1, f_max(fabsf(*t1), fabsf(*t2)));
 }
 
 static inline float f_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
@@ -427,9 +505,17 @@ static v3 cuboid_normal(v3 mn, v3 mx, v3 p)
     v3 half = v_scale(v_sub(mx, mn), 0.5f);
     v3 cs = v_sub(p, v_scale(v_add(mx, mn), 0.5f));
     v3 n;
+#ifdef PT_ORACLE_PERTURB /* (step(edge, x) = x < edge ? 0 : 1 with x = EPSILON: the same comparison, as a DECIDE site) */
+#define STEP_EPS(c_, h_) (DECIDE(EPSILON < fabsf(fabsf(c_) - (h_)), fabsf(fabsf(c_) - (h_)) - EPSILON, f_max(f_max(fabsf(c_), (h_)), 1.0f)) ? 0.0f : 1.0f)
+    n.x = f_sign(cs.x) * STEP_EPS(cs.x, half.x);
+    n.y = f_sign(cs.y) * STEP_EPS(cs.y, half.y);
+    n.z = f_sign(cs.z) * STEP_EPS(cs.z, half.z);
+#undef STEP_EPS
+#else
     n.x = f_sign(cs.x) * f_step(fabsf(fabsf(cs.x) - half.x), EPSILON);
     n.y = f_sign(cs.y) * f_step(fabsf(fabsf(cs.y) - half.y), EPSILON);
     n.z = f_sign(cs.z) * f_step(fabsf(fabsf(cs.z) - half.z), EPSILON);
+#endif
 #ifdef PT_ORACLE_MARGINS
     { /* compute.glsl:322-332: step(EPSILON, | |p - centre| - halfsize |) per axis decides which faces the normal sees (a hit point within
          EPSILON of an edge); error = the hit point's + fresh rounding of the coordinates involved */
@@ -557,9 +643,9 @@ static int ray_trace(const Ctx *c, v3 o, v3 d, HitInfo *h, Stats *st)
 #endif
     for (int i = 0; i < c->numSpheres; i++) {
         const float *s = ob + (size_t)i * SPHERE_STRIDE;
-        if (ray_sphere(o, d, V(s[0], s[1], s[2]), s[3], &t1, &t2) && t2 > 0.0f && t1 < T) {
+        if (ray_sphere(o, d, V(s[0], s[1], s[2]), s[3], &t1, &t2) && DECIDE(t2 > 0.0f, t2, f_max(fabsf(t1), fabsf(t2))) && DECIDE(t1 < T, t1 - T, f_max(fabsf(t1), fabsf(T)))) {
             NOTE_ACCEPT();
-            T = t1 < 0.0f ? t2 : t1;
+            T = DECIDE(t1 < 0.0f, t1, f_max(fabsf(t1), fabsf(t2))) ? t2 : t1;
             wt2 = t2;
             winner = i;
         }
@@ -567,9 +653,9 @@ static int ray_trace(const Ctx *c, v3 o, v3 d, HitInfo *h, Stats *st)
     v3 invd = V(f_rcp(d.x), f_rcp(d.y), f_rcp(d.z));
     for (int i = 0; i < c->numCuboids; i++) {
         const float *q = ob + CUBOIDS_OFFSET + (size_t)i * CUBOID_STRIDE;
-        if (ray_cuboid(o, d, invd, V(q[0], q[1], q[2]), V(q[4], q[5], q[6]), &t1, &t2) && t2 > 0.0f && t1 < T) {
+        if (ray_cuboid(o, d, invd, V(q[0], q[1], q[2]), V(q[4], q[5], q[6]), &t1, &t2) && DECIDE(t2 > 0.0f, t2, f_max(fabsf(t1), fabsf(t2))) && DECIDE(t1 < T, t1 - T, f_max(fabsf(t1), fabsf(T)))) {
             NOTE_ACCEPT();
-            T = t1 < 0.0f ? t2 : t1;
+            T = DECIDE(t1 < 0.0f, t1, f_max(fabsf(t1), fabsf(t2))) ? t2 : t1;
             wt2 = t2;
             winner = 256 + i;
         }
@@ -630,7 +716,10 @@ static v3 f_refract(v3 i, v3 n, float eta)
     margin_eps(k, 2.0f * eta * eta * fabsf(ni) * tl_dcos + ERR_FRESH * f_max(1.0f, eta * eta));
     tl_refr_k = k;
 #endif
-    if (k < 0.0f) return V(0.0f, 0.0f, 0.0f);
+    if (DECIDE(k < 0.0f, k, f_max(1.0f, eta * eta))) return V(0.0f, 0.0f, 0.0f);
+#ifdef PT_ORACLE_PERTURB
+    if (k < 0.0f) k = 0.0f; /* (the inverted decision) */
+#endif
     float f = fmaf(eta, ni, pt_sqrt(k));
     return V(fmaf(eta, i.x, -(f * n.x)), fmaf(eta, i.y, -(f * n.y)), fmaf(eta, i.z, -(f * n.z)));
 }
@@ -665,11 +754,12 @@ static float bsdf(v3 *ro, v3 *rd, const HitInfo *h, int *isRefractive, uint32_t 
         tl_dthr += (h->m.specularChance > 0.0f ? dspec_ / prob_ : 0.0f) + ERR_FRESH;
     }
 #endif
-    if (spec > roll) {
+    const int lobeSpec = DECIDE(spec > roll, spec - roll, 1.0f);
+    if (lobeSpec) {
         v3 refl = f_reflect(*rd, h->normal);
         *rd = v_normalize(v_mix(refl, diffuseRay, h->m.specularRoughness * h->m.specularRoughness));
         prob = spec;
-    } else if (spec + refr > roll) {
+    } else if (DECIDE(spec + refr > roll, spec + refr - roll, 1.0f)) {
         v3 rf = f_refract(*rd, h->normal, h->fromInside ? h->m.ior : f_rcp(h->m.ior));
         v3 rough = cosine_sample_hemisphere(v_neg(h->normal), seed);
         *rd = v_normalize(v_mix(rf, rough, h->m.refractionRoughness * h->m.refractionRoughness));
@@ -734,7 +824,8 @@ static v3 radiance(const Ctx *c, v3 ro, v3 rd, uint32_t *seed, Stats *st)
                 if (i + 1 < c->rayDepth) margin_eps(roll_ - p, p * tl_dthr + ERR_FRESH * p); /* compute.glsl:169 (after the last bounce the outcome no longer matters) */
             }
 #endif
-            if (rand01(seed) > p) break;
+            const float rr_ = rand01(seed);
+            if (DECIDE(rr_ > p, rr_ - p, f_max(p, 1.0f))) break;
             throughput = v_scale(throughput, f_rcp(p));
         } else {
             rgb e = sample_env(c, rd);
@@ -776,6 +867,10 @@ static void shade_pixel(const Ctx *c, int px, int py, int frame, const float *la
 {
     uint32_t seed = ((uint32_t)px * 1973u + (uint32_t)py * 9277u + (uint32_t)frame * 2699u) | 1u; /* :106 */
     v3 irr = V(0.0f, 0.0f, 0.0f);
+#ifdef PT_ORACLE_PERTURB
+    tl_dec_n = 0; tl_close_n = 0; tl_nan_env = 0;
+    memset(tl_call_n, 0, sizeof tl_call_n);
+#endif
     for (int s = 0; s < c->spp; s++) {
         float u0 = rand01(&seed), u1 = rand01(&seed); /* :113, x first */
         float ndcx = fmaf(((float)px + u0) * (1.0f / (float)c->width), 2.0f, -1.0f);  /* uniform 1/W, 1/H */
@@ -1056,6 +1151,253 @@ PTO_API int pto_set_perturbation(int prim, int ulps)
     return 0;
 #else
     (void)prim; (void)ulps;
+    return -1;
+#endif
+}
+
+/* witness build: 1 = every multiply-add outside the primitives is evaluated with two roundings (what llvmpipe does); 0 = the contract. */
+PTO_API int pto_set_unfused(int on)
+{
+#ifdef PT_ORACLE_PERTURB
+    g_unfuse_all = on != 0;
+    return 0;
+#else
+    (void)on;
+    return -1;
+#endif
+}
+
+/* witness build: texture(env, NaN direction) returns rgb3 (NULL: the contract's clamped lookup again).  The pixel is linear in this value,
+ * so two replays (0 and 1) tell which value of the undefined lookup would reproduce a given pixel of the reference. */
+PTO_API int pto_set_nan_env(const float *rgb3)
+{
+#ifdef PT_ORACLE_PERTURB
+    g_nan_env_set = rgb3 != NULL;
+    if (rgb3) memcpy(g_nan_env, rgb3, sizeof g_nan_env);
+    return 0;
+#else
+    (void)rgb3;
+    return -1;
+#endif
+}
+
+/* witness build: evaluate ONE pixel with up to three of its comparisons inverted (flips3[k] = decision index, -1 = none) and nsites
+ * primitive calls shifted (sites[3 t] = primitive, [3 t + 1] = call index within the pixel, [3 t + 2] = ulps); powNegNan 1 / 2: pow() of a
+ * negative (or within four ulps of zero) base is NaN.  Returns the number of
+ * DECIDE sites the evaluation passed (-1 in builds without the hooks). */
+PTO_API int pto_render_pixel_variant(const PtoParams *p, const float *basic144, const float *objects26624, const void *env,
+                                     int x, int y, int frame, const float *last4, const int *flips3, int nsites, const int *sites, int powNegNan,
+                                     float *out4)
+{
+#ifdef PT_ORACLE_PERTURB
+    Ctx c;
+    make_ctx(&c, p, basic144, objects26624, env);
+    if (nsites > WIT_MAX_SITES) return -2;
+    g_pow_neg_nan = powNegNan;
+    for (int k = 0; k < WIT_MAX_FLIPS; k++) g_flip_at[k] = flips3 ? flips3[k] : -1;
+    for (int t = 0; t < nsites; t++) { g_tprim[t] = sites[3 * t]; g_tcall[t] = sites[3 * t + 1]; g_tulps[t] = sites[3 * t + 2]; }
+    g_tn = nsites;
+    shade_pixel(&c, x, y, frame, last4, out4, NULL);
+    for (int k = 0; k < WIT_MAX_FLIPS; k++) g_flip_at[k] = -1;
+    g_tn = 0;
+    g_pow_neg_nan = 0;
+    return tl_dec_n;
+#else
+    (void)p; (void)basic144; (void)objects26624; (void)env; (void)x; (void)y; (void)frame; (void)last4; (void)flips3; (void)nsites; (void)sites; (void)powNegNan; (void)out4;
+    return -1;
+#endif
+}
+
+#ifdef PT_ORACLE_PERTURB
+/* distance from the reference in units of the band: <= 1 is inside (tests/tolerances.py within(); NaN == NaN agrees: the reference has
+ * NaN pixels by design) */
+static double wit_distance(const float *ref3, const float *got, double band)
+{
+    int refNan = 0, gotNan = 0;
+    double worst = 0.0;
+    for (int ch = 0; ch < 3; ch++) { refNan |= ref3[ch] != ref3[ch]; gotNan |= got[ch] != got[ch]; }
+    if (refNan || gotNan) return refNan && gotNan ? 0.0 : INFINITY;
+    for (int ch = 0; ch < 3; ch++) {
+        const double r = ref3[ch], tolc = band * (fabs(r) > 1.0 ? fabs(r) : 1.0), d = fabs(r - (double)got[ch]) / tolc;
+        if (!(d <= worst)) worst = d; /* (inf / NaN stay) */
+    }
+    return worst;
+}
+static int wit_cmp_gap(const void *a, const void *b)
+{
+    const float ga = ((const float *)a)[1], gb = ((const float *)b)[1];
+    return ga < gb ? -1 : ga > gb;
+}
+typedef struct { int prim, call; double move; } WitSite;
+static int wit_cmp_move(const void *a, const void *b)
+{
+    const double ma = ((const WitSite *)a)->move, mb = ((const WitSite *)b)->move;
+    return ma > mb ? -1 : ma < mb;
+}
+/* what implementations may differ by, in ulps, per primitive (0 rcp, 1 rsqrt, 2 sqrt, 3 sin, 4 cos, 5 exp, 6 pow5): GLSL 4.60 section 4.7.1
+ * allows 2.5 ulp for a / b, 2 for inversesqrt, leaves sin / cos / exp to the implementation and derives pow from exp2 / log2 (llvmpipe's
+ * pow(x, 5) is ~22 ulps from the product, its exp ~16); the search stays well inside */
+static const int wit_ulps[8] = { 2, 2, 2, 4, 4, 4, 16, 1 }; /* (7 = a multiply-add evaluated unfused: on or off) */
+#endif
+
+/* witness build: search a conforming neighbour of the contract that puts pixel (x, y) of frame `frame` inside band * max(1, |ref|) of
+ * the reference's value ref3.  Order: (0) pow() of a negative base returns NaN (undefined in GLSL; llvmpipe does); (1) each comparison whose operands are closer than closeGap (relative to their scale), nearest
+ * first, inverted alone; (2) each call of each primitive alone, +-1 .. its allowance; (3) pairs: a close comparison inverted + one LATER
+ * close comparison of the changed path inverted; (4) several calls at once: the calls that move the pixel at all, most sensitive first,
+ * each set to the shift (within its allowance) that brings the pixel nearest, two sweeps (coordinate descent).
+ * (5) every combination of -2 .. +2 ulps on the six most sensitive calls.
+ * Returns 0 = none, 1 = single flip, 2 = single call, 3 = pair of flips, 4 / 5 = several calls, 9 = pow(x < 0, 5) = NaN, 7 / 8 = no neighbour inside but the path
+ * (with one comparison inverted / as it is) ends in the environment lookup of a NaN direction, undefined in GL; flips3 / sites (capacity 3 * 32) / *nsites
+ * describe the witness for pto_render_pixel_variant; stats4 = { variants evaluated, calls that move the pixel by more than the band
+ * when one ulp off, the largest such move in units of the band x 1000 (saturated), the remaining distance in units of the band x 1000 }.
+ * out4 = the witness's (or the nearest variant's) pixel.  Single-threaded. */
+PTO_API int pto_witness_search(const PtoParams *p, const float *basic144, const float *objects26624, const void *env,
+                               int x, int y, int frame, const float *last4, const float *ref3, double band,
+                               float closeGap, int maxFlips, int *flips3, int *sites, int *nsites, int *stats4, float *out4)
+{
+#ifdef PT_ORACLE_PERTURB
+    Ctx c;
+    make_ctx(&c, p, basic144, objects26624, env);
+    int tried = 0, found = 0;
+    float base[4], v[4];
+    flips3[0] = flips3[1] = flips3[2] = -1;
+    *nsites = 0;
+    /* dry pass: the decisions worth inverting and the primitives' call counts */
+    static float close1[WIT_MAX_CLOSE][2], close2[WIT_MAX_CLOSE][2];
+    static WitSite moved[65536];
+    int calls[8], nmoved = 0, unstable = 0;
+    double largest = 0.0;
+    g_record_gap = closeGap;
+    shade_pixel(&c, x, y, frame, last4, base, NULL);
+    memcpy(out4, base, sizeof base);
+    const int baseNanEnv = tl_nan_env;
+    int flipToNanEnv = -1;
+    const int n1 = tl_close_n;
+    for (int k = 0; k < n1; k++) { close1[k][0] = (float)tl_close[k].idx; close1[k][1] = tl_close[k].gap; }
+    memcpy(calls, tl_call_n, sizeof calls);
+    qsort(close1, (size_t)n1, sizeof close1[0], wit_cmp_gap);
+    const int nf = n1 < maxFlips ? n1 : maxFlips;
+    g_record_gap = 0.0f;
+    for (int mode = 1; mode <= 2 && !found; mode++) { /* (0) pow(x < 0, 5) = NaN: 1 - cos(theta) an ulp below zero in the Fresnel term (a camera at the centre of a glass sphere) */
+        g_pow_neg_nan = mode;
+        shade_pixel(&c, x, y, frame, last4, v, NULL);
+        g_pow_neg_nan = 0;
+        tried++;
+        if (wit_distance(ref3, v, band) <= 1.0) { found = 9; flips3[2] = mode; memcpy(out4, v, sizeof v); } /* (flips3[2]: the mode, for the replay) */
+        else if (tl_nan_env && !baseNanEnv && flipToNanEnv == -1) { flipToNanEnv = -2; flips3[2] = mode; }
+    }
+    for (int k = 0; k < nf && !found; k++) { /* (1) */
+        g_flip_at[0] = (int)close1[k][0];
+        shade_pixel(&c, x, y, frame, last4, v, NULL);
+        tried++;
+        if (wit_distance(ref3, v, band) <= 1.0) { found = 1; flips3[0] = g_flip_at[0]; memcpy(out4, v, sizeof v); }
+        else if (tl_nan_env && flipToNanEnv < 0) flipToNanEnv = g_flip_at[0];
+    }
+    g_flip_at[0] = -1;
+    g_tn = 1;
+    for (int prim = 0; prim < 8 && !found; prim++) /* (2) */
+        for (int n = 0; n < calls[prim] && !found; n++)
+            for (int u = 1; u <= wit_ulps[prim] && !found; u++)
+                for (int sgn = 1; sgn >= (prim == 7 ? 1 : -1) && !found; sgn -= 2) {
+                    g_tprim[0] = prim; g_tcall[0] = n; g_tulps[0] = sgn * u;
+                    shade_pixel(&c, x, y, frame, last4, v, NULL);
+                    tried++;
+                    if (wit_distance(ref3, v, band) <= 1.0) {
+                        found = 2; sites[0] = prim; sites[1] = n; sites[2] = sgn * u; *nsites = 1; memcpy(out4, v, sizeof v);
+                    }
+                    if (u == 1 && sgn == 1) { /* how far ONE ulp at this call moves the pixel, in units of the band around the contract's value */
+                        const double mv = wit_distance(base, v, band);
+                        if (mv > 1.0) unstable++;
+                        if (mv > largest) largest = mv;
+                        if (mv > 0.0 && nmoved < 65536) { moved[nmoved].prim = prim; moved[nmoved].call = n; moved[nmoved].move = mv; nmoved++; }
+                    }
+                }
+    g_tn = 0;
+    const int npair = nf < 24 ? nf : 24;
+    for (int k = 0; k < npair && !found; k++) { /* (3) */
+        const int first = (int)close1[k][0];
+        g_flip_at[0] = first;
+        g_record_gap = closeGap;
+        shade_pixel(&c, x, y, frame, last4, v, NULL);
+        g_record_gap = 0.0f;
+        int n2 = 0;
+        for (int q = 0; q < tl_close_n; q++)
+            if (tl_close[q].idx > first) { close2[n2][0] = (float)tl_close[q].idx; close2[n2][1] = tl_close[q].gap; n2++; }
+        qsort(close2, (size_t)n2, sizeof close2[0], wit_cmp_gap);
+        if (n2 > 24) n2 = 24;
+        for (int q = 0; q < n2 && !found; q++) {
+            g_flip_at[1] = (int)close2[q][0];
+            shade_pixel(&c, x, y, frame, last4, v, NULL);
+            tried++;
+            if (wit_distance(ref3, v, band) <= 1.0) { found = 3; flips3[0] = first; flips3[1] = g_flip_at[1]; memcpy(out4, v, sizeof v); }
+        }
+        g_flip_at[1] = -1;
+    }
+    g_flip_at[0] = g_flip_at[1] = -1;
+    double best = wit_distance(ref3, base, band);
+    if (!found && nmoved > 0 && best < INFINITY) { /* (4) */
+        qsort(moved, (size_t)nmoved, sizeof moved[0], wit_cmp_move);
+        const int ns = nmoved < WIT_MAX_SITES ? nmoved : WIT_MAX_SITES;
+        for (int t = 0; t < ns; t++) { g_tprim[t] = moved[t].prim; g_tcall[t] = moved[t].call; g_tulps[t] = 0; }
+        g_tn = ns;
+        for (int sweep = 0; sweep < 2 && !found; sweep++)
+            for (int t = 0; t < ns && !found; t++) {
+                const int U = wit_ulps[g_tprim[t]];
+                int keep = g_tulps[t];
+                for (int u = (g_tprim[t] == 7 ? 0 : -U); u <= U && !found; u++) {
+                    if (u == keep) continue;
+                    g_tulps[t] = u;
+                    shade_pixel(&c, x, y, frame, last4, v, NULL);
+                    tried++;
+                    const double dist = wit_distance(ref3, v, band);
+                    if (dist < best) { best = dist; keep = u; memcpy(out4, v, sizeof v); }
+                    if (dist <= 1.0) found = 4;
+                }
+                g_tulps[t] = keep;
+            }
+        /* (5) the paths that amplify answer a shifted call CHAOTICALLY (the roundings downstream change too: +1 ulp at one normalisation
+           moved a pixel by -0.3 bands, -1 by -1.2, +2 by +2.8), so shifts do not add up and descent is a poor guide: enumerate every
+           combination of -2 .. +2 ulps on the six calls the pixel is most sensitive to (15,625 neighbours of the contract) */
+        if (!found) {
+            const int K = ns < 6 ? ns : 6;
+            int odo[6], lo[6], hi[6];
+            for (int t = 0; t < K; t++) { lo[t] = g_tprim[t] == 7 ? 0 : -2; hi[t] = g_tprim[t] == 7 ? 1 : 2; odo[t] = lo[t]; }
+            for (int t = 0; t < ns; t++) g_tulps[t] = 0;
+            g_tn = K;
+            for (;;) {
+                for (int t = 0; t < K; t++) g_tulps[t] = odo[t];
+                shade_pixel(&c, x, y, frame, last4, v, NULL);
+                tried++;
+                const double dist = wit_distance(ref3, v, band);
+                if (dist < best) { best = dist; memcpy(out4, v, sizeof v); }
+                if (dist <= 1.0) { found = 5; break; }
+                int t = 0;
+                while (t < K && ++odo[t] > hi[t]) { odo[t] = lo[t]; t++; }
+                if (t == K) break;
+            }
+            if (!found) for (int t = 0; t < K; t++) g_tulps[t] = 0;
+        }
+        if (found) {
+            int m = 0;
+            for (int t = 0; t < ns; t++)
+                if (g_tulps[t] != 0) { sites[3 * m] = g_tprim[t]; sites[3 * m + 1] = g_tcall[t]; sites[3 * m + 2] = g_tulps[t]; m++; }
+            *nsites = m;
+        }
+        g_tn = 0;
+    }
+    /* no neighbour lands inside, but the pixel's path — the contract's (8), or the contract's with one close comparison inverted (7, e.g.
+       refract's k < 0: total internal reflection -> refract() = 0 -> normalize(0) = NaN) — ends in texture(env, NaN direction), which GL
+       leaves undefined: llvmpipe returns one deterministic texel average, the contract another (docs/parity.md) */
+    if (!found && baseNanEnv) found = 8;
+    if (!found && flipToNanEnv != -1) { found = 7; flips3[0] = flipToNanEnv; /* (-2: through pow(x < 0) = NaN) */ }
+    stats4[0] = tried;
+    stats4[1] = unstable;
+    stats4[2] = largest * 1000.0 < 2e9 ? (int)(largest * 1000.0) : 2000000000;
+    stats4[3] = found ? 0 : (best * 1000.0 < 2e9 ? (int)(best * 1000.0) : 2000000000);
+    return found;
+#else
+    (void)p; (void)basic144; (void)objects26624; (void)env; (void)x; (void)y; (void)frame; (void)last4; (void)ref3; (void)band;
+    (void)closeGap; (void)maxFlips; (void)flips3; (void)sites; (void)nsites; (void)stats4; (void)out4;
     return -1;
 #endif
 }

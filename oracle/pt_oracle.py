@@ -88,6 +88,14 @@ class Oracle:
         L.pto_log.argtypes = [C.c_float]
         L.pto_set_perturbation.restype = C.c_int
         L.pto_set_perturbation.argtypes = [C.c_int, C.c_int]
+        _ip = C.POINTER(C.c_int)
+        L.pto_render_pixel_variant.restype = C.c_int
+        L.pto_render_pixel_variant.argtypes = [C.c_void_p, _fp, _fp, C.c_void_p, C.c_int, C.c_int, C.c_int, _fp, _ip, C.c_int, _ip, C.c_int, _fp]
+        L.pto_set_nan_env.restype = C.c_int
+        L.pto_set_nan_env.argtypes = [_fp]
+        L.pto_witness_search.restype = C.c_int
+        L.pto_witness_search.argtypes = [C.c_void_p, _fp, _fp, C.c_void_p, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_double, C.c_float, C.c_int,
+                                         _ip, _ip, _ip, _ip, _fp]
         L.pto_atmosphere.restype = C.c_int
         L.pto_atmosphere.argtypes = [_fp, _fp, C.c_float, C.c_int, C.c_int, C.c_int, _fp, C.c_int]
 
@@ -95,6 +103,56 @@ class Oracle:
         """Oracle(perturb=True) only: primitive `prim` (0 rcp, 1 rsqrt, 2 sqrt, 3 sin, 4 cos, 5 exp) returns results `ulps` units in the
         last place further from zero from now on (negative: nearer; 0 = the contract again)."""
         assert self.lib.pto_set_perturbation(prim, ulps) == 0, "this oracle build has no perturbation hooks (Oracle(perturb=True))"
+
+    def set_unfused(self, on: bool) -> None:
+        """Oracle(perturb=True) only: every a * b + c outside the primitives with two roundings (llvmpipe never fuses) / the contract again."""
+        assert self.lib.pto_set_unfused(int(on)) == 0, "this oracle build has no witness hooks (Oracle(perturb=True))"
+
+    def set_nan_env(self, rgb) -> None:
+        """Oracle(perturb=True) only: what texture(env, NaN direction) returns (None: the contract's clamped lookup)."""
+        v = None if rgb is None else np.ascontiguousarray(rgb, np.float32)
+        assert self.lib.pto_set_nan_env(None if v is None else _ptr(v)) == 0, "this oracle build has no witness hooks (Oracle(perturb=True))"
+
+    def witness_search(self, width, height, basic_ubo, objects_ubo, env_faces, xy, ref, band, *, num_spheres, num_cuboids, ray_depth, spp=1,
+                       focal_length=20.0, aperture=0.14, frame=0, last=None, close_gap=1e-2, max_flips=256):
+        """Oracle(perturb=True) only.  For every listed pixel: a conforming neighbour of the contract — one comparison inverted, one call of
+        one primitive a few ulps off, a pair of inverted comparisons, or several calls a few ulps off — that lands inside
+        band * max(1, |ref|) of `ref` (n x 3); see pto_witness_search.  Returns a list of dicts: kind (0 = none, 1 .. 5, 9 = a neighbour
+        inside; 7, 8 = the path ends in texture(env, NaN), undefined in GL), flips, sites
+        [(primitive, call, ulps)], value (4,), evaluated, unstable_calls, largest_move (bands), distance (bands, of the nearest variant)."""
+        basic, objs, env = self._inputs(basic_ubo, objects_ubo, env_faces)
+        p = self._params(width, height, num_spheres, num_cuboids, ray_depth, spp, focal_length, aperture, env)
+        xy = np.ascontiguousarray(xy, dtype=np.int32)
+        n = xy.shape[0]
+        last = np.zeros((n, 4), np.float32) if last is None else np.ascontiguousarray(last, np.float32)
+        ref = np.ascontiguousarray(ref, np.float32)
+        ip = C.POINTER(C.c_int)
+        res = []
+        for i in range(n):
+            flips, sites, ns, stats, out = np.zeros(3, np.int32), np.zeros(96, np.int32), C.c_int(0), np.zeros(4, np.int32), np.zeros(4, np.float32)
+            kind = self.lib.pto_witness_search(C.byref(p), _ptr(basic), _ptr(objs), env.ctypes.data_as(C.c_void_p), int(xy[i, 0]), int(xy[i, 1]),
+                                               frame, _ptr(last[i]), _ptr(ref[i]), float(band), close_gap, max_flips,
+                                               flips.ctypes.data_as(ip), sites.ctypes.data_as(ip), C.byref(ns), stats.ctypes.data_as(ip), _ptr(out))
+            assert kind >= 0, "this oracle build has no witness hooks (Oracle(perturb=True))"
+            res.append(dict(kind=kind, flips=tuple(int(f) for f in flips), sites=[tuple(int(v) for v in sites[3 * t:3 * t + 3]) for t in range(ns.value)],
+                            value=out, evaluated=int(stats[0]), unstable_calls=int(stats[1]), largest_move=stats[2] / 1000.0, distance=stats[3] / 1000.0))
+        return res
+
+    def render_pixel_variant(self, width, height, basic_ubo, objects_ubo, env_faces, x, y, *, num_spheres, num_cuboids, ray_depth, spp=1,
+                             focal_length=20.0, aperture=0.14, frame=0, last=None, flips=(-1, -1, -1), sites=(), pow_neg_nan=0):
+        """Oracle(perturb=True) only: one pixel with the listed comparisons inverted and / or the listed primitive calls shifted
+        (sites = [(primitive, call, ulps)]; pow_neg_nan 1 / 2: pow() of a negative / nearly zero base is NaN; see witness_search).  Returns (pixel (4,), number of comparisons the evaluation passed)."""
+        basic, objs, env = self._inputs(basic_ubo, objects_ubo, env_faces)
+        p = self._params(width, height, num_spheres, num_cuboids, ray_depth, spp, focal_length, aperture, env)
+        last = np.zeros(4, np.float32) if last is None else np.ascontiguousarray(last, np.float32)
+        fl = np.array((list(flips) + [-1, -1, -1])[:3], np.int32)
+        st = np.array([v for site in sites for v in site] or [0], np.int32)
+        out = np.zeros(4, np.float32)
+        ip = C.POINTER(C.c_int)
+        nd = self.lib.pto_render_pixel_variant(C.byref(p), _ptr(basic), _ptr(objs), env.ctypes.data_as(C.c_void_p), int(x), int(y), frame, _ptr(last),
+                                               fl.ctypes.data_as(ip), len(sites), st.ctypes.data_as(ip), pow_neg_nan, _ptr(out))
+        assert nd >= 0, "this oracle build has no witness hooks (Oracle(perturb=True))"
+        return out, nd
 
     # ---------------------------------------------------------------- frames
     @staticmethod
