@@ -89,7 +89,7 @@ static int g_flip_at[WIT_MAX_FLIPS] = { -1, -1, -1 };
 #define WIT_MAX_SITES 32
 static int g_tn = 0, g_tprim[WIT_MAX_SITES], g_tcall[WIT_MAX_SITES], g_tulps[WIT_MAX_SITES]; /* targeted primitive calls */
 static float g_record_gap = 0.0f; /* > 0: record the decisions whose operands are closer than this (relative to their scale) */
-static __thread int tl_dec_n, tl_call_n[8], tl_close_n, tl_nan_env;
+static __thread int tl_dec_n, tl_call_n[10], tl_close_n, tl_nan_env;
 static __thread struct { int idx; float gap; } tl_close[WIT_MAX_CLOSE];
 static inline float ulp_shift(float y, int ulps)
 {
@@ -131,7 +131,22 @@ static inline float wit_fma(float a, float b, float c)
     if (unfused) { const float m = a * b; return m + c; } /* (-ffp-contract=off: two roundings) */
     return __builtin_fmaf(a, b, c);
 }
+/* "primitive" 8: a / b where the contract multiplies by a reciprocal it has already (sphere normal (p - c) / r, throughput /= prob,
+ * throughput /= p: compute.glsl:318,164,170); a targeted site divides.  "primitive" 9: mix(x, y, a) as x + a (y - x) instead of
+ * x (1 - a) + y a (GLSL: "the linear blend"; both forms are in use). */
+static inline int wit_targeted(int prim)
+{
+    const int n = tl_call_n[prim]++;
+    for (int t = 0; t < g_tn; t++)
+        if (g_tprim[t] == prim && n == g_tcall[t] && g_tulps[t] != 0) return 1;
+    return 0;
+}
+static inline float wit_quot(float a, float b, float rb) { return wit_targeted(8) ? a / b : a * rb; }
+#define QUOT(a, b, rb) wit_quot((a), (b), (rb))
+#define MIX_OTHER_FORM() wit_targeted(9)
 #else
+#define QUOT(a, b, rb) ((a) * (rb))
+#define MIX_OTHER_FORM() 0
 #define perturbed(prim, y) (y)
 #define DECIDE(cond, diff, scale) (cond)
 #endif
@@ -181,7 +196,11 @@ static inline float pt_sqrt(float x)
 #ifdef PT_ORACLE_PERTURB
 #define fmaf(a, b, c) wit_fma((a), (b), (c)) /* (the vector helpers and the integrator; not the primitives) */
 #endif
-static inline float f_mix(float x, float y, float a) { return fmaf(y, a, x * (1.0f - a)); }
+static inline float f_mix(float x, float y, float a)
+{
+    if (MIX_OTHER_FORM()) return x + a * (y - x);
+    return fmaf(y, a, x * (1.0f - a));
+}
 
 static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
 static inline v3 v_add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -196,6 +215,7 @@ static inline v3 v_normalize(v3 a) { return v_scale(a, f_rsqrt(v_dot(a, a))); }
 static inline v3 v_mix(v3 x, v3 y, float a)
 {
     float ia = 1.0f - a;
+    if (MIX_OTHER_FORM()) return V(x.x + a * (y.x - x.x), x.y + a * (y.y - x.y), x.z + a * (y.z - x.z));
     return V(fmaf(y.x, a, x.x * ia), fmaf(y.y, a, x.y * ia), fmaf(y.z, a, x.z * ia));
 }
 
@@ -675,7 +695,8 @@ static int ray_trace(const Ctx *c, v3 o, v3 d, HitInfo *h, Stats *st)
         const float *s = ob + (size_t)winner * SPHERE_STRIDE;
         h->m = load_material(s + 4);
         v3 pc = v_sub(h->nearHitPos, V(s[0], s[1], s[2])); /* compute.glsl:316-319 GetNormal(Sphere) */
-        h->normal = v_scale(pc, 1.0f / s[3]); /* 1/radius: IEEE quotient, computed once per sphere */
+        const float ir = 1.0f / s[3]; /* 1/radius: IEEE quotient, computed once per sphere */
+        h->normal = V(QUOT(pc.x, s[3], ir), QUOT(pc.y, s[3], ir), QUOT(pc.z, s[3], ir));
     } else {
         const float *q = ob + CUBOIDS_OFFSET + (size_t)(winner - 256) * CUBOID_STRIDE;
         h->m = load_material(q + 8);
@@ -815,7 +836,10 @@ static v3 radiance(const Ctx *c, v3 ro, v3 rd, uint32_t *seed, Stats *st)
             rad = V(fmaf(h.m.emissiv.x, throughput.x, rad.x), fmaf(h.m.emissiv.y, throughput.y, rad.y),
                     fmaf(h.m.emissiv.z, throughput.z, rad.z));
             if (!isRefractive) throughput = v_mul(throughput, h.m.albedo);
-            throughput = v_scale(throughput, f_rcp(prob));
+            {
+                const float rprob = f_rcp(prob);
+                throughput = V(QUOT(throughput.x, prob, rprob), QUOT(throughput.y, prob, rprob), QUOT(throughput.z, prob, rprob));
+            }
             float p = f_max(throughput.x, f_max(throughput.y, throughput.z));
 #ifdef PT_ORACLE_MARGINS
             {
@@ -826,7 +850,10 @@ static v3 radiance(const Ctx *c, v3 ro, v3 rd, uint32_t *seed, Stats *st)
 #endif
             const float rr_ = rand01(seed);
             if (DECIDE(rr_ > p, rr_ - p, f_max(p, 1.0f))) break;
-            throughput = v_scale(throughput, f_rcp(p));
+            {
+                const float rp = f_rcp(p);
+                throughput = V(QUOT(throughput.x, p, rp), QUOT(throughput.y, p, rp), QUOT(throughput.z, p, rp));
+            }
         } else {
             rgb e = sample_env(c, rd);
             if (st) st->envLookups++;
@@ -1237,7 +1264,7 @@ static int wit_cmp_move(const void *a, const void *b)
 /* what implementations may differ by, in ulps, per primitive (0 rcp, 1 rsqrt, 2 sqrt, 3 sin, 4 cos, 5 exp, 6 pow5): GLSL 4.60 section 4.7.1
  * allows 2.5 ulp for a / b, 2 for inversesqrt, leaves sin / cos / exp to the implementation and derives pow from exp2 / log2 (llvmpipe's
  * pow(x, 5) is ~22 ulps from the product, its exp ~16); the search stays well inside */
-static const int wit_ulps[8] = { 2, 2, 2, 4, 4, 4, 16, 1 }; /* (7 = a multiply-add evaluated unfused: on or off) */
+static const int wit_ulps[10] = { 2, 2, 2, 4, 4, 4, 16, 1, 1, 1 }; /* (7 = a multiply-add unfused, 8 = a true division, 9 = the other form of mix: on or off) */
 #endif
 
 /* witness build: search a conforming neighbour of the contract that puts pixel (x, y) of frame `frame` inside band * max(1, |ref|) of
@@ -1265,7 +1292,7 @@ PTO_API int pto_witness_search(const PtoParams *p, const float *basic144, const 
     /* dry pass: the decisions worth inverting and the primitives' call counts */
     static float close1[WIT_MAX_CLOSE][2], close2[WIT_MAX_CLOSE][2];
     static WitSite moved[65536];
-    int calls[8], nmoved = 0, unstable = 0;
+    int calls[10], nmoved = 0, unstable = 0;
     double largest = 0.0;
     g_record_gap = closeGap;
     shade_pixel(&c, x, y, frame, last4, base, NULL);
@@ -1295,10 +1322,10 @@ PTO_API int pto_witness_search(const PtoParams *p, const float *basic144, const 
     }
     g_flip_at[0] = -1;
     g_tn = 1;
-    for (int prim = 0; prim < 8 && !found; prim++) /* (2) */
+    for (int prim = 0; prim < 10 && !found; prim++) /* (2) */
         for (int n = 0; n < calls[prim] && !found; n++)
             for (int u = 1; u <= wit_ulps[prim] && !found; u++)
-                for (int sgn = 1; sgn >= (prim == 7 ? 1 : -1) && !found; sgn -= 2) {
+                for (int sgn = 1; sgn >= (prim >= 7 ? 1 : -1) && !found; sgn -= 2) {
                     g_tprim[0] = prim; g_tcall[0] = n; g_tulps[0] = sgn * u;
                     shade_pixel(&c, x, y, frame, last4, v, NULL);
                     tried++;
@@ -1344,7 +1371,7 @@ PTO_API int pto_witness_search(const PtoParams *p, const float *basic144, const 
             for (int t = 0; t < ns && !found; t++) {
                 const int U = wit_ulps[g_tprim[t]];
                 int keep = g_tulps[t];
-                for (int u = (g_tprim[t] == 7 ? 0 : -U); u <= U && !found; u++) {
+                for (int u = (g_tprim[t] >= 7 ? 0 : -U); u <= U && !found; u++) {
                     if (u == keep) continue;
                     g_tulps[t] = u;
                     shade_pixel(&c, x, y, frame, last4, v, NULL);
@@ -1361,7 +1388,7 @@ PTO_API int pto_witness_search(const PtoParams *p, const float *basic144, const 
         if (!found) {
             const int K = ns < 6 ? ns : 6;
             int odo[6], lo[6], hi[6];
-            for (int t = 0; t < K; t++) { lo[t] = g_tprim[t] == 7 ? 0 : -2; hi[t] = g_tprim[t] == 7 ? 1 : 2; odo[t] = lo[t]; }
+            for (int t = 0; t < K; t++) { lo[t] = g_tprim[t] >= 7 ? 0 : -2; hi[t] = g_tprim[t] >= 7 ? 1 : 2; odo[t] = lo[t]; }
             for (int t = 0; t < ns; t++) g_tulps[t] = 0;
             g_tn = K;
             for (;;) {

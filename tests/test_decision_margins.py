@@ -79,7 +79,8 @@ def test_every_out_of_band_pixel_of_the_full_size_configs_sits_on_a_knife_edge(o
 # pto_render_pixel_variant:
 #   1  ONE data-dependent comparison of the pixel's path inverted (operands closer than 1e-2 of their scale), everything else the contract;
 #   2  ONE call of ONE primitive (1/x, inversesqrt, sqrt, sin, cos, exp, pow) 1-2 ulps off (sin / cos / exp up to 4, pow up to 16: GLSL
-#      leaves them to the implementation), or ONE a * b + c evaluated with two roundings instead of fused (llvmpipe never fuses);
+#      leaves them to the implementation), ONE a * b + c evaluated with two roundings instead of fused (llvmpipe never fuses), ONE a / b
+#      as a true division where the contract multiplies by a reciprocal, or ONE mix(x, y, a) as x + a (y - x);
 #   3  two comparisons inverted (the second on the changed path);
 #   4, 5  several such calls at once (paths that amplify: a few bounces on curved surfaces turn one ulp into 1e-3 of the colour, and
 #      the reference's pixel is one of the values the neighbours scatter over);
@@ -89,9 +90,8 @@ def test_every_out_of_band_pixel_of_the_full_size_configs_sits_on_a_knife_edge(o
 # normalize(0)).  Accumulated frames are taken one frame at a time from the REFERENCE's own previous accumulation (dumps of consecutive
 # frames), so every dump is a single-frame statement.  Measured over all fixtures (553 pixel-frames outside the band, 460 searched): 81 %
 # hit by a neighbour, 7 % end in the undefined lookup (and imply the same value of it as at least two other pixel-frames of the
-# environment), 10 % are moved out of the band by a single call one ulp off (demonstrably unstable) without a neighbour of THIS family
-# landing inside — the family varies the primitives and the fusing, not e.g. the algebraic form of mix() or a true division where the
-# contract multiplies by a reciprocal —, 1.5 % neither.  Gated: the share reached, and that no pixel is without
+# environment), 10 % are moved out of the band by a single call one ulp off (demonstrably unstable) without a neighbour landing inside
+# — their neighbours scatter over tens to thousands of bands and the search enumerates six sites at a time —, 1.5 % neither.  Gated: the share reached, and that no pixel is without
 # any of the three.  The global variants of the earlier rounds (one primitive off EVERYWHERE: 40-60 %) are subsumed.
 MAX_SEARCHED = 64      # pixels per dump the search runs on (the 256-sphere fixtures have up to 156 outside the band; ~0.3 s each there)
 _WITNESS_REPORT = []
