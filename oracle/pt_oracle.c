@@ -121,6 +121,10 @@ static inline int decide(int cond, float diff, float scale)
  * does.  A targeted site (any non-zero shift) evaluates that ONE multiply-add the other way; pto_set_unfused(1) all of them (outside
  * the primitives above, whose own Newton steps are part of their definition). */
 static int g_unfuse_all = 0, g_pow_neg_nan = 0, g_nan_env_set = 0;
+/* base variants (pto_set_base_variant): the searches above run AROUND a conforming implementation, by default the contract; llvmpipe's
+ * arithmetic differs from it everywhere at once (correctly rounded 1/x, sqrt, 1/sqrt; the literal a / b; never fused), and a pixel that
+ * amplifies is closer to the reference's value from a base that shares those than from the contract */
+static int g_base_exact = 0, g_base_truediv = 0;
 static float g_nan_env[3]; /* what texture(env, NaN direction) returns instead of the contract's clamped lookup (pto_set_nan_env) */
 static inline float wit_fma(float a, float b, float c)
 {
@@ -141,7 +145,7 @@ static inline int wit_targeted(int prim)
         if (g_tprim[t] == prim && n == g_tcall[t] && g_tulps[t] != 0) return 1;
     return 0;
 }
-static inline float wit_quot(float a, float b, float rb) { return wit_targeted(8) ? a / b : a * rb; }
+static inline float wit_quot(float a, float b, float rb) { return (wit_targeted(8) != 0) != (g_base_truediv != 0) ? a / b : a * rb; }
 #define QUOT(a, b, rb) wit_quot((a), (b), (rb))
 #define MIX_OTHER_FORM() wit_targeted(9)
 #else
@@ -156,6 +160,9 @@ static inline float f_rcp(float x)
 #ifdef PT_EXACT_DIVSQRT /* fidelity study only (oracle/Makefile): correctly rounded 1/x, 1/sqrt(x), sqrt(x) as llvmpipe's / and sqrt are */
     return 1.0f / x;
 #endif
+#ifdef PT_ORACLE_PERTURB
+    if (g_base_exact) return perturbed(0, 1.0f / x);
+#endif
     float y = f_unbits(0x7EF311C7u - f_bits(x));
     float e = fmaf(-x, y, 1.0f); y = fmaf(y, e, y);
     e = fmaf(-x, y, 1.0f); y = fmaf(y, e, y);
@@ -168,6 +175,9 @@ static inline float f_rsqrt(float x)
 {
 #ifdef PT_EXACT_DIVSQRT
     return 1.0f / sqrtf(x);
+#endif
+#ifdef PT_ORACLE_PERTURB
+    if (g_base_exact) return perturbed(1, 1.0f / sqrtf(x));
 #endif
     float y = f_unbits(0x5F3759DFu - (f_bits(x) >> 1));
     float h = 0.5f * x, t;
@@ -184,6 +194,9 @@ static inline float pt_sqrt(float x)
 {
 #ifdef PT_EXACT_DIVSQRT
     return sqrtf(x);
+#endif
+#ifdef PT_ORACLE_PERTURB
+    if (g_base_exact) return perturbed(2, sqrtf(x));
 #endif
     float y = f_unbits(0x5F3759DFu - (f_bits(x) >> 1));
     float h = 0.5f * x, t;
@@ -505,9 +518,16 @@ static int ray_cuboid(v3 o, v3 d, v3 invd, v3 mn, v3 mx, float *t1, float *t2)
     v3 t0s = V((mn.x - o.x) / d.x, (mn.y - o.y) / d.y, (mn.z - o.z) / d.z);
     v3 t1s = V((mx.x - o.x) / d.x, (mx.y - o.y) / d.y, (mx.z - o.z) / d.z);
 #else
-    (void)d;
     v3 t0s = v_mul(v_sub(mn, o), invd);
     v3 t1s = v_mul(v_sub(mx, o), invd);
+#ifdef PT_ORACLE_PERTURB
+    if (g_base_truediv) {
+        t0s = V((mn.x - o.x) / d.x, (mn.y - o.y) / d.y, (mn.z - o.z) / d.z);
+        t1s = V((mx.x - o.x) / d.x, (mx.y - o.y) / d.y, (mx.z - o.z) / d.z);
+    }
+#else
+    (void)d;
+#endif
 #endif
     v3 sm = V(f_min(t0s.x, t1s.x), f_min(t0s.y, t1s.y), f_min(t0s.z, t1s.z));
     v3 bg = V(f_max(t0s.x, t1s.x), f_max(t0s.y, t1s.y), f_max(t0s.z, t1s.z));
@@ -1190,6 +1210,22 @@ PTO_API int pto_set_unfused(int on)
     return 0;
 #else
     (void)on;
+    return -1;
+#endif
+}
+
+/* witness build: the implementation the searches and replays run around.  bits: 1 = never fuse a * b + c (outside the primitives), 2 =
+ * correctly rounded 1/x, 1/sqrt, sqrt, 4 = the literal a / b where the contract multiplies by a reciprocal (cuboid slabs, sphere normal,
+ * throughput).  7 = all three, what llvmpipe does; 0 = the contract. */
+PTO_API int pto_set_base_variant(int bits)
+{
+#ifdef PT_ORACLE_PERTURB
+    g_unfuse_all = (bits & 1) != 0;
+    g_base_exact = (bits & 2) != 0;
+    g_base_truediv = (bits & 4) != 0;
+    return 0;
+#else
+    (void)bits;
     return -1;
 #endif
 }

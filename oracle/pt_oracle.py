@@ -108,6 +108,11 @@ class Oracle:
         """Oracle(perturb=True) only: every a * b + c outside the primitives with two roundings (llvmpipe never fuses) / the contract again."""
         assert self.lib.pto_set_unfused(int(on)) == 0, "this oracle build has no witness hooks (Oracle(perturb=True))"
 
+    def set_base_variant(self, bits: int) -> None:
+        """Oracle(perturb=True) only: the conforming implementation the witness searches and replays run around — 1 never fused, 2 correctly
+        rounded 1/x, sqrt, 1/sqrt, 4 literal divisions; 7 = llvmpipe's choices, 0 = the contract."""
+        assert self.lib.pto_set_base_variant(int(bits)) == 0, "this oracle build has no witness hooks (Oracle(perturb=True))"
+
     def set_nan_env(self, rgb) -> None:
         """Oracle(perturb=True) only: what texture(env, NaN direction) returns (None: the contract's clamped lookup)."""
         v = None if rgb is None else np.ascontiguousarray(rgb, np.float32)
