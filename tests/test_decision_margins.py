@@ -217,6 +217,32 @@ def test_out_of_band_pixels_of_the_full_size_configs_have_conforming_witnesses(o
     _witnesses(name, fixtures.load(name), oracle, witness_oracle, True)
 
 
+def test_planted_errors_find_no_witness(oracle_margins, witness_oracle):
+    """The discriminating power of the pair (margin, witness).  The margin test alone lets a wrong pixel through whenever the pixel's
+    M < TAU (45 - 85 % of the pixels).  Plant errors of 10 bands into 120 seeded in-band pixels of a fixture: the ones with M >= TAU fail
+    the margin test; for the others the witness search must come back empty — a neighbour of the contract reproduces what the REFERENCE
+    computed, not an arbitrary value.  (Measured on four fixtures, errors of 3 / 10 / 100 bands, 1,500 planted pixels that pass the
+    margin test: 0 explained.)"""
+    name = "frame_default_128x72_d8"
+    fx = fixtures.load(name)
+    W, H, kw = fx["width"], fx["height"], fixtures.kwargs(fx)
+    scene = (W, H, fx["basic"], fx["objects"], fx["env"])
+    yy, xx = np.mgrid[0:H, 0:W]
+    xy = np.stack([xx.ravel(), yy.ravel()], 1).astype(np.int32)
+    ref = fx["expected"][0].reshape(-1, 3)
+    got, margin, cont = oracle_margins.render_pixels_margins(*scene, xy, **kw)
+    inside = tol.within(ref, got[:, :3], tol.REL_TOL)
+    M = sensitivity(margin, cont, ref, tol.REL_TOL)
+    rng = np.random.default_rng(7)
+    sel = rng.choice(np.nonzero(inside & np.isfinite(ref).all(-1))[0], 120, replace=False)
+    planted = ref[sel] + np.sign(rng.standard_normal((120, 3))) * 10.0 * tol.REL_TOL * np.maximum(1.0, np.abs(ref[sel]))
+    passes_margin = M[sel] < TAU
+    assert 30 <= passes_margin.sum() <= 110  # (the margin test alone is not enough: that is the point)
+    res = witness_oracle.witness_search(*scene, xy[sel[passes_margin]], planted[passes_margin], tol.REL_TOL, **kw)
+    explained = sum(1 for r in res if r["kind"] in (1, 2, 3, 4, 5, 9))
+    assert explained <= 1, f"{explained} of {passes_margin.sum()} planted errors have a 'witness'"
+
+
 def test_witness_share():
     """(runs after the witness tests) over all fixtures: the share of the searched out-of-band pixels that a neighbouring conforming
     implementation reproduces inside the band or whose path ends in GL's undefined lookup; and how many have nothing to show."""
