@@ -24,6 +24,7 @@ namespace ptimpl {
     do {                                                                                                                             \
         if (pt::tuning().feedLog) {                                                                                                  \
             std::fprintf(stderr, "[feed %9.1f us] ", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - 1e6 * (long long)(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count())); \
+            std::fprintf(stderr, "%p ", (void *)h);                                                                                  \
             std::fprintf(stderr, __VA_ARGS__);                                                                                       \
             std::fprintf(stderr, "\n");                                                                                              \
         }                                                                                                                            \
@@ -90,11 +91,20 @@ static int enqueue_repairs(pt_handle h, bool flagWasDown)
     // then every remembered launch gets its pass.)
     if (flagWasDown) {
         auto flag_down = [&]() -> bool { return !(h->hostErrWord && *(volatile unsigned int *)h->hostErrWord); };
-        while (!h->unverified.empty() && hipEventQuery(h->unverified.front().done) == hipSuccess && flag_down()) h->unverified.pop_front();
+        while (!h->unverified.empty() && hipEventQuery(h->unverified.front().done) == hipSuccess && flag_down()) {
+            FEED_LOG("repairs: launch %u frames [%d,+%d) seen complete with the flag down: no pass", h->unverified.front().a.launchSeq, h->unverified.front().a.frame, h->unverified.front().a.batchFrames);
+            h->unverified.pop_front();
+        }
         (void)hipGetLastError(); // (hipErrorNotReady of the query is not an error)
     }
-    if (h->unverified.empty()) return PT_OK;
-    for (const pt_renderer::LaunchRecord &r : h->unverified) PT_HIP(h, pt::launch_repair(r.a, h->dRepairCtl, h->stream));
+    // (nothing remembered and no abandonment noted: nothing to do.  An abandonment noted with nothing remembered — the launches it belongs to
+    // had their passes enqueued by an earlier join, before they gave up — still gets the closing kernel: the device's abandon word and
+    // ticket counters must never stay behind a flag the host has cleared)
+    if (h->unverified.empty() && flagWasDown) return PT_OK;
+    for (const pt_renderer::LaunchRecord &r : h->unverified) {
+        FEED_LOG("repairs: pass for launch %u frames [%d,+%d) chainTag %g keepTags %d variant %d", r.a.launchSeq, r.a.frame, r.a.batchFrames, (double)r.a.chainTag, r.a.keepTags, r.a.variant);
+        PT_HIP(h, pt::launch_repair(r.a, h->dRepairCtl, h->stream));
+    }
     PT_HIP(h, pt::launch_repair_done(h->dAbandon, h->dQueue, h->stripeQueueBase[0], h->dQueue + kChainQueueWord, h->chainQueueBase,
                                      h->dRepairCtl, h->stream));
     h->unverified.clear();
@@ -117,6 +127,7 @@ static void note_abandonment(pt_handle h)
 {
     const unsigned int why = *(volatile unsigned int *)h->hostErrWord;
     *(volatile unsigned int *)h->hostErrWord = 0;
+    FEED_LOG("abandon flag %u seen and cleared (frame %d, %zu launches remembered, feed open %d published %d)", why, h->frame, h->unverified.size(), (int)h->feed.open, h->feed.published);
     h->abandonEpoch++;
     // a hand-over that ran out of its budget = a contended device: launches stop overlapping for a while.  A frame-fed launch that ended
     // itself because no frame came (reason "idle") says nothing about the device — only about the host's pace: a host whose fed launches
@@ -188,6 +199,8 @@ static int resolve_fused_orphan(pt_handle h)
 
 int join_stripes(pt_handle h, bool repairNow)
 {
+    FEED_LOG("join (repairNow %d, frame %d, pending %d, tagsLive %d, %zu remembered, flag %u)", (int)repairNow, h->frame, h->pendingFrames, (int)h->tagsLive, h->unverified.size(),
+             h->hostErrWord ? *(volatile unsigned int *)h->hostErrWord : 0u);
     feed_close(h);
     if (h->pendingFrames > 0) {
         // whatever follows a join is ordered by the streams again, so this launch need not leave its tags in the image: its
@@ -213,8 +226,8 @@ int join_stripes(pt_handle h, bool repairNow)
     // hand-over repair of the launches since the last join (everything they wrote is behind h->stream now).  A caller that synchronises
     // h->stream next and then calls settle_handover() leaves it to that — unless the image still carries tags: the alpha pass that
     // follows such a join would wipe out what the repair reads.
-    if (!h->unverified.empty() && (repairNow || h->tagsLive)) {
-        const bool raised = h->hostErrWord && *(volatile unsigned int *)h->hostErrWord;
+    const bool raised = h->hostErrWord && *(volatile unsigned int *)h->hostErrWord;
+    if (raised || (!h->unverified.empty() && (repairNow || h->tagsLive))) {
         if (raised) note_abandonment(h);
         if (int rc = enqueue_repairs(h, !raised && !h->repairPendingAll)) return rc;
         h->repairPendingAll = false;
@@ -228,13 +241,12 @@ int settle_handover(pt_handle h)
 {
     if (h->hostErrWord && *(volatile unsigned int *)h->hostErrWord) {
         note_abandonment(h);
-        // (the launches the flag belongs to may already have been repaired by an earlier join; then nothing is left to do here)
-        if (!h->unverified.empty()) {
-            if (int rc = enqueue_repairs(h, false)) return rc;
-            h->repairPendingAll = false;
-            PT_HIP(h, hipStreamSynchronize(h->stream));
-        }
+        // (the launches the flag belongs to may already have been repaired by an earlier join; then only the closing kernel runs)
+        if (int rc = enqueue_repairs(h, false)) return rc;
+        h->repairPendingAll = false;
+        PT_HIP(h, hipStreamSynchronize(h->stream));
     }
+    if (!h->unverified.empty()) FEED_LOG("settle: %zu launches forgotten (synchronised, flag down)", h->unverified.size());
     h->unverified.clear();
     if (h->repairCheckDue) {
         // Repair passes ran since the last look (rare: a contended device).  A pixel whose tag fits nothing the launch sequence can have
@@ -933,7 +945,10 @@ void remember_launch(pt_handle h, const pt::FrameArgs &a, hipEvent_t done)
     // A launch seen COMPLETE with the flag DOWN — read in that order: an abandoning launch raises the flag before it ends — ran to its
     // end and needs no repair pass.
     auto flag_down = [&]() -> bool { return !(h->hostErrWord && *(volatile unsigned int *)h->hostErrWord); };
-    while (h->unverified.size() > 2 && hipEventQuery(h->unverified.front().done) == hipSuccess && flag_down()) h->unverified.pop_front();
+    while (h->unverified.size() > 2 && hipEventQuery(h->unverified.front().done) == hipSuccess && flag_down()) {
+        FEED_LOG("remember: launch %u frames [%d,+%d) seen complete with the flag down: forgotten", h->unverified.front().a.launchSeq, h->unverified.front().a.frame, h->unverified.front().a.batchFrames);
+        h->unverified.pop_front();
+    }
     (void)hipGetLastError(); // (hipErrorNotReady of the query is not an error)
     static_assert(pt_renderer::kLaunchEvents / 2 <= pt::kMaxUnverifiedLaunches, "frame-tag window (pt_kernels.hpp)");
     if (h->unverified.size() >= (size_t)pt_renderer::kLaunchEvents / 2) { // (the event ring must not lap a remembered launch; also the frame-tag window's bound)
@@ -941,6 +956,16 @@ void remember_launch(pt_handle h, const pt::FrameArgs &a, hipEvent_t done)
         if (flag_down()) h->unverified.pop_front();
     }
     h->unverified.push_back({a, done});
+    FEED_LOG("launch %u frames [%d,+%d) chainTag %g keepTags %d variant %d spp %d (%zu remembered)", a.launchSeq, a.frame, a.batchFrames, (double)a.chainTag, a.keepTags, a.variant, a.spp, h->unverified.size());
+    if (pt::tuning().feedLog >= 2) { // (debug: a blocking look at the device's abandon word and ticket counters)
+        unsigned int w = 0, q[2] = {0, 0};
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(&w, h->dAbandon, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&q[0], h->dQueue, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&q[1], h->dQueue + ptimpl::kChainQueueWord, 4, hipMemcpyDeviceToHost);
+        FEED_LOG("  after launch %u: abandon word %08x, tickets main %u (host %u) chain %u (host %u), flag %u", a.launchSeq, w, q[0], h->stripeQueueBase[0], q[1], h->chainQueueBase,
+                 h->hostErrWord ? *(volatile unsigned int *)h->hostErrWord : 0u);
+    }
 }
 
 // ---- frame-fed launches (pt_renderer.hpp: FeedState).  Wanted when few frames go out and nothing says the host is about to join: the

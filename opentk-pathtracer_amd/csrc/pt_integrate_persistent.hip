@@ -340,6 +340,22 @@ __global__ __launch_bounds__(NWAVES * 64, MIN_WAVES_PER_SIMD) void pt_integrate_
         }
         if (a.startedFlags) // "this workgroup is resident" (launch chaining): a system-scope store, the host polls the word
             __hip_atomic_store(a.startedFlags + blockIdx.x, a.launchSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef PT_AUDIT
+        // (audit build: a tagged launch that STARTS with a ticket counter outside its own range of the host's base draws only failing tickets
+        // and renders nothing — logged like a violation: site 91, "pix" = the counter, "frame" = the host's base)
+        if (a.tagged && a.audit && a.auditLog && blockIdx.x == 0) {
+            const unsigned int c = __hip_atomic_load((const unsigned int *)a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned int)(c - a.queueBase) > (unsigned int)numTiles + 65536u) {
+                const unsigned int slot = atomicAdd(a.auditLog, 1u);
+                if (slot < (unsigned int)kAuditLogRecords) {
+                    unsigned int *r = a.auditLog + 4 + slot * kAuditRecordWords;
+                    r[0] = 91u; r[1] = c; r[2] = a.queueBase; r[3] = 0u; r[4] = 0u; r[5] = 0u; r[6] = 0u; r[7] = a.launchSeq;
+                    r[8] = (unsigned int)a.frame | ((unsigned int)a.batchFrames << 24); r[9] = __float_as_uint(a.chainTag); r[10] = 0u;
+                    r[11] = (unsigned int)a.tagged | ((unsigned int)a.keepTags << 1) | ((unsigned int)a.variant << 8);
+                }
+            }
+        }
+#endif
     }
     if constexpr (FEED) {
         if (threadIdx.x < 8) wgDone[threadIdx.x] = 0u;

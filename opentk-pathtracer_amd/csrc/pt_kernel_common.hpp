@@ -324,6 +324,7 @@ struct FeedQueue {             // one per workgroup, static LDS (only the FEED k
 };
 PT_DEV unsigned int feed_count(unsigned int word) { return (word >> 16) & 0x7fffu; }
 constexpr int QUEUE_NOT_YET = -2; // queue_pop_tile_feed: work exists, but the host has not published its frame yet
+constexpr unsigned int kStashRemainder = 0x80000000u; // FeedQueue::stash, low word: first tile + 1 | this flag (see queue_pop_tile_feed)
 
 // What has the host published?  The launch's MONITOR wavefront is the only one that reads the host word (over PCIe) — it broadcasts every
 // new word into kFeedBcastSlots device words, and a workgroup reads the slot blockIdx % kFeedBcastSlots.  (Round 6, first version: every
@@ -372,8 +373,11 @@ PT_DEV int queue_pop_tile_feed(BlockQueue *q, FeedQueue *fq)
                 const unsigned int capTiles = (unsigned int)(ca->tilesX * ca->tilesY * ca->batchFrames), chunk = (unsigned int)ca->queueChunk;
                 unsigned long long st = lds_load64(&fq->stash);
                 unsigned int first, last;
+                bool remainder = false; // the stash is the REST of a ticket part of which has been handed out (kStashRemainder)
                 if (__builtin_amdgcn_readfirstlane((int)(st != 0ull))) {
-                    first = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)st) - 1u;
+                    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)st);
+                    remainder = (lo & kStashRemainder) != 0u;
+                    first = (lo & ~kStashRemainder) - 1u;
                     last = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(st >> 32));
                 } else {
                     unsigned int ticket = 0;
@@ -399,11 +403,18 @@ PT_DEV int queue_pop_tile_feed(BlockQueue *q, FeedQueue *fq)
                     if (first < limit) { // (part of) the ticket is published
                         const unsigned int upto = last < limit ? last : limit;
                         if (leader) atomicExch(&q->pair, ((unsigned long long)upto << 32) | (unsigned long long)first);
-                        if (upto < last && !closed) newStash = ((unsigned long long)last << 32) | (unsigned long long)(upto + 1u);
-                    } else if (closed) { // nothing of it will ever be published: the failing ticket
+                        if (upto < last && !closed) newStash = ((unsigned long long)last << 32) | (unsigned long long)((upto + 1u) | kStashRemainder);
+                    } else if (closed && !remainder) { // nothing of it will ever be published: the failing ticket
                         if (leader) lds_store(&q->done, 1u);
+                    } else if (closed) {
+                        // the unpublished rest of a ticket whose first tiles WERE handed out: that ticket counts among the successful ones in the
+                        // host's accounting (every ticket below ceil(final tiles / chunk)), so this workgroup still has its failing ticket to
+                        // draw — the stash is dropped and the next round draws it.  (Without this the device counter ended one short of the
+                        // host's base per such workgroup whenever a launch closed on a frame count whose tiles do not fill whole chunks —
+                        // 1440 x 900 has 20,340 tiles, chunk 8 — and a launch of a tiny image, with fewer workgroups than the deficit, then drew
+                        // only failing tickets and rendered nothing: found by tools/handover_stress --tune feed_min_tiles=0.)
                     } else {
-                        newStash = ((unsigned long long)last << 32) | (unsigned long long)(first + 1u);
+                        newStash = ((unsigned long long)last << 32) | (unsigned long long)((first + 1u) | (remainder ? kStashRemainder : 0u));
                         notYet = true;
                     }
                 }

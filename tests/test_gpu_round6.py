@@ -237,6 +237,40 @@ def test_frame_fed_launch_is_bit_exact(pkg, native_lib, oracle, size, frames):
     assert pkg.native.debug_handover_stats  # (kept for symmetry with the hand-over tests)
 
 
+@pytest.mark.parametrize("size", [(24, 16), (40, 24), (136, 72)], ids=lambda v: str(v))
+def test_frame_fed_launches_that_close_inside_a_ticket_keep_the_ticket_count(pkg, native_lib, oracle, size):
+    """Tickets hand out tiles in chunks (8, or 4 for small batched launches) and a fed launch's frames end wherever their tiles end: an
+    image whose tiles per frame are no multiple of the chunk (6, 15, 153 here; 1440 x 900 has 20,340) leaves the workgroup that holds the
+    straddling ticket with an unpublished REST when the launch closes.  That rest is not the workgroup's failing ticket — the ticket
+    counts as handed out in the host's accounting — so the workgroup still draws one.  (It did not, up to round 6: every such close left
+    the device's counter one short of the host's base, and after as many closes as a launch of a tiny image has workgroups, launches drew
+    nothing but failing tickets and rendered nothing.  Found by tools/handover_stress --tune feed_min_tiles=0.)  60 launches that close
+    after 1, 3 or 5 frames, then a frame through a classic launch: bit-exact, no repair pass needed."""
+    w = configs.Workload("fedtickets", "default", size[0], size[1], 8, "sky_f32_32")
+    sc, basic, objs, env, kw = configs.inputs(w)
+    with _Tune(pkg, feed_min_tiles=0, feed_idle_us=200000):
+        pt = make_tracer(pkg, w)
+        _open_feed(pt)
+        total = 3
+        for i in range(60):
+            for _ in range((1, 3, 5)[i % 3]):
+                pt.Render()
+            total += (1, 3, 5)[i % 3]
+            pt.Synchronize()  # (a join closes the open launch)
+        st = pkg.native.debug_launch_stats(pt._h)
+        pt.SetFrameBatch(64)
+        pt.Render()
+        total += 1
+        got = pt.Result
+        ho = pkg.native.debug_handover_stats(pt._h)
+        pt.Dispose()
+    print(f"{size}: {st['feed_opens']} fed launches closed by joins, {st['published']} frames published; repair: {ho}")
+    assert st["feed_opens"] >= 40, "the frames did not go through frame-fed launches"
+    assert ho["pairs_repaired"] == 0 and ho["inconsistent"] == 0, "a launch had to be repaired"
+    want = oracle.render(w.width, w.height, basic, objs, env, num_frames=total, **kw)
+    assert_bit_exact(got, want, f"{total} frames through 60 frame-fed launches at {size}")
+
+
 def test_frame_fed_launch_ends_itself_when_the_host_stops_and_nothing_is_lost(pkg, native_lib, oracle):
     """A host that stops rendering must not keep the GPU: the launch's wavefronts wait feed_idle_us for the next frame, then the launch
     abandons itself (reason "idle"); the host's next call repairs whatever a racing publish left undone and launches anew.  Frames
