@@ -120,4 +120,5 @@ N=12000; NM=5000; F1=600; F2=400; F4=1000; if [ "$QUICK" = --quick ]; then N=300
   ( cd /tmp; rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU --output-format csv -d $R/gpurun_out/prof_${RND}_atmo -o pmc -- python $R/tools/atmo_profile.py 1024 2 > /dev/null 2>&1 )
   grep atmo $R/gpurun_out/prof_${RND}_atmo/pmc_counter_collection.csv > gpurun_out/$RND/atmosphere_pmc_1024.csv; } 2>&1 | grep -v amdgpu.ids > gpurun_out/$RND/atmosphere_profile.log
 cp gpurun_out/$RND/${RND}_default_bench.json gpurun_out/$RND/bench_default.json 2>/dev/null
+echo "FAILURES in the stress logs (must be 0):"; grep -c "library error\|MISMATCH\|AUDIT violation" gpurun_out/$RND/handover_stress.log gpurun_out/$RND/handover_zero_budget.log
 tail -3 gpurun_out/$RND/pytest_gpu.log; grep "handover_stress:\|==\|hand-over bound" gpurun_out/$RND/handover_zero_budget.log; cat gpurun_out/$RND/atmosphere_profile.log; grep "handover_stress:\|==" gpurun_out/$RND/handover_stress.log; grep "cases,\|==" gpurun_out/$RND/fuzz.log; grep "ms per" gpurun_out/$RND/present_rate.log; tail -14 gpurun_out/$RND/bench_configs.log
