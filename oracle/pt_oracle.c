@@ -90,7 +90,7 @@ static int g_flip_at[WIT_MAX_FLIPS] = { -1, -1, -1 };
 static int g_tn = 0, g_tprim[WIT_MAX_SITES], g_tcall[WIT_MAX_SITES], g_tulps[WIT_MAX_SITES]; /* targeted primitive calls */
 static float g_record_gap = 0.0f; /* > 0: record the decisions whose operands are closer than this (relative to their scale) */
 static __thread int tl_dec_n, tl_call_n[10], tl_close_n, tl_nan_env;
-static __thread struct { int idx; float gap; } tl_close[WIT_MAX_CLOSE];
+static __thread struct { int idx; float gap; int line; float diff; } tl_close[WIT_MAX_CLOSE];
 static inline float ulp_shift(float y, int ulps)
 {
     if (!(fabsf(y) > 1.17549435e-38f) || isinf(y)) return y;
@@ -99,24 +99,55 @@ static inline float ulp_shift(float y, int ulps)
     memcpy(&y, &u, 4);
     return y;
 }
+/* ENSEMBLE members (round 6, pto_set_ensemble; tests/test_ensemble_stability.py).  A member is ONE conforming implementation that differs
+ * from the contract everywhere at once, the way a real driver does: its primitive P'(x) = P(x) shifted by s ulps, s a fixed pseudo-random
+ * function of (member seed, primitive, the bits of P(x)) in [-a_P, +a_P] with a_P = min(amplitude, GLSL's / the search's allowance for P);
+ * each a * b + c is fused or not, each division literal or by reciprocal, as a fixed function of the member and the operands' bits.  The
+ * shift depends on the value only, so P' is a function (the same argument gives the same result in every pixel and frame).  A pixel
+ * whose value does not move under any member of an ensemble is insensitive to what conforming implementations differ by — the
+ * statement the first-order margins can only bound from one side. */
+static int g_sig_alpha = 0;            /* pto_set_signature_alpha: the alpha channel carries the pixel's PATH SIGNATURE instead of 1 */
+static __thread int tl_ub;            /* the pixel touched something GLSL / GL leave undefined (pow of a base that is negative or within four ulps of zero, a comparison on a NaN, texture(env, NaN)) */
+static __thread uint32_t tl_sig;       /* hash of the path's discrete events: object hit, lobe taken, how it ended — per bounce, sample, frame */
+static inline void sig_note(uint32_t ev) { tl_sig = (tl_sig ^ ev) * 0x01000193u + 0x9E3779B9u; tl_sig ^= tl_sig >> 15; }
+#define SIG_NOTE(ev) sig_note((uint32_t)(ev))
+static uint32_t g_ens_seed = 0; /* 0 = off */
+static int g_ens_amp = 0;
+static const int ens_allow[7] = { 2, 2, 2, 4, 4, 4, 16 }; /* (= wit_ulps below: rcp, rsqrt, sqrt, sin, cos, exp, pow5) */
+static inline uint32_t ens_hash(uint32_t a, uint32_t b)
+{
+    uint32_t h = (g_ens_seed ^ (a * 0x9E3779B9u)) + b * 0x85EBCA6Bu;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
 static inline float perturbed(int prim, float y)
 {
     const int n = tl_call_n[prim]++;
     for (int t = 0; t < g_tn; t++)
         if (prim == g_tprim[t] && n == g_tcall[t]) return ulp_shift(y, g_tulps[t]);
+    if (g_ens_seed != 0 && prim < 7) {
+        uint32_t u; memcpy(&u, &y, 4);
+        const int a = g_ens_amp < ens_allow[prim] ? g_ens_amp : ens_allow[prim];
+        return ulp_shift(y, (int)(ens_hash((uint32_t)prim, u) % (uint32_t)(2 * a + 1)) - a);
+    }
     if (prim != g_perturb_prim || g_perturb_ulps == 0) return y;
     return ulp_shift(y, g_perturb_ulps);
 }
-static inline int decide(int cond, float diff, float scale)
+static inline int decide_at(int cond, float diff, float scale, int line)
 {
     const int k = tl_dec_n++;
     if (g_record_gap > 0.0f) {
         const float gap = fabsf(diff) / fmaxf(fabsf(scale), 1e-30f);
-        if (gap < g_record_gap && tl_close_n < WIT_MAX_CLOSE) { tl_close[tl_close_n].idx = k; tl_close[tl_close_n].gap = gap; tl_close_n++; }
+        if (gap < g_record_gap && tl_close_n < WIT_MAX_CLOSE) { tl_close[tl_close_n].idx = k; tl_close[tl_close_n].gap = gap; tl_close[tl_close_n].line = line; tl_close[tl_close_n].diff = diff; tl_close_n++; }
     }
+    /* an ensemble member decides comparisons ON A NaN for itself (GLSL 4.60 section 4.7.1: "operations and built-in functions that operate on
+       a NaN are not required to return a NaN", min / max of a NaN are undefined: after refract() = 0 -> normalize(0) the ray is NaN and
+       whether it "hits" a slab is the implementation's choice; llvmpipe's misses everything and looks the environment up at NaN) */
+    if (diff != diff) tl_ub = 1;
+    if (g_ens_seed != 0 && diff != diff) return (int)(ens_hash(200u + (uint32_t)(k & 15), 0u) >> 31);
     return (k == g_flip_at[0] || k == g_flip_at[1] || k == g_flip_at[2]) ? !cond : cond;
 }
-#define DECIDE(cond, diff, scale) decide((cond), (diff), (scale))
+#define DECIDE(cond, diff, scale) decide_at((cond), (diff), (scale), __LINE__)
 /* "primitive" 7: a * b + c.  GLSL lets an implementation fuse it or not; the contract fuses where this file says fmaf, llvmpipe never
  * does.  A targeted site (any non-zero shift) evaluates that ONE multiply-add the other way; pto_set_unfused(1) all of them (outside
  * the primitives above, whose own Newton steps are part of their definition). */
@@ -130,6 +161,10 @@ static inline float wit_fma(float a, float b, float c)
 {
     const int n = tl_call_n[7]++;
     int unfused = g_unfuse_all;
+    if (g_ens_seed != 0) { /* this member fuses about half of the multiply-adds: a fixed function of the operands */
+        uint32_t ua, ub, uc; memcpy(&ua, &a, 4); memcpy(&ub, &b, 4); memcpy(&uc, &c, 4);
+        unfused = (int)(ens_hash(7u + ua, ub ^ (uc * 0xC2B2AE35u)) >> 31);
+    }
     for (int t = 0; t < g_tn; t++)
         if (g_tprim[t] == 7 && n == g_tcall[t] && g_tulps[t] != 0) unfused = !unfused;
     if (unfused) { const float m = a * b; return m + c; } /* (-ffp-contract=off: two roundings) */
@@ -145,7 +180,12 @@ static inline int wit_targeted(int prim)
         if (g_tprim[t] == prim && n == g_tcall[t] && g_tulps[t] != 0) return 1;
     return 0;
 }
-static inline float wit_quot(float a, float b, float rb) { return (wit_targeted(8) != 0) != (g_base_truediv != 0) ? a / b : a * rb; }
+static inline float wit_quot(float a, float b, float rb)
+{
+    int literal = (wit_targeted(8) != 0) != (g_base_truediv != 0);
+    if (g_ens_seed != 0) { uint32_t ua, ub; memcpy(&ua, &a, 4); memcpy(&ub, &b, 4); literal = (int)(ens_hash(8u + ua, ub) >> 31); }
+    return literal ? a / b : a * rb;
+}
 #define QUOT(a, b, rb) wit_quot((a), (b), (rb))
 #define MIX_OTHER_FORM() wit_targeted(9)
 #else
@@ -153,6 +193,7 @@ static inline float wit_quot(float a, float b, float rb) { return (wit_targeted(
 #define MIX_OTHER_FORM() 0
 #define perturbed(prim, y) (y)
 #define DECIDE(cond, diff, scale) (cond)
+#define SIG_NOTE(ev) ((void)0)
 #endif
 /* pt-f32 reciprocal: seed by exponent negation, three Newton steps; zero and denormals give +-inf */
 static inline float f_rcp(float x)
@@ -285,6 +326,12 @@ static inline float f_pow5(float x) /* (GLSL: pow(x, 5.0) — llvmpipe's is ~22 
 #ifdef PT_ORACLE_PERTURB
     /* pow(x, y) is undefined for x < 0 (GLSL 4.60 section 8.2); llvmpipe's exp2(y log2 x) is NaN.  Mode 2: also for a base within four
        ulps of 1 - cos = 0 — whether 1 - dot(-d, n) of two unit vectors comes out as +-1e-7 or 0 is the last bit of the dot product */
+    if (x < 4.8e-7f) tl_ub = 1;
+    if (g_ens_seed != 0) { /* an ensemble member: a negative base is NaN for two members in three; a base within four ulps of zero is one
+                              whose sign the member's own last bits decide — NaN for about half of such calls (by call, not by value:
+                              the same 1 - cos comes out of different dot products) */
+        if (x < 0.0f ? g_pow_neg_nan != 0 : (x < 4.8e-7f && (ens_hash(60u, (uint32_t)tl_call_n[6]) >> 31))) { tl_call_n[6]++; return NAN; }
+    } else
     if (g_pow_neg_nan && (x < 0.0f || (g_pow_neg_nan == 2 && x < 4.8e-7f))) return NAN;
 #endif
     float x2 = x * x;
@@ -710,6 +757,7 @@ static int ray_trace(const Ctx *c, v3 o, v3 d, HitInfo *h, Stats *st)
     if (winner < 0 || !(T != FLOAT_MAX)) return 0; /* compute.glsl:257 */
     h->T = T;
     h->fromInside = (T == wt2);
+    SIG_NOTE(0x1000 + winner * 2 + h->fromInside);
     h->nearHitPos = v_fma(d, T, o);
     if (winner < 256) {
         const float *s = ob + (size_t)winner * SPHERE_STRIDE;
@@ -800,15 +848,18 @@ static float bsdf(v3 *ro, v3 *rd, const HitInfo *h, int *isRefractive, uint32_t 
         v3 refl = f_reflect(*rd, h->normal);
         *rd = v_normalize(v_mix(refl, diffuseRay, h->m.specularRoughness * h->m.specularRoughness));
         prob = spec;
+        SIG_NOTE(0x2001);
     } else if (DECIDE(spec + refr > roll, spec + refr - roll, 1.0f)) {
         v3 rf = f_refract(*rd, h->normal, h->fromInside ? h->m.ior : f_rcp(h->m.ior));
         v3 rough = cosine_sample_hemisphere(v_neg(h->normal), seed);
         *rd = v_normalize(v_mix(rf, rough, h->m.refractionRoughness * h->m.refractionRoughness));
         prob = refr;
         *isRefractive = 1;
+        SIG_NOTE(0x2002);
     } else {
         *rd = diffuseRay;
         prob = 1.0f - spec - refr;
+        SIG_NOTE(0x2000);
     }
     *ro = v_fma(*rd, EPSILON, h->nearHitPos);
     return f_max(prob, EPSILON);
@@ -869,13 +920,14 @@ static v3 radiance(const Ctx *c, v3 ro, v3 rd, uint32_t *seed, Stats *st)
             }
 #endif
             const float rr_ = rand01(seed);
-            if (DECIDE(rr_ > p, rr_ - p, f_max(p, 1.0f))) break;
+            if (DECIDE(rr_ > p, rr_ - p, f_max(p, 1.0f))) { SIG_NOTE(0x3001); break; }
             {
                 const float rp = f_rcp(p);
                 throughput = V(QUOT(throughput.x, p, rp), QUOT(throughput.y, p, rp), QUOT(throughput.z, p, rp));
             }
         } else {
             rgb e = sample_env(c, rd);
+            SIG_NOTE(0x3002);
             if (st) st->envLookups++;
 #ifdef PT_ORACLE_MARGINS
             { /* no flip, still an error: the environment's change over the direction's error (finite differences along two tangents,
@@ -916,6 +968,8 @@ static void shade_pixel(const Ctx *c, int px, int py, int frame, const float *la
     v3 irr = V(0.0f, 0.0f, 0.0f);
 #ifdef PT_ORACLE_PERTURB
     tl_dec_n = 0; tl_close_n = 0; tl_nan_env = 0;
+    tl_sig = g_sig_alpha ? (f_bits(last[3]) & 0x7FFFFFu) : 0u; /* (chained over the frames of an accumulation) */
+    tl_ub = 0;
     memset(tl_call_n, 0, sizeof tl_call_n);
 #endif
     for (int s = 0; s < c->spp; s++) {
@@ -954,6 +1008,10 @@ static void shade_pixel(const Ctx *c, int px, int py, int frame, const float *la
     out[1] = f_mix(last[1], irr.y, w);
     out[2] = f_mix(last[2], irr.z, w);
     out[3] = 1.0f; /* :129 */
+#ifdef PT_ORACLE_PERTURB
+    if (tl_ub || tl_nan_env) sig_note(0xDEAD0000u ^ g_ens_seed ^ 0x5bd1e995u); /* undefined behaviour on the way: no two implementations "follow the same path" */
+    if (g_sig_alpha) out[3] = f_unbits(0x3F800000u | (tl_sig & 0x7FFFFFu)); /* a float in [1, 2): 23 bits of the signature, survives copies */
+#endif
 }
 
 /* ------------------------------------------------------------------ public C API (ctypes) */
@@ -1226,6 +1284,66 @@ PTO_API int pto_set_base_variant(int bits)
     return 0;
 #else
     (void)bits;
+    return -1;
+#endif
+}
+
+/* witness build: 1 = the alpha channel of every rendered pixel carries 23 bits of its PATH SIGNATURE (a hash of which object each bounce
+ * hit and from which side, which lobe it took and how the path ended, over the samples of the pixel and — through the previous alpha —
+ * the frames accumulated so far) instead of 1.0; 0 = the reference's alpha again.  Two implementations whose pixel has the same
+ * signature followed the same path through the scene, whatever their colours are. */
+PTO_API int pto_set_signature_alpha(int on)
+{
+#ifdef PT_ORACLE_PERTURB
+    g_sig_alpha = on != 0;
+    return 0;
+#else
+    (void)on;
+    return -1;
+#endif
+}
+
+/* witness build, diagnostic: the comparisons of pixel (x, y) whose operands are closer than closeGap (relative to their scale), in path
+ * order: out4[4 k] = decision index, [4 k + 1] = source line of the DECIDE site in this file, [4 k + 2] = relative gap, [4 k + 3] = a - b.
+ * Returns how many (at most cap), -1 in builds without the hooks. */
+PTO_API int pto_list_close_decisions(const PtoParams *p, const float *basic144, const float *objects26624, const void *env,
+                                     int x, int y, int frame, const float *last4, float closeGap, int cap, float *out4)
+{
+#ifdef PT_ORACLE_PERTURB
+    Ctx c;
+    float v[4];
+    make_ctx(&c, p, basic144, objects26624, env);
+    g_record_gap = closeGap;
+    shade_pixel(&c, x, y, frame, last4, v, NULL);
+    g_record_gap = 0.0f;
+    const int n = tl_close_n < cap ? tl_close_n : cap;
+    for (int k = 0; k < n; k++) {
+        out4[4 * k] = (float)tl_close[k].idx; out4[4 * k + 1] = (float)tl_close[k].line;
+        out4[4 * k + 2] = tl_close[k].gap; out4[4 * k + 3] = tl_close[k].diff;
+    }
+    return n;
+#else
+    (void)p; (void)basic144; (void)objects26624; (void)env; (void)x; (void)y; (void)frame; (void)last4; (void)closeGap; (void)cap; (void)out4;
+    return -1;
+#endif
+}
+
+/* witness build: the library becomes ensemble member `seed` (0: the contract / the base variant again): every primitive call up to
+ * min(amplitude, its allowance) ulps off, every multiply-add fused or not, every division literal or by reciprocal — each a fixed
+ * pseudo-random function of the member and the operands (see ens_hash).  Thread-safe to render with; set while nothing renders. */
+PTO_API int pto_set_ensemble(unsigned seed, int amplitude)
+{
+#ifdef PT_ORACLE_PERTURB
+    g_ens_seed = seed;
+    g_ens_amp = amplitude < 0 ? 0 : amplitude;
+    /* what GLSL / GL leave UNDEFINED a member also chooses for itself: pow(x, 5) of a negative base (and, every third member, of a base
+       within four ulps of zero: the last bit of 1 - dot(-d, n)) is NaN or the product; texture(env, NaN direction) is some colour */
+    g_pow_neg_nan = seed == 0 ? 0 : (int)(seed % 3u);
+    g_nan_env_set = seed != 0;
+    for (int ch = 0; ch < 3; ch++) g_nan_env[ch] = (float)(ens_hash(100u + (uint32_t)ch, 0u) >> 8) * (1.0f / 16777216.0f);
+    return 0;
+#else
+    (void)seed; (void)amplitude;
     return -1;
 #endif
 }

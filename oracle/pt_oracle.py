@@ -113,6 +113,20 @@ class Oracle:
         rounded 1/x, sqrt, 1/sqrt, 4 literal divisions; 7 = llvmpipe's choices, 0 = the contract."""
         assert self.lib.pto_set_base_variant(int(bits)) == 0, "this oracle build has no witness hooks (Oracle(perturb=True))"
 
+    def set_ensemble(self, seed: int, amplitude: int = 16) -> None:
+        """Oracle(perturb=True) only: the library becomes ensemble member `seed` (0: off) — ONE conforming implementation that differs from the
+        contract everywhere at once: every primitive call up to min(amplitude, its allowance) ulps off, every multiply-add fused or not, every
+        division literal or by reciprocal, each a fixed function of the member and the operands (pt_oracle.c, ens_hash)."""
+        if not hasattr(self.lib.pto_set_ensemble, "_typed"):
+            self.lib.pto_set_ensemble.restype = C.c_int
+            self.lib.pto_set_ensemble.argtypes = [C.c_uint, C.c_int]
+        assert self.lib.pto_set_ensemble(int(seed) & 0xFFFFFFFF, int(amplitude)) == 0, "this oracle build has no witness hooks (Oracle(perturb=True))"
+
+    def set_signature_alpha(self, on: bool) -> None:
+        """Oracle(perturb=True) only: alpha = 23 bits of the pixel's path signature (objects hit, lobes taken, how each path ended; chained
+        over samples and accumulated frames) as a float in [1, 2) instead of 1.0."""
+        assert self.lib.pto_set_signature_alpha(int(on)) == 0, "this oracle build has no witness hooks (Oracle(perturb=True))"
+
     def set_nan_env(self, rgb) -> None:
         """Oracle(perturb=True) only: what texture(env, NaN direction) returns (None: the contract's clamped lookup)."""
         v = None if rgb is None else np.ascontiguousarray(rgb, np.float32)
