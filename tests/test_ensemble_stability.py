@@ -136,6 +136,22 @@ def test_a_planted_error_is_caught_where_the_pixel_is_certified(members):
     assert caught / total >= 0.93   # = the certified share of these two fixtures (98.8 %, 95.4 %) minus pixels the error happens to leave inside
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["frame_default_128x72_d8", "frame_stress256_128x72_d8", "frame_edge_128x72_d16"])
+def test_gpu_every_certified_pixel_is_inside_the_band_of_the_reference(pkg, native_lib, members, name):
+    """The same statement on the GPU's own images (the HIP path renders the contract's bits: shown here, not assumed)."""
+    fx = fixtures.load(name)
+    base, certified, _, _ = certify(members, fx, False)
+    hip = fixtures.hip_frames(pkg, fx)
+    band = tol.SRGB_REL_TOL if fx["env"].dtype == np.uint8 else tol.REL_TOL
+    for k in range(base.shape[0]):
+        same = (hip[k].view(np.uint32) == base[k][..., :3].view(np.uint32)) | (np.isnan(hip[k]) & np.isnan(base[k][..., :3]))  # (NaN payloads may differ)
+        assert same.all()
+        d_ref = _band_distance(fx["expected"][k], hip[k], band)
+        assert not ((d_ref > 1.0) & certified[k]).any()
+        assert certified[k].mean() >= MIN_SHARE
+
+
 def test_report():
     """(prints the table; run with -s)"""
     print("\nensemble stability: dump | outside the band | certified share | largest distance of a certified pixel (bands) | in-band share: contract, members min .. max")
