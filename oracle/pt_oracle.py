@@ -133,7 +133,7 @@ class Oracle:
         assert self.lib.pto_set_nan_env(None if v is None else _ptr(v)) == 0, "this oracle build has no witness hooks (Oracle(perturb=True))"
 
     def witness_search(self, width, height, basic_ubo, objects_ubo, env_faces, xy, ref, band, *, num_spheres, num_cuboids, ray_depth, spp=1,
-                       focal_length=20.0, aperture=0.14, frame=0, last=None, close_gap=1e-2, max_flips=256):
+                       focal_length=20.0, aperture=0.14, frame=0, last=None, close_gap=1e-6, max_flips=256):
         """Oracle(perturb=True) only.  For every listed pixel: a conforming neighbour of the contract — one comparison inverted, one call of
         one primitive a few ulps off, a pair of inverted comparisons, or several calls a few ulps off — that lands inside
         band * max(1, |ref|) of `ref` (n x 3); see pto_witness_search.  Returns a list of dicts: kind (0 = none, 1 .. 5, 9 = a neighbour
