@@ -264,7 +264,24 @@ static inline v3 v_scale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
 static inline v3 v_neg(v3 a) { return V(-a.x, -a.y, -a.z); }
 /* a + b*s, fused */
 static inline v3 v_fma(v3 b, float s, v3 a) { return V(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z)); }
+#ifdef PT_ORACLE_PERTURB
+/* an ensemble member also sums the three products of a dot product in an order of its own (GLSL does not fix one): a fixed function of
+   the member and the operands */
+static inline float v_dot(v3 a, v3 b)
+{
+    if (g_ens_seed != 0) {
+        uint32_t ua, ub; memcpy(&ua, &a.x, 4); memcpy(&ub, &b.y, 4);
+        switch (ens_hash(11u + ua, ub) % 3u) {
+        case 1: return fmaf(a.x, b.x, fmaf(a.z, b.z, a.y * b.y));
+        case 2: return fmaf(a.y, b.y, fmaf(a.x, b.x, a.z * b.z));
+        default: break;
+        }
+    }
+    return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x));
+}
+#else
 static inline float v_dot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+#endif
 static inline v3 v_normalize(v3 a) { return v_scale(a, f_rsqrt(v_dot(a, a))); }
 static inline v3 v_mix(v3 x, v3 y, float a)
 {
@@ -957,6 +974,20 @@ static v3 radiance(const Ctx *c, v3 ro, v3 rd, uint32_t *seed, Stats *st)
 /* GLSL mat4 * vec4 with the column-major view of the UBO bytes */
 static void mat_vec(const float *m, float x, float y, float z, float w, float *out)
 {
+#ifdef PT_ORACLE_PERTURB
+    if (g_ens_seed != 0) { /* (an ensemble member's own order of the four column terms, per product) */
+        uint32_t ux, uy; memcpy(&ux, &x, 4); memcpy(&uy, &y, 4);
+        const uint32_t order = ens_hash(12u + ux, uy) % 4u;
+        for (int r = 0; r < 4; r++) {
+            const float cx = m[r], cy = m[4 + r], cz = m[8 + r], cw = m[12 + r];
+            out[r] = order == 1 ? fmaf(cx, x, fmaf(cy, y, fmaf(cz, z, cw * w)))        /* w first */
+                   : order == 2 ? (fmaf(cy, y, cx * x)) + (fmaf(cw, w, cz * z))         /* pairwise */
+                   : order == 3 ? fmaf(cz, z, fmaf(cw, w, fmaf(cy, y, cx * x)))
+                   : fmaf(cw, w, fmaf(cz, z, fmaf(cy, y, cx * x)));
+        }
+        return;
+    }
+#endif
     for (int r = 0; r < 4; r++)
         out[r] = fmaf(m[12 + r], w, fmaf(m[8 + r], z, fmaf(m[4 + r], y, m[r] * x)));
 }

@@ -1,0 +1,109 @@
+"""Layer-2 fuzzing with the ensemble certificate as the discriminator (BUILD CONTAINER ONLY: runs the reference's own GLSL live on Mesa
+llvmpipe through oracle/_ref/glsl_runner; reads the shader text from /root/reference at run time).
+
+The committed fixtures are 17 scenes.  This tool draws random ones — sphere / cuboid counts from 0 to the UBO's limits, sizes from tiny to
+huge, nested and overlapping objects, random materials incl. glass, cameras inside objects, lens, depth, spp, both environment formats —
+renders each with the reference, the contract and eight ensemble members (tests/test_ensemble_stability.py), and checks the same
+statement: EVERY certified pixel lies inside the band of the reference.  An exception is a discrepancy that last-bit arithmetic does not
+explain, i.e. a candidate semantic difference between the oracle (and with it the HIP path) and the reference: it is printed with
+everything needed to replay it.
+
+    python tools/ensemble_fuzz.py [cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle", "glsl_ref")]
+import __graft_entry__ as g  # noqa: E402
+import run as ref            # noqa: E402
+import tolerances as tol     # noqa: E402
+import test_ensemble_stability as ens  # noqa: E402
+
+pkg = g.load_package()
+S = pkg.scene
+F = np.float32
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+members = g.load_oracle().Oracle(perturb=True)
+assert ref.available(), "needs oracle/_ref/glsl_runner and /root/reference (build container)"
+
+
+def rand_material():
+    kind = rng.randint(5)
+    if kind == 0:
+        return S.Material(albedo=rng.rand(3), emissiv=rng.rand(3) * (rng.rand() < 0.3) * 3)
+    if kind == 1:
+        return S.Material(albedo=rng.rand(3), specular_chance=rng.rand(), specular_roughness=rng.rand() * (rng.rand() < 0.7))
+    if kind == 2:
+        return S.Material(albedo=S.vec3(1.0), absorbance=rng.rand(3) * 2, specular_chance=0.02 + 0.1 * rng.rand(), ior=1.0 + rng.rand(),
+                          refraction_chance=0.9 * rng.rand(), refraction_roughness=rng.rand() * (rng.rand() < 0.5))
+    return S.Material(albedo=rng.rand(3), specular_chance=rng.rand() * 0.5, specular_roughness=rng.rand(), ior=1 + rng.rand(),
+                      refraction_chance=rng.rand() * 0.5, refraction_roughness=rng.rand(), absorbance=rng.rand(3))
+
+
+def rand_scene():
+    kind = rng.randint(4)
+    if kind == 0:
+        return S.default_scene()
+    if kind == 1:
+        return S.glass_scene()
+    sc = S.Scene()
+    ns, nc = int(rng.choice([0, 1, 3, 17, 48, 100, 256])), int(rng.choice([0, 1, 7, 20, 64]))
+    scale = float(rng.choice([0.05, 0.6, 2.0, 8.0]))
+    for i in range(ns):
+        sc.spheres.append(S.Sphere(rng.uniform([-18, -11, -20], [18, 11, 0]).astype(F), F(scale * rng.uniform(0.2, 1.5)), i, rand_material()))
+    if rng.rand() < 0.5:
+        sc.cuboids = S.default_cuboids()[:min(nc, 7)]
+    for i in range(len(sc.cuboids), nc):
+        sc.cuboids.append(S.Cuboid(rng.uniform([-18, -11, -20], [18, 11, 0]).astype(F), rng.uniform(0.2, 6.0, 3).astype(F), i, rand_material()))
+    return sc
+
+
+tot = dict(pixels=0, certified=0, outside=0, exceptions=0)
+t0 = time.time()
+for case in range(cases):
+    sc = rand_scene()
+    W, H = int(rng.choice([33, 64, 96, 128])), int(rng.choice([17, 40, 54, 72]))
+    depth, spp = int(rng.choice([1, 2, 5, 8, 8, 20, 32])), int(rng.choice([1, 1, 1, 2, 4]))
+    cam_pos = rng.uniform([-19, -12, -22], [19, 12, 2])
+    if rng.rand() < 0.2 and sc.num_spheres:  # inside (or at the surface of) a sphere
+        sp = sc.spheres[rng.randint(sc.num_spheres)]
+        cam_pos = np.asarray(sp.position, np.float64) + rng.uniform(-1, 1, 3) * abs(float(sp.radius))
+    if rng.rand() < 0.4:
+        cam = pkg.camera.Camera()
+    else:
+        cam = pkg.camera.Camera(position=tuple(float(v) for v in cam_pos), look_x=float(rng.uniform(-180, 180)), look_y=float(rng.uniform(-85, 85)))
+    focal, aperture = float(rng.choice([0.5, 5.0, 20.0, 200.0])), float(rng.choice([0.0, 0.14, 0.14, 2.0]))
+    srgb = rng.rand() < 0.25
+    env = pkg.envmap.synthetic_sky_srgb8(16) if srgb else pkg.envmap.synthetic_sky_rgba32f(int(rng.choice([16, 64])))
+    basic = pkg.camera.basic_data_ubo(cam, W, H)
+    kw = dict(num_spheres=sc.num_spheres, num_cuboids=sc.num_cuboids, ray_depth=depth, spp=spp, focal_length=focal, aperture=aperture)
+    fx = dict(width=W, height=H, basic=basic, objects=sc.ubo_bytes(), env=env, frames=1, frame_indices=[0], params=None)
+    desc = f"case {case}: ns={sc.num_spheres} nc={sc.num_cuboids} {W}x{H} depth={depth} spp={spp} focal={focal} aperture={aperture} env={'srgb8' if srgb else 'rgba32f'}{env.shape[1]}"
+    expected = ref.run_pathtracer(W, H, basic, sc.ubo_bytes(), env, **kw)[0][..., :3]
+    # (ens.certify goes through fixtures.kwargs(fx): hand it the same keyword set)
+    import fixtures
+    _kwargs = fixtures.kwargs
+    fixtures.kwargs = lambda _fx: kw
+    try:
+        base, certified, spread, _ = ens.certify(members, fx, False)
+    finally:
+        fixtures.kwargs = _kwargs
+    band = tol.SRGB_REL_TOL if srgb else tol.REL_TOL
+    d_ref = ens._band_distance(expected, base[0][..., :3], band)
+    outside = d_ref > 1.0
+    bad = np.argwhere(outside & certified[0])
+    tot["pixels"] += outside.size; tot["certified"] += int(certified[0].sum()); tot["outside"] += int(outside.sum()); tot["exceptions"] += len(bad)
+    print(f"{desc}: outside {int(outside.sum())} certified {certified[0].mean():.2%} exceptions {len(bad)}", flush=True)
+    for y, x in bad[:5]:
+        print(f"    EXCEPTION pixel ({x}, {y}): reference {expected[y, x]} contract {base[0][y, x, :3]} ({d_ref[y, x]:.1f} bands), members' spread {spread[0][y, x]:.3f}")
+    if len(bad):
+        os.makedirs(os.path.join(ROOT, "gpurun_out", "ensemble_fuzz"), exist_ok=True)
+        np.savez(os.path.join(ROOT, "gpurun_out", "ensemble_fuzz", f"case{case}_seed{sys.argv[2] if len(sys.argv) > 2 else 1}.npz"), basic=np.frombuffer(basic, np.uint8),
+                 objects=np.frombuffer(sc.ubo_bytes(), np.uint8), env=env, expected=expected, width=W, height=H, bad=bad, **{k: np.array(v) for k, v in kw.items()})
+print(f"ensemble_fuzz: {cases} cases, {tot['pixels']} pixels, {tot['certified'] / max(1, tot['pixels']):.2%} certified, {tot['outside']} outside the band, "
+      f"{tot['exceptions']} certified pixels outside the band, {time.time() - t0:.0f} s")
+sys.exit(1 if tot["exceptions"] else 0)
