@@ -156,6 +156,7 @@ static int g_unfuse_all = 0, g_pow_neg_nan = 0, g_nan_env_set = 0;
  * arithmetic differs from it everywhere at once (correctly rounded 1/x, sqrt, 1/sqrt; the literal a / b; never fused), and a pixel that
  * amplifies is closer to the reference's value from a base that shares those than from the contract */
 static int g_base_exact = 0, g_base_truediv = 0;
+static int g_base_matvec = 0, g_base_dot = 0; /* (base variants, bits 8 / 16 and 32 / 64: the order in which matrix-vector and dot products sum their terms) */
 static float g_nan_env[3]; /* what texture(env, NaN direction) returns instead of the contract's clamped lookup (pto_set_nan_env) */
 static inline float wit_fma(float a, float b, float c)
 {
@@ -269,9 +270,9 @@ static inline v3 v_fma(v3 b, float s, v3 a) { return V(fmaf(b.x, s, a.x), fmaf(b
    the member and the operands */
 static inline float v_dot(v3 a, v3 b)
 {
-    if (g_ens_seed != 0) {
+    if (g_ens_seed != 0 || g_base_dot != 0) {
         uint32_t ua, ub; memcpy(&ua, &a.x, 4); memcpy(&ub, &b.y, 4);
-        switch (ens_hash(11u + ua, ub) % 3u) {
+        switch (g_ens_seed != 0 ? ens_hash(11u + ua, ub) % 3u : (uint32_t)g_base_dot) {
         case 1: return fmaf(a.x, b.x, fmaf(a.z, b.z, a.y * b.y));
         case 2: return fmaf(a.y, b.y, fmaf(a.x, b.x, a.z * b.z));
         default: break;
@@ -975,9 +976,9 @@ static v3 radiance(const Ctx *c, v3 ro, v3 rd, uint32_t *seed, Stats *st)
 static void mat_vec(const float *m, float x, float y, float z, float w, float *out)
 {
 #ifdef PT_ORACLE_PERTURB
-    if (g_ens_seed != 0) { /* (an ensemble member's own order of the four column terms, per product) */
+    if (g_ens_seed != 0 || g_base_matvec != 0) { /* (an ensemble member's own order of the four column terms, per product) */
         uint32_t ux, uy; memcpy(&ux, &x, 4); memcpy(&uy, &y, 4);
-        const uint32_t order = ens_hash(12u + ux, uy) % 4u;
+        const uint32_t order = g_ens_seed != 0 ? ens_hash(12u + ux, uy) % 4u : (uint32_t)g_base_matvec;
         for (int r = 0; r < 4; r++) {
             const float cx = m[r], cy = m[4 + r], cz = m[8 + r], cw = m[12 + r];
             out[r] = order == 1 ? fmaf(cx, x, fmaf(cy, y, fmaf(cz, z, cw * w)))        /* w first */
@@ -1312,6 +1313,8 @@ PTO_API int pto_set_base_variant(int bits)
     g_unfuse_all = (bits & 1) != 0;
     g_base_exact = (bits & 2) != 0;
     g_base_truediv = (bits & 4) != 0;
+    g_base_matvec = (bits >> 3) & 3; /* 0 = the contract's x, y, z, w chain; 1 = w first; 2 = pairwise (x + y) + (z + w); 3 = x, y, w, z */
+    g_base_dot = (bits >> 5) & 3;    /* 0 = the contract's x, y, z chain; 1 = y, z, x; 2 = z, x, y */
     return 0;
 #else
     (void)bits;
