@@ -64,3 +64,23 @@ def test_llvmpipes_arithmetic_choices_close_two_thirds_of_the_gap(variants):
     assert n > 150000 and 600 <= contract <= 900          # (measured 787)
     assert orders_only <= contract                         # (743: the order alone helps a little under fused arithmetic)
     assert llvmpipe <= 0.45 * contract                     # (271 = 0.34 x)
+
+
+@pytest.mark.parametrize("name", fixtures.names("atmo_"))
+def test_the_atmosphere_cubes_band_is_the_same_named_choices(variants, name):
+    """The atmosphere precompute (AtmosphericScattering/compute.glsl) has no branching on random numbers: its distance from
+    the reference's cube is arithmetic only.  Contract: largest per-texel error 1.5e-4 ... 3.5e-4, median 4e-6, 97.8 - 99.9 % of the texels
+    within 1e-4 (the frozen marks of tests/tolerances.py).  With llvmpipe's choices — never fused + correctly rounded 1/x, sqrt — the SAME
+    restatement is within 9e-5 EVERYWHERE, median 1.4e-7: the band the atmosphere needs is those two choices (what remains is llvmpipe's
+    exp, ~16 ulps, over 750 accumulation steps).  Either choice alone does not do it (never fused: 1.5e-4 ... 2.2e-4; exact roots: unchanged)."""
+    fx = fixtures.load(name)
+    size, isteps, jsteps = (int(v) for v in fx["params"])
+    err = {}
+    for bits in (0, LLVMPIPE):
+        variants.set_base_variant(bits)
+        got = variants.atmosphere(size, fx["ubo"].tobytes(), fx["light_pos"], float(fx["intensity"]), isteps, jsteps)[..., :3]
+        err[bits] = tol.atmo_error(fx["expected"], got)
+    variants.set_base_variant(0)
+    assert err[LLVMPIPE].max() <= 1e-4, f"{name}: {err[LLVMPIPE].max():.3g}"
+    assert err[LLVMPIPE].max() <= 0.6 * err[0].max()
+    assert np.median(err[LLVMPIPE]) <= 1e-6 or np.median(err[0]) == 0.0
