@@ -298,8 +298,90 @@ static inline float f_from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return
 
 /* sin and cos of a (radians), |a| small (the integrator only passes [0, 2*pi]).  Cody-Waite reduction by pi/2
  * with two fused steps, then the classic single-precision minimax polynomials on [-pi/4, pi/4]. */
+#ifdef PT_ORACLE_PERTURB
+/* base variant bit 128: sin, cos, exp, pow the way llvmpipe's gallivm evaluates them (Mesa, src/gallium/auxiliary/gallivm/lp_bld_arit.c —
+ * a third-party dependency of the REFERENCE'S TEST RIG, absent from /root/reference; restated from its published algorithm and pinned by
+ * black-box probing: tests/test_arithmetic_choices.py runs the GLSL built-ins on the live llvmpipe through oracle/_ref/glsl_runner and
+ * finds these functions BIT-IDENTICAL on 65,536 arguments each).  sin / cos: the Cephes-derived SSE routine (reduction by pi/4 in three
+ * steps, j = (int(|x| 4/pi) + 1) & ~1, two minimax polynomials, multiply-adds fused).  exp2: floor / fraction split, degree-5 polynomial of
+ * the fraction evaluated as even and odd halves with fused multiply-adds, scaled by 2^floor.  log2: exponent + y P(y^2) with
+ * y = (m - 1) / (m + 1), degree-4 P, same evaluation.  exp(x) = exp2(x log2 e), pow(x, y) = exp2(log2(x) y): negative base NaN, zero 0. */
+static int g_base_llvm_math = 0;
+static inline float ll_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+static float ll_poly(float x, const float *co, int n) /* lp_build_polynomial: even and odd powers separately, then odd * x + even */
+{
+    const float x2 = x * x;
+    float even = 0.0f, odd = 0.0f;
+    int haveEven = 0, haveOdd = 0;
+    for (int i = n; i--;) {
+        if ((i & 1) == 0) { even = haveEven ? ll_fma(x2, even, co[i]) : co[i]; haveEven = 1; }
+        else { odd = haveOdd ? ll_fma(x2, odd, co[i]) : co[i]; haveOdd = 1; }
+    }
+    return haveOdd ? ll_fma(odd, x, even) : even;
+}
+static float ll_exp2(float x)
+{
+    static const float co[6] = { 1.000000000000000000000f, 0.693153073200168932794f, 0.240153617044375388211f, 0.0558263180532956664775f,
+                                 0.00898934009049466391101f, 0.00187757667519147912699f };
+    if (x != x) return x;
+    if (x > 128.0f) x = 128.0f;
+    if (x < -126.99999f) x = -126.99999f;
+    const float ip = floorf(x), fp = x - ip;
+    return f_unbits((uint32_t)((int)ip + 127) << 23) * ll_poly(fp, co, 6);
+}
+static float ll_log2(float x)
+{
+    static const float co[5] = { 2.88539009343309178325f, 0.961791550404184197881f, 0.577440339438736392009f, 0.403343858251329912514f,
+                                 0.406718052498846252698f };
+    if (x != x || x < 0.0f) return NAN;
+    if (x == 0.0f) return -INFINITY;
+    if (isinf(x)) return x;
+    const uint32_t i = f_bits(x);
+    const float e = (float)((int)((i >> 23) & 0xffu) - 127);
+    const float m = f_unbits((i & 0x007fffffu) | 0x3f800000u);
+    const float y = (m - 1.0f) / (m + 1.0f);
+    return ll_fma(y, ll_poly(y * y, co, 5), e);
+}
+static float ll_exp(float x) { return ll_exp2(x * 1.44269504088896340735992f); }
+static float ll_pow(float x, float y)
+{
+    if (x != x) return 0.0f; /* (measured: pow(NaN, 5.0) = 0 on llvmpipe) */
+    if (x == 0.0f) return 0.0f;
+    return ll_exp2(ll_log2(x) * y);
+}
+static float ll_sin_or_cos(float a, int want_cos)
+{
+    const float x_abs = fabsf(a);
+    int j = (int)(x_abs * 1.27323954473516f);
+    j = (j + 1) & ~1;
+    const float y = (float)j;
+    const int j2 = want_cos ? j - 2 : j;
+    const uint32_t sign = want_cos ? ((~(uint32_t)j2 & 4u) << 29) : ((((uint32_t)j2 & 4u) << 29) ^ (f_bits(a) & 0x80000000u));
+    float x = ll_fma(y, -0.78515625f, x_abs);
+    x = ll_fma(y, -2.4187564849853515625e-4f, x);
+    x = ll_fma(y, -3.77489497744594108e-8f, x);
+    const float z = x * x;
+    float c = ll_fma(z, 2.443315711809948E-005f, -1.388731625493765E-003f);
+    c = ll_fma(c, z, 4.166664568298827E-002f);
+    c = c * z; c = c * z;
+    c = ll_fma(z, -0.5f, c); c = c + 1.0f;
+    float sv = ll_fma(z, -1.9515295891E-4f, 8.3321608736E-3f);
+    sv = ll_fma(sv, z, -1.6666654611E-1f);
+    sv = sv * z;
+    sv = ll_fma(sv, x, x);
+    return f_unbits(f_bits((j2 & 2) == 0 ? sv : c) ^ sign);
+}
+/* (exported for the probe test: the four functions on arrays) */
+#endif
 static void f_sincos(float a, float *sn, float *cs)
 {
+#ifdef PT_ORACLE_PERTURB
+    if (g_base_llvm_math) {
+        *sn = perturbed(3, ll_sin_or_cos(a, 0));
+        *cs = perturbed(4, ll_sin_or_cos(a, 1));
+        return;
+    }
+#endif
     float k = rintf(a * 0.636619772f);
     float r = fmaf(k, -1.57079637050628662109375f, a);
     r = fmaf(k, 4.37113900018624283e-8f, r);
@@ -321,6 +403,9 @@ static void f_sincos(float a, float *sn, float *cs)
  * power-of-two factors so that denormal results are rounded once. */
 static float f_exp(float x)
 {
+#ifdef PT_ORACLE_PERTURB
+    if (g_base_llvm_math) return perturbed(5, ll_exp(x));
+#endif
     if (x != x) return x;
     if (x > 88.72283935546875f) return INFINITY;
     if (x < -104.0f) return 0.0f;
@@ -344,6 +429,7 @@ static inline float f_pow5(float x) /* (GLSL: pow(x, 5.0) — llvmpipe's is ~22 
 #ifdef PT_ORACLE_PERTURB
     /* pow(x, y) is undefined for x < 0 (GLSL 4.60 section 8.2); llvmpipe's exp2(y log2 x) is NaN.  Mode 2: also for a base within four
        ulps of 1 - cos = 0 — whether 1 - dot(-d, n) of two unit vectors comes out as +-1e-7 or 0 is the last bit of the dot product */
+    if (g_base_llvm_math && g_ens_seed == 0) { if (x < 0.0f) tl_ub = 1; return perturbed(6, ll_pow(x, 5.0f)); }
     if (x < 4.8e-7f) tl_ub = 1;
     if (g_ens_seed != 0) { /* an ensemble member: a negative base is NaN for two members in three; a base within four ulps of zero is one
                               whose sign the member's own last bits decide — NaN for about half of such calls (by call, not by value:
@@ -1315,9 +1401,25 @@ PTO_API int pto_set_base_variant(int bits)
     g_base_truediv = (bits & 4) != 0;
     g_base_matvec = (bits >> 3) & 3; /* 0 = the contract's x, y, z, w chain; 1 = w first; 2 = pairwise (x + y) + (z + w); 3 = x, y, w, z */
     g_base_dot = (bits >> 5) & 3;    /* 0 = the contract's x, y, z chain; 1 = y, z, x; 2 = z, x, y */
+    g_base_llvm_math = (bits >> 7) & 1; /* 128 = sin, cos, exp, pow as llvmpipe's gallivm evaluates them (bit-identical on the probe) */
     return 0;
 #else
     (void)bits;
+    return -1;
+#endif
+}
+
+/* witness build: llvmpipe's built-ins as restated above, on arrays (which: 0 sin, 1 cos, 2 exp, 3 pow(x, y), 4 exp2, 5 log2) — for the
+ * probe test that compares them bit for bit with the live llvmpipe.  Returns -1 in builds without the hooks. */
+PTO_API int pto_llvmpipe_like(int which, const float *x, const float *y, int n, float *out)
+{
+#ifdef PT_ORACLE_PERTURB
+    for (int i = 0; i < n; i++)
+        out[i] = which == 0 ? ll_sin_or_cos(x[i], 0) : which == 1 ? ll_sin_or_cos(x[i], 1) : which == 2 ? ll_exp(x[i])
+               : which == 3 ? ll_pow(x[i], y[i]) : which == 4 ? ll_exp2(x[i]) : ll_log2(x[i]);
+    return 0;
+#else
+    (void)which; (void)x; (void)y; (void)n; (void)out;
     return -1;
 #endif
 }
