@@ -1068,7 +1068,7 @@ static void mat_vec(const float *m, float x, float y, float z, float w, float *o
         for (int r = 0; r < 4; r++) {
             const float cx = m[r], cy = m[4 + r], cz = m[8 + r], cw = m[12 + r];
             out[r] = order == 1 ? fmaf(cx, x, fmaf(cy, y, fmaf(cz, z, cw * w)))        /* w first */
-                   : order == 2 ? (fmaf(cy, y, cx * x)) + (fmaf(cw, w, cz * z))         /* pairwise */
+                   : order == 2 ? fmaf(cy, y, fmaf(cz, z, fmaf(cx, x, cw * w)))        /* ((w + x) + z) + y: llvmpipe's, found by matching its primary rays bit for bit */
                    : order == 3 ? fmaf(cz, z, fmaf(cw, w, fmaf(cy, y, cx * x)))
                    : fmaf(cw, w, fmaf(cz, z, fmaf(cy, y, cx * x)));
         }
@@ -1399,7 +1399,7 @@ PTO_API int pto_set_base_variant(int bits)
     g_unfuse_all = (bits & 1) != 0;
     g_base_exact = (bits & 2) != 0;
     g_base_truediv = (bits & 4) != 0;
-    g_base_matvec = (bits >> 3) & 3; /* 0 = the contract's x, y, z, w chain; 1 = w first; 2 = pairwise (x + y) + (z + w); 3 = x, y, w, z */
+    g_base_matvec = (bits >> 3) & 3; /* 0 = the contract's x, y, z, w chain; 1 = w, z, y, x; 2 = ((w + x) + z) + y, llvmpipe's; 3 = x, y, w, z */
     g_base_dot = (bits >> 5) & 3;    /* 0 = the contract's x, y, z chain; 1 = y, z, x; 2 = z, x, y */
     g_base_llvm_math = (bits >> 7) & 1; /* 128 = sin, cos, exp, pow as llvmpipe's gallivm evaluates them (bit-identical on the probe) */
     return 0;

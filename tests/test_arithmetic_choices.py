@@ -8,12 +8,15 @@ x86: never fused, correctly rounded divps / sqrtps, literal divisions, and — f
 The oracle's witness build can BE that implementation (pto_set_base_variant, bits below), and then it misses a third of the pixels the
 contract misses:
 
-    pixels outside the band, all reference fixtures (179,481 pixel-frames):   contract 787   |   llvmpipe's choices 266 (271 before its sin / cos / exp / pow were restated exactly)
+    pixels outside the band, all reference fixtures (179,481 pixel-frames):   contract 787   |   llvmpipe's choices 145
+    (271 with a translation-first order guessed from the fixtures' statistics and the contract's sin / cos / exp / pow; 266 with llvmpipe's own,
+    restated exactly; 145 with its exact mat4 * vec4 order, ((w + x) + z) + y, found by matching its primary rays BIT FOR BIT: 100.00 % of a frame's
+    origins and directions)
     one choice at a time on top of llvmpipe's summation orders (743):  never fused 593, exact 1/x sqrt 1/sqrt 640, both 282, + literal division 271
 
 (on 600 random scenes of tools/ensemble_fuzz.py, build container only: 11 scenes with undefined behaviour in view — a camera inside a glass
 sphere and the like — hold 8,904 of the 12,995 pixels outside the band and do not move, 8,900; the other 589 scenes go 4,091 -> 2,753)
-i.e. on the reference's own scenes two thirds, on random scenes a third of what separates the contract from the reference is these NAMED, conforming choices (the rest is NOT llvmpipe's exp / pow / sin / cos: restated exactly — bit-identical
+i.e. on the reference's own scenes four fifths, on random scenes (measured with the first guess of the orders) a third of what separates the contract from the reference is these NAMED, conforming choices (the rest is NOT llvmpipe's exp / pow / sin / cos: restated exactly — bit-identical
 with the live llvmpipe, last test — they move 271 to 266; it is the evaluation order of the remaining expressions, the sampler, and chaos).  The contract keeps its choices because the integrator is VALU-issue-bound
 (DESIGN 3.6): unfused multiply-adds and IEEE division / square root (43 / 52 issue cycles on gfx950) would cost a quarter of the speed
 for 0.3 points of agreement with ONE other conforming implementation.  This test pins the measurement."""
@@ -33,8 +36,8 @@ _spec = importlib.util.spec_from_file_location("glsl_run", os.path.join(ROOT, "o
 ref = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(ref)
 
-NEVER_FUSED, EXACT_DIV_SQRT, LITERAL_DIVISION, MATVEC_W_FIRST, DOT_X_PLUS_YZ, LLVM_MATH = 1, 2, 4, 1 << 3, 1 << 5, 1 << 7
-LLVMPIPE = NEVER_FUSED | EXACT_DIV_SQRT | LITERAL_DIVISION | MATVEC_W_FIRST | DOT_X_PLUS_YZ | LLVM_MATH   # (LLVM_MATH: its sin, cos, exp, pow — exact, see the probe below)
+NEVER_FUSED, EXACT_DIV_SQRT, LITERAL_DIVISION, MATVEC_W_FIRST, MATVEC_LLVMPIPE, DOT_X_PLUS_YZ, LLVM_MATH = 1, 2, 4, 1 << 3, 2 << 3, 1 << 5, 1 << 7
+LLVMPIPE = NEVER_FUSED | EXACT_DIV_SQRT | LITERAL_DIVISION | MATVEC_LLVMPIPE | DOT_X_PLUS_YZ | LLVM_MATH   # (LLVM_MATH: its sin, cos, exp, pow — exact, see the probe below)
 
 
 @pytest.fixture(scope="module")
@@ -68,12 +71,12 @@ def outside(o, bits):
 
 def test_llvmpipes_arithmetic_choices_close_two_thirds_of_the_gap(variants):
     contract, n = outside(variants, 0)
-    orders_only, _ = outside(variants, MATVEC_W_FIRST | DOT_X_PLUS_YZ)
+    orders_only, _ = outside(variants, MATVEC_LLVMPIPE | DOT_X_PLUS_YZ)
     llvmpipe, _ = outside(variants, LLVMPIPE)
     print(f"\n  outside the band of {n} pixel-frames: contract {contract}, llvmpipe's summation orders only {orders_only}, all of llvmpipe's choices {llvmpipe}")
     assert n > 150000 and 600 <= contract <= 900          # (measured 787)
     assert orders_only <= contract                         # (743: the order alone helps a little under fused arithmetic)
-    assert llvmpipe <= 0.45 * contract                     # (266 = 0.34 x)
+    assert llvmpipe <= 0.25 * contract                     # (145 = 0.18 x)
 
 
 @pytest.mark.parametrize("name", fixtures.names("atmo_"))
