@@ -156,6 +156,8 @@ static int g_unfuse_all = 0, g_pow_neg_nan = 0, g_nan_env_set = 0;
  * arithmetic differs from it everywhere at once (correctly rounded 1/x, sqrt, 1/sqrt; the literal a / b; never fused), and a pixel that
  * amplifies is closer to the reference's value from a base that shares those than from the contract */
 static int g_base_exact = 0, g_base_truediv = 0;
+static int g_base_sampler_lerp = 0; /* (base variant bit 512) */
+static int g_base_mix_lerp = 0; /* (base variant bit 256: mix(x, y, a) = x + a (y - x), llvmpipe's form — probed: 100 % bit-identical) */
 static int g_base_matvec = 0, g_base_dot = 0; /* (base variants, bits 8 / 16 and 32 / 64: the order in which matrix-vector and dot products sum their terms) */
 static float g_nan_env[3]; /* what texture(env, NaN direction) returns instead of the contract's clamped lookup (pto_set_nan_env) */
 static inline float wit_fma(float a, float b, float c)
@@ -188,7 +190,7 @@ static inline float wit_quot(float a, float b, float rb)
     return literal ? a / b : a * rb;
 }
 #define QUOT(a, b, rb) wit_quot((a), (b), (rb))
-#define MIX_OTHER_FORM() wit_targeted(9)
+#define MIX_OTHER_FORM() ((wit_targeted(9) != 0) != (g_base_mix_lerp != 0))
 #else
 #define QUOT(a, b, rb) ((a) * (rb))
 #define MIX_OTHER_FORM() 0
@@ -636,6 +638,16 @@ static rgb sample_env(const Ctx *c, v3 d)
         w01 = miss01 ? 0.0f : w01 + a; w11 = miss11 ? 0.0f : w11 + a;
     }
     rgb o;
+#ifdef PT_ORACLE_PERTURB
+    if (g_base_sampler_lerp && !(miss00 || miss10 || miss01 || miss11)) { /* base variant bit 512: two nested lerps a + w (b - a), x first (llvmpipe's filter) */
+#define LERP_(a_, b_, w_) ((a_) + (w_) * ((b_) - (a_)))
+        o.r = LERP_(LERP_(t00.r, t10.r, wu), LERP_(t01.r, t11.r, wu), wv);
+        o.g = LERP_(LERP_(t00.g, t10.g, wu), LERP_(t01.g, t11.g, wu), wv);
+        o.b = LERP_(LERP_(t00.b, t10.b, wu), LERP_(t01.b, t11.b, wu), wv);
+#undef LERP_
+        return o;
+    }
+#endif
     o.r = fmaf(t11.r, w11, fmaf(t01.r, w01, fmaf(t10.r, w10, t00.r * w00)));
     o.g = fmaf(t11.g, w11, fmaf(t01.g, w01, fmaf(t10.g, w10, t00.g * w00)));
     o.b = fmaf(t11.b, w11, fmaf(t01.b, w01, fmaf(t10.b, w10, t00.b * w00)));
@@ -1401,6 +1413,8 @@ PTO_API int pto_set_base_variant(int bits)
     g_base_truediv = (bits & 4) != 0;
     g_base_matvec = (bits >> 3) & 3; /* 0 = the contract's x, y, z, w chain; 1 = w, z, y, x; 2 = ((w + x) + z) + y, llvmpipe's; 3 = x, y, w, z */
     g_base_dot = (bits >> 5) & 3;    /* 0 = the contract's x, y, z chain; 1 = y, z, x; 2 = z, x, y */
+    g_base_sampler_lerp = (bits >> 9) & 1;
+    g_base_mix_lerp = (bits >> 8) & 1;
     g_base_llvm_math = (bits >> 7) & 1; /* 128 = sin, cos, exp, pow as llvmpipe's gallivm evaluates them (bit-identical on the probe) */
     return 0;
 #else

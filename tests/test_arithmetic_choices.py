@@ -8,10 +8,11 @@ x86: never fused, correctly rounded divps / sqrtps, literal divisions, and — f
 The oracle's witness build can BE that implementation (pto_set_base_variant, bits below), and then it misses a third of the pixels the
 contract misses:
 
-    pixels outside the band, all reference fixtures (179,481 pixel-frames):   contract 787   |   llvmpipe's choices 145
+    pixels outside the band, all reference fixtures (179,481 pixel-frames):   contract 787   |   llvmpipe's choices 117
     (271 with a translation-first order guessed from the fixtures' statistics and the contract's sin / cos / exp / pow; 266 with llvmpipe's own,
     restated exactly; 145 with its exact mat4 * vec4 order, ((w + x) + z) + y, found by matching its primary rays BIT FOR BIT: 100.00 % of a frame's
-    origins and directions)
+    origins and directions; 117 with mix(x, y, a) = x + a (y - x) — probed: llvmpipe's form — and the cube filter as two nested lerps of that form)
+    and BIT FOR BIT equal to the reference in 88 % of the first frames' pixels (contract: 39 %)
     one choice at a time on top of llvmpipe's summation orders (743):  never fused 593, exact 1/x sqrt 1/sqrt 640, both 282, + literal division 271
 
 (on 600 random scenes of tools/ensemble_fuzz.py, build container only: 11 scenes with undefined behaviour in view — a camera inside a glass
@@ -36,8 +37,8 @@ _spec = importlib.util.spec_from_file_location("glsl_run", os.path.join(ROOT, "o
 ref = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(ref)
 
-NEVER_FUSED, EXACT_DIV_SQRT, LITERAL_DIVISION, MATVEC_W_FIRST, MATVEC_LLVMPIPE, DOT_X_PLUS_YZ, LLVM_MATH = 1, 2, 4, 1 << 3, 2 << 3, 1 << 5, 1 << 7
-LLVMPIPE = NEVER_FUSED | EXACT_DIV_SQRT | LITERAL_DIVISION | MATVEC_LLVMPIPE | DOT_X_PLUS_YZ | LLVM_MATH   # (LLVM_MATH: its sin, cos, exp, pow — exact, see the probe below)
+NEVER_FUSED, EXACT_DIV_SQRT, LITERAL_DIVISION, MATVEC_W_FIRST, MATVEC_LLVMPIPE, DOT_X_PLUS_YZ, LLVM_MATH, MIX_AS_LERP, SAMPLER_LERPS = 1, 2, 4, 1 << 3, 2 << 3, 1 << 5, 1 << 7, 1 << 8, 1 << 9
+LLVMPIPE = NEVER_FUSED | EXACT_DIV_SQRT | LITERAL_DIVISION | MATVEC_LLVMPIPE | DOT_X_PLUS_YZ | LLVM_MATH | MIX_AS_LERP | SAMPLER_LERPS   # (LLVM_MATH: its sin, cos, exp, pow — exact, see the probe below)
 
 
 @pytest.fixture(scope="module")
@@ -76,7 +77,7 @@ def test_llvmpipes_arithmetic_choices_close_two_thirds_of_the_gap(variants):
     print(f"\n  outside the band of {n} pixel-frames: contract {contract}, llvmpipe's summation orders only {orders_only}, all of llvmpipe's choices {llvmpipe}")
     assert n > 150000 and 600 <= contract <= 900          # (measured 787)
     assert orders_only <= contract                         # (743: the order alone helps a little under fused arithmetic)
-    assert llvmpipe <= 0.25 * contract                     # (145 = 0.18 x)
+    assert llvmpipe <= 0.2 * contract                      # (117 = 0.15 x)
 
 
 @pytest.mark.parametrize("name", fixtures.names("atmo_"))
@@ -154,3 +155,26 @@ def test_llvmpipes_builtins_as_restated_are_bit_identical_with_the_live_llvmpipe
     assert same(np.float32(1.0) / np.sqrt(w), b[..., 2]) == 1.0                       # inversesqrt = 1 / sqrt, two roundings
     assert same(img[..., 2] * w + img[..., 1], b[..., 3]) == 1.0                      # a * b + c: never fused
     assert same(np.sqrt(w), c[..., 0]) == 1.0 and same(np.float32(1.0) / w, c[..., 1]) == 1.0 and same(img[..., 2] / w, c[..., 2]) == 1.0
+
+
+def test_with_llvmpipes_choices_the_restatement_renders_the_references_bits(variants):
+    """The strongest form of "the oracle restates the reference's algorithm": evaluated with llvmpipe's arithmetic choices the SAME C code
+    reproduces the reference's first frames BIT FOR BIT in 88 % of the pixels (the contract, whose choices are the GPU's: 39 %; within 1e-6:
+    95.0 -> 99.5 %), and the environment-only frames in 78 - 94 %.  What is left are expression forms not yet matched; no pixel class is
+    systematically off."""
+    def bit_exact(bits):
+        variants.set_base_variant(bits)
+        same = n = 0
+        for name in fixtures.names("frame_"):
+            fx = fixtures.load(name)
+            if fx["env"].dtype == np.uint8:
+                continue  # (llvmpipe decodes sRGB8 with a cubic approximation)
+            got = variants.render(fx["width"], fx["height"], fx["basic"], fx["objects"], fx["env"], num_frames=1, **fixtures.kwargs(fx))[..., :3]
+            eq = (got.view(np.uint32) == fx["expected"][0].view(np.uint32)).all(-1)
+            same += int(eq.sum())
+            n += eq.size
+        variants.set_base_variant(0)
+        return same / n
+    contract, llvmpipe = bit_exact(0), bit_exact(LLVMPIPE)
+    print(f"\n  first frames bit for bit equal to the reference: contract {contract:.1%}, with llvmpipe's choices {llvmpipe:.1%}")
+    assert llvmpipe >= 0.8 and contract <= 0.5
