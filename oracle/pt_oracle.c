@@ -904,7 +904,7 @@ static v3 cosine_sample_hemisphere(v3 n, uint32_t *seed)
 /* compute.glsl:359-364 */
 static float fresnel_schlick(float cosTheta, float n1, float n2)
 {
-    float r0 = (n1 - n2) * f_rcp(n1 + n2);
+    float r0 = QUOT(n1 - n2, n1 + n2, f_rcp(n1 + n2)); /* (compute.glsl:361 divides; the contract multiplies by the reciprocal) */
     r0 *= r0;
     return fmaf(1.0f - r0, f_pow5(1.0f - cosTheta), r0);
 }
@@ -1106,6 +1106,12 @@ static void shade_pixel(const Ctx *c, int px, int py, int frame, const float *la
         float u0 = rand01(&seed), u1 = rand01(&seed); /* :113, x first */
         float ndcx = fmaf(((float)px + u0) * (1.0f / (float)c->width), 2.0f, -1.0f);  /* uniform 1/W, 1/H */
         float ndcy = fmaf(((float)py + u1) * (1.0f / (float)c->height), 2.0f, -1.0f);
+#ifdef PT_ORACLE_PERTURB
+        if (g_base_truediv) { /* (base variant: the literal / imgResultSize of compute.glsl:114 — llvmpipe divides) */
+            ndcx = fmaf(((float)px + u0) / (float)c->width, 2.0f, -1.0f);
+            ndcy = fmaf(((float)py + u1) / (float)c->height, 2.0f, -1.0f);
+        }
+#endif
         /* GetWorldSpaceRay :352-357 */
         float eye[4], wd[4];
         mat_vec(c->invProj, ndcx, ndcy, -1.0f, 0.0f, eye);
