@@ -640,7 +640,7 @@ static rgb sample_env(const Ctx *c, v3 d)
     rgb o;
 #ifdef PT_ORACLE_PERTURB
     if (g_base_sampler_lerp && !(miss00 || miss10 || miss01 || miss11)) { /* base variant bit 512: two nested lerps a + w (b - a), x first (llvmpipe's filter) */
-#define LERP_(a_, b_, w_) ((a_) + (w_) * ((b_) - (a_)))
+#define LERP_(a_, b_, w_) __builtin_fmaf((w_), (b_) - (a_), (a_)) /* (lp_build_lerp: a multiply-add of the sampler's own code, fused like the built-ins' polynomials) */
         o.r = LERP_(LERP_(t00.r, t10.r, wu), LERP_(t01.r, t11.r, wu), wv);
         o.g = LERP_(LERP_(t00.g, t10.g, wu), LERP_(t01.g, t11.g, wu), wv);
         o.b = LERP_(LERP_(t00.b, t10.b, wu), LERP_(t01.b, t11.b, wu), wv);

@@ -13,12 +13,13 @@ contract misses:
     restated exactly; 145 with its exact mat4 * vec4 order, ((w + x) + z) + y, found by matching its primary rays BIT FOR BIT: 100.00 % of a frame's
     origins and directions; 117 with mix(x, y, a) = x + a (y - x) — probed: llvmpipe's form — and the cube filter as two nested lerps of that form;
     49 with the literal divisions of compute.glsl:114 (/ imgResultSize) and :361 (Fresnel's r0) where the contract multiplies by reciprocals)
-    and BIT FOR BIT equal to the reference in 94 % of the first frames' pixels (contract: 39 %)
+    and BIT FOR BIT equal to the reference in 98.6 % of the first frames' pixels (contract: 39 %; 93.7 % before the filter's lerps were fused the
+    way llvmpipe's own code is — lp_build_lerp is a multiply-add of the driver, not of the shader)
     one choice at a time on top of llvmpipe's summation orders (743):  never fused 593, exact 1/x sqrt 1/sqrt 640, both 282, + literal division 271
 
 (on 600 random scenes of tools/ensemble_fuzz.py, build container only: 11 scenes with undefined behaviour in view — a camera inside a glass
 sphere and the like — hold 8,904 of the 12,995 pixels outside the band and do not move, 8,900; the other 589 scenes go 4,091 -> 2,753)
-i.e. on the reference's own scenes 94 %, on random scenes (measured with the first guess of the orders) a third of what separates the contract from the reference is these NAMED, conforming choices (the rest is NOT llvmpipe's exp / pow / sin / cos: restated exactly — bit-identical
+i.e. on the reference's own scenes 94 % (and 98.6 % of the pixels to the last bit), on random scenes (measured with the first guess of the orders) a third of what separates the contract from the reference is these NAMED, conforming choices (the rest is NOT llvmpipe's exp / pow / sin / cos: restated exactly — bit-identical
 with the live llvmpipe, last test — they move 271 to 266; it is the evaluation order of the remaining expressions, the sampler, and chaos).  The contract keeps its choices because the integrator is VALU-issue-bound
 (DESIGN 3.6): unfused multiply-adds and IEEE division / square root (43 / 52 issue cycles on gfx950) would cost a quarter of the speed
 for 0.3 points of agreement with ONE other conforming implementation.  This test pins the measurement."""
@@ -160,8 +161,8 @@ def test_llvmpipes_builtins_as_restated_are_bit_identical_with_the_live_llvmpipe
 
 def test_with_llvmpipes_choices_the_restatement_renders_the_references_bits(variants):
     """The strongest form of "the oracle restates the reference's algorithm": evaluated with llvmpipe's arithmetic choices the SAME C code
-    reproduces the reference's first frames BIT FOR BIT in 94 % of the pixels (the contract, whose choices are the GPU's: 39 %; within 1e-6:
-    95.0 -> 99.97 %), and the environment-only frames in 81 - 97 %.  What is left are expression forms not yet matched; no pixel class is
+    reproduces the reference's first frames BIT FOR BIT in 98.6 % of the pixels (the contract, whose choices are the GPU's: 39 %; within 1e-6:
+    95.0 -> 99.97 %), and the environment-only frames in 92 - 99 %.  What is left are expression forms not yet matched; no pixel class is
     systematically off."""
     def bit_exact(bits):
         variants.set_base_variant(bits)
@@ -178,4 +179,4 @@ def test_with_llvmpipes_choices_the_restatement_renders_the_references_bits(vari
         return same / n
     contract, llvmpipe = bit_exact(0), bit_exact(LLVMPIPE)
     print(f"\n  first frames bit for bit equal to the reference: contract {contract:.1%}, with llvmpipe's choices {llvmpipe:.1%}")
-    assert llvmpipe >= 0.9 and contract <= 0.5
+    assert llvmpipe >= 0.97 and contract <= 0.5
