@@ -18,8 +18,8 @@ contract misses:
     one choice at a time on top of llvmpipe's summation orders (743):  never fused 593, exact 1/x sqrt 1/sqrt 640, both 282, + literal division 271
 
 (on 600 random scenes of tools/ensemble_fuzz.py, build container only: 11 scenes with undefined behaviour in view — a camera inside a glass
-sphere and the like — hold 8,904 of the 12,995 pixels outside the band and do not move, 8,900; the other 589 scenes go 4,091 -> 2,753)
-i.e. on the reference's own scenes 94 % (and 98.6 % of the pixels to the last bit), on random scenes (measured with the first guess of the orders) a third of what separates the contract from the reference is these NAMED, conforming choices (the rest is NOT llvmpipe's exp / pow / sin / cos: restated exactly — bit-identical
+sphere and the like — hold 8,904 of the 12,995 pixels outside the band and do not move, 8,900; the other 589 scenes go 4,091 -> 2,326)
+i.e. on the reference's own scenes 94 % (and 98.6 % of the pixels to the last bit), on random scenes 43 % of what separates the contract from the reference is these NAMED, conforming choices (the rest is NOT llvmpipe's exp / pow / sin / cos: restated exactly — bit-identical
 with the live llvmpipe, last test — they move 271 to 266; it is the evaluation order of the remaining expressions, the sampler, and chaos).  The contract keeps its choices because the integrator is VALU-issue-bound
 (DESIGN 3.6): unfused multiply-adds and IEEE division / square root (43 / 52 issue cycles on gfx950) would cost a quarter of the speed
 for 0.3 points of agreement with ONE other conforming implementation.  This test pins the measurement."""

@@ -98,7 +98,7 @@ for case in range(cases):
     d_ref = ens._band_distance(expected, base[0][..., :3], band)
     outside = d_ref > 1.0
     # the same scene under llvmpipe's own arithmetic choices (tests/test_arithmetic_choices.py): how much of the gap do they explain here?
-    members.set_base_variant(47)
+    members.set_base_variant(951)
     like = members.render(W, H, basic, sc.ubo_bytes(), env, **kw)[..., :3]
     members.set_base_variant(0)
     n_like = int((ens._band_distance(expected, like, band) > 1.0).sum())
