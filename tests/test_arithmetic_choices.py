@@ -15,7 +15,8 @@ contract misses:
     49 with the literal divisions of compute.glsl:114 (/ imgResultSize) and :361 (Fresnel's r0) where the contract multiplies by reciprocals)
     and BIT FOR BIT equal to the reference in 98.6 % of the first frames' pixels (contract: 39 %; 93.7 % before the filter's lerps were fused the
     way llvmpipe's own code is — lp_build_lerp is a multiply-add of the driver, not of the shader)
-    one choice at a time on top of llvmpipe's summation orders (743):  never fused 593, exact 1/x sqrt 1/sqrt 640, both 282, + literal division 271
+    cumulatively, cheapest first: orders + mix form + filter lerps (free on the GPU) 740, + literal divisions 732, + exact 1/x sqrt 1/sqrt 593,
+    + NEVER FUSED 61, + llvmpipe's sin cos exp pow 49 — the gap is, above all, the fused multiply-add
 
 (on 600 random scenes of tools/ensemble_fuzz.py, build container only: 11 scenes with undefined behaviour in view — a camera inside a glass
 sphere and the like — hold 8,904 of the 12,995 pixels outside the band and do not move, 8,900; the other 589 scenes go 4,091 -> 2,326)
