@@ -1,29 +1,28 @@
 """Layer-2 parity, explained by NAME (round 6): which arithmetic choices separate the pt-f32 contract from the reference's run on llvmpipe.
 
-GLSL leaves open whether a * b + c is fused, how accurate 1/x, sqrt and inversesqrt are, whether a / b is a division or a product with a
-reciprocal, and in which order a dot product's three and a matrix-vector product's four terms are summed.  The contract (oracle/pt_oracle.c,
-csrc/pt_math.hpp) chose for the GPU: fused chains, Newton sequences (<= 0.5 / 1.7 ulp), reciprocals, x-y-z(-w) order.  llvmpipe chose for
-x86: never fused, correctly rounded divps / sqrtps, literal divisions, and — found with the ensemble members' re-association
-(tests/test_ensemble_stability.py, tools/ensemble_fuzz.py) — x + (y + z) for dot products and the translation column first for mat4 * vec4.
-The oracle's witness build can BE that implementation (pto_set_base_variant, bits below), and then it misses a third of the pixels the
-contract misses:
+GLSL leaves open whether a * b + c is fused, how accurate 1/x, sqrt, inversesqrt, sin, cos, exp, pow are, whether a / b is a division or a
+product with a reciprocal, which algebraic form mix() takes, and in which order a dot product's three and a matrix-vector product's four
+terms are summed.  The contract (oracle/pt_oracle.c, csrc/pt_math.hpp) chose for the GPU: fused chains, Newton sequences (<= 0.5 / 1.7
+ulp), reciprocals, x-y-z(-w) order, x (1 - a) + y a.  What llvmpipe chose was MEASURED here, in the build container, by running GLSL on
+the live llvmpipe through oracle/_ref/glsl_runner (own test mains; intermediate values of an instrumented scratch copy of the reference's
+shader): a * b + c in shader code never fused; a / b, 1 / x, sqrt correctly rounded; inversesqrt(x) = 1 / sqrt(x); mix = x + a (y - x); dot
+products x x + (y y + z z); mat4 * vec4 = ((w + x) + z) + y by columns (a frame's primary rays then match bit for bit: 100.00 % of origins and
+directions); the cube filter two nested fused lerps; and its sin, cos, exp, pow as Mesa's gallivm evaluates them — restated from the
+published algorithm and BIT-IDENTICAL with the live llvmpipe on 65,536 arguments each (last test).
 
-    pixels outside the band, all reference fixtures (179,481 pixel-frames):   contract 787   |   llvmpipe's choices 49
-    (271 with a translation-first order guessed from the fixtures' statistics and the contract's sin / cos / exp / pow; 266 with llvmpipe's own,
-    restated exactly; 145 with its exact mat4 * vec4 order, ((w + x) + z) + y, found by matching its primary rays BIT FOR BIT: 100.00 % of a frame's
-    origins and directions; 117 with mix(x, y, a) = x + a (y - x) — probed: llvmpipe's form — and the cube filter as two nested lerps of that form;
-    49 with the literal divisions of compute.glsl:114 (/ imgResultSize) and :361 (Fresnel's r0) where the contract multiplies by reciprocals)
-    and BIT FOR BIT equal to the reference in 98.6 % of the first frames' pixels (contract: 39 %; 93.7 % before the filter's lerps were fused the
-    way llvmpipe's own code is — lp_build_lerp is a multiply-add of the driver, not of the shader)
-    cumulatively, cheapest first: orders + mix form + filter lerps (free on the GPU) 740, + literal divisions 732, + exact 1/x sqrt 1/sqrt 593,
-    + NEVER FUSED 61, + llvmpipe's sin cos exp pow 49 — the gap is, above all, the fused multiply-add
+The oracle's witness build can BE that implementation (pto_set_base_variant, bits below).  Then the SAME C restatement
 
-(on 600 random scenes of tools/ensemble_fuzz.py, build container only: 11 scenes with undefined behaviour in view — a camera inside a glass
-sphere and the like — hold 8,904 of the 12,995 pixels outside the band and do not move, 8,900; the other 589 scenes go 4,091 -> 2,326)
-i.e. on the reference's own scenes 94 % (and 98.6 % of the pixels to the last bit), on random scenes 43 % of what separates the contract from the reference is these NAMED, conforming choices (the rest is NOT llvmpipe's exp / pow / sin / cos: restated exactly — bit-identical
-with the live llvmpipe, last test — they move 271 to 266; it is the evaluation order of the remaining expressions, the sampler, and chaos).  The contract keeps its choices because the integrator is VALU-issue-bound
-(DESIGN 3.6): unfused multiply-adds and IEEE division / square root (43 / 52 issue cycles on gfx950) would cost a quarter of the speed
-for 0.3 points of agreement with ONE other conforming implementation.  This test pins the measurement."""
+    misses 49 instead of 787 of the fixtures' 179,481 pixel-frames                          (outside the band 1e-4 max(1, |ref|))
+    equals the reference BIT FOR BIT in 98.6 % of the first frames' pixels                   (contract 38.8 %; every dump incl. accumulated: 98.2 %)
+    cumulatively, cheapest first:  contract 787 -> summation orders + mix form + filter lerps (free on the GPU) 740 -> literal divisions 732
+                                   -> exact 1/x sqrt 1/sqrt 593 -> NEVER FUSED 61 -> llvmpipe's sin cos exp pow 49
+
+which is the strongest available form of "the oracle restates the reference's algorithm": no pixel class is systematically off, and what
+separates the two is, above all, the fused multiply-add.  (On 600 random scenes of tools/ensemble_fuzz.py: 11 scenes with undefined
+behaviour in view hold 8,904 of the 12,995 out-of-band pixels and do not move; the other 589 go 4,091 -> 2,326.)  The contract keeps its
+choices because the integrator is VALU-issue-bound: unfused multiply-adds and IEEE division / square root (43 / 52 issue
+cycles on gfx950) would cost about a quarter of the speed for 0.4 points of agreement with ONE other conforming implementation.  These
+tests pin the measurements."""
 import ctypes as C
 import importlib.util
 import os
